@@ -1,0 +1,286 @@
+"""fp32 CPU restatement of the UNet / VAE the reference calls across its
+drop-in boundary.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+PARITY UNPINNED: the arithmetic lives in diffusers ~= 0.16.0
+(reference pyproject.toml:22), absent from /root/reference; call sites are
+  gyre/pipeline/unet/core.py:262-274      unet(latents, t, encoder_hidden_states=...).sample
+  gyre/pipeline/unified_pipeline.py:309   vae.encode(image).latent_dist
+  gyre/pipeline/unified_pipeline.py:1531  vae.decode(latents).sample
+Topology / hyper-parameters follow gyre/ldm_config/v1-inference.yaml:29-64 and
+the diffusers key names consumed by gyre/ckpt_utils.py:259-285.
+
+Everything is plain ``torch.nn.functional`` over a flat ``{diffusers_key: tensor}``
+dict, i.e. the same ATen ops the reference's CPU path dispatches to
+(conv2d, group_norm, linear, baddbmm+softmax, layer_norm, gelu, silu,
+interpolate) - which is why this file doubles as the reported CPU baseline.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# configs (mirrors of diffusers config.json fields the reference reads:
+# unified_pipeline.py:186 in_channels, :1318 sample_size, :1402 block_out_channels)
+# --------------------------------------------------------------------------
+@dataclass
+class UNetRefConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    # per level: does the level carry Transformer2D blocks
+    attn_levels: Tuple[bool, ...] = (True, True, True, False)
+    num_heads: Tuple[int, ...] = (8, 8, 8, 8)  # SD1.x "attention_head_dim: 8" is really num_heads
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    transformer_depth: Tuple[int, ...] = (1, 1, 1, 1)
+    use_linear_projection: bool = False
+    sample_size: int = 64
+    flip_sin_to_cos: bool = True
+    freq_shift: float = 0.0
+
+
+@dataclass
+class VAERefConfig:
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def _gn(x: Tensor, sd: SD, p: str, groups: int, eps: float) -> Tensor:
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _conv(x: Tensor, sd: SD, p: str, stride: int = 1, padding: int = 1) -> Tensor:
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+
+
+def _lin(x: Tensor, sd: SD, p: str) -> Tensor:
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0) -> Tensor:
+    """diffusers.models.embeddings.get_timestep_embedding [3P]; SD uses
+    flip_sin_to_cos=True, downscale_freq_shift=0 -> [cos, sin] order."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device)
+    exponent = exponent / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def resnet_block(x: Tensor, temb: Optional[Tensor], sd: SD, p: str, groups: int, eps: float) -> Tensor:
+    """ResnetBlock2D [3P]: GN+SiLU+conv3x3 (+temb) GN+SiLU+conv3x3 + shortcut."""
+    h = F.silu(_gn(x, sd, p + ".norm1", groups, eps))
+    h = _conv(h, sd, p + ".conv1")
+    if temb is not None and (p + ".time_emb_proj.weight") in sd:
+        h = h + _lin(F.silu(temb), sd, p + ".time_emb_proj")[:, :, None, None]
+    h = F.silu(_gn(h, sd, p + ".norm2", groups, eps))
+    h = _conv(h, sd, p + ".conv2")
+    if (p + ".conv_shortcut.weight") in sd:
+        x = _conv(x, sd, p + ".conv_shortcut", padding=0)
+    return x + h
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
+    """[B,N,h*d] -> [B*h,N,d], softmax(q k^T * d^-1/2) v, no mask.  Same reshape /
+    scale as reference gyre/pipeline/models/memory_efficient_cross_attention.py:32-60."""
+    B, Nq, C = q.shape
+    d = C // heads
+
+    def split(t):
+        return t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], d)
+
+    q, k, v = split(q), split(k), split(v)
+    scores = torch.baddbmm(
+        torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device),
+        q, k.transpose(1, 2), beta=0, alpha=d ** -0.5)
+    probs = scores.softmax(dim=-1)
+    out = torch.bmm(probs, v)
+    return out.reshape(B, heads, Nq, d).permute(0, 2, 1, 3).reshape(B, Nq, C)
+
+
+def basic_transformer_block(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int) -> Tensor:
+    """BasicTransformerBlock [3P]: LN+self-attn, LN+cross-attn, LN+GEGLU-FF (erf gelu)."""
+    C = x.shape[-1]
+    h = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+    a = attention(_lin(h, sd, p + ".attn1.to_q"), _lin(h, sd, p + ".attn1.to_k"),
+                  _lin(h, sd, p + ".attn1.to_v"), heads)
+    x = x + _lin(a, sd, p + ".attn1.to_out.0")
+    h = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+    a = attention(_lin(h, sd, p + ".attn2.to_q"), _lin(ctx, sd, p + ".attn2.to_k"),
+                  _lin(ctx, sd, p + ".attn2.to_v"), heads)
+    x = x + _lin(a, sd, p + ".attn2.to_out.0")
+    h = F.layer_norm(x, (C,), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"], 1e-5)
+    h = _lin(h, sd, p + ".ff.net.0.proj")
+    val, gate = h.chunk(2, dim=-1)
+    h = val * F.gelu(gate)
+    x = x + _lin(h, sd, p + ".ff.net.2")
+    return x
+
+
+def transformer_2d(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int, groups: int, depth: int,
+                   linear_proj: bool) -> Tensor:
+    """Transformer2DModel [3P]: GN(eps 1e-6), proj_in, blocks, proj_out, + residual."""
+    B, C, H, W = x.shape
+    res = x
+    h = _gn(x, sd, p + ".norm", groups, 1e-6)
+    if not linear_proj:
+        h = _conv(h, sd, p + ".proj_in", padding=0)
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    else:
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = _lin(h, sd, p + ".proj_in")
+    for d in range(depth):
+        h = basic_transformer_block(h, ctx, sd, f"{p}.transformer_blocks.{d}", heads)
+    if not linear_proj:
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        h = _conv(h, sd, p + ".proj_out", padding=0)
+    else:
+        h = _lin(h, sd, p + ".proj_out")
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return h + res
+
+
+# --------------------------------------------------------------------------
+# UNet2DConditionModel forward
+# --------------------------------------------------------------------------
+def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder_hidden_states: Tensor,
+                 taps: Optional[dict] = None) -> Tensor:
+    """eps = unet(latents[NCHW], t[int64 N], ctx[N,S,D]).  ``taps`` (optional dict)
+    receives named intermediate activations for block-level parity tests."""
+    g, eps = cfg.norm_num_groups, 1e-5
+    boc = cfg.block_out_channels
+    if t.ndim == 0:
+        t = t[None].expand(latents.shape[0])
+    temb = timestep_embedding(t, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift).to(latents.dtype)
+    temb = _lin(temb, sd, "time_embedding.linear_1")
+    temb = _lin(F.silu(temb), sd, "time_embedding.linear_2")
+    if taps is not None:
+        taps["temb"] = temb
+
+    h = _conv(latents, sd, "conv_in")
+    skips: List[Tensor] = [h]
+    nlev = len(boc)
+    for i in range(nlev):
+        for j in range(cfg.layers_per_block):
+            h = resnet_block(h, temb, sd, f"down_blocks.{i}.resnets.{j}", g, eps)
+            if cfg.attn_levels[i]:
+                h = transformer_2d(h, encoder_hidden_states, sd, f"down_blocks.{i}.attentions.{j}",
+                                   cfg.num_heads[i], g, cfg.transformer_depth[i], cfg.use_linear_projection)
+            skips.append(h)
+        if i < nlev - 1:
+            h = _conv(h, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
+            skips.append(h)
+        if taps is not None:
+            taps[f"down{i}"] = h
+
+    h = resnet_block(h, temb, sd, "mid_block.resnets.0", g, eps)
+    h = transformer_2d(h, encoder_hidden_states, sd, "mid_block.attentions.0", cfg.num_heads[-1], g,
+                       cfg.transformer_depth[-1], cfg.use_linear_projection)
+    h = resnet_block(h, temb, sd, "mid_block.resnets.1", g, eps)
+    if taps is not None:
+        taps["mid"] = h
+
+    for i in range(nlev):
+        lvl = nlev - 1 - i
+        for j in range(cfg.layers_per_block + 1):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = resnet_block(h, temb, sd, f"up_blocks.{i}.resnets.{j}", g, eps)
+            if cfg.attn_levels[lvl]:
+                h = transformer_2d(h, encoder_hidden_states, sd, f"up_blocks.{i}.attentions.{j}",
+                                   cfg.num_heads[lvl], g, cfg.transformer_depth[lvl], cfg.use_linear_projection)
+        if i < nlev - 1:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv(h, sd, f"up_blocks.{i}.upsamplers.0.conv")
+        if taps is not None:
+            taps[f"up{i}"] = h
+
+    h = F.silu(_gn(h, sd, "conv_norm_out", g, eps))
+    return _conv(h, sd, "conv_out")
+
+
+# --------------------------------------------------------------------------
+# AutoencoderKL
+# --------------------------------------------------------------------------
+def _vae_attn(x: Tensor, sd: SD, p: str, groups: int) -> Tensor:
+    """diffusers 0.16 AttentionBlock (1 head, d=C) [3P].  Accepts both the 0.16 key
+    names (group_norm/query/key/value/proj_attn) and the later to_q/... names."""
+    B, C, H, W = x.shape
+    names = ("group_norm", "query", "key", "value", "proj_attn")
+    if (p + ".to_q.weight") in sd:
+        names = ("group_norm", "to_q", "to_k", "to_v", "to_out.0")
+    h = _gn(x, sd, f"{p}.{names[0]}", groups, 1e-6)
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    q, k, v = (_lin(h, sd, f"{p}.{n}") for n in names[1:4])
+    a = attention(q, k, v, 1)
+    a = _lin(a, sd, f"{p}.{names[4]}")
+    return x + a.reshape(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def _vae_mid(h: Tensor, sd: SD, p: str, groups: int) -> Tensor:
+    h = resnet_block(h, None, sd, p + ".resnets.0", groups, 1e-6)
+    h = _vae_attn(h, sd, p + ".attentions.0", groups)
+    return resnet_block(h, None, sd, p + ".resnets.1", groups, 1e-6)
+
+
+def vae_encode_moments(sd: SD, cfg: VAERefConfig, image: Tensor) -> Tensor:
+    """image [B,3,H,W] in -1..1 -> moments [B,2*z,H/8,W/8] (mean | logvar)."""
+    g = cfg.norm_num_groups
+    boc = cfg.block_out_channels
+    h = _conv(image, sd, "encoder.conv_in")
+    for i in range(len(boc)):
+        for j in range(cfg.layers_per_block):
+            h = resnet_block(h, None, sd, f"encoder.down_blocks.{i}.resnets.{j}", g, 1e-6)
+        if i < len(boc) - 1:
+            h = F.pad(h, (0, 1, 0, 1))  # asymmetric pad, stride-2 conv pad 0 [3P Downsample2D]
+            h = _conv(h, sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+    h = _vae_mid(h, sd, "encoder.mid_block", g)
+    h = F.silu(_gn(h, sd, "encoder.conv_norm_out", g, 1e-6))
+    h = _conv(h, sd, "encoder.conv_out")
+    return _conv(h, sd, "quant_conv", padding=0)
+
+
+def vae_posterior_sample(moments: Tensor, generator: Optional[torch.Generator]) -> Tensor:
+    """DiagonalGaussianDistribution.sample [3P]: mean + exp(0.5*clamp(logvar,-30,20)) * randn."""
+    mean, logvar = moments.chunk(2, dim=1)
+    std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+    noise = torch.randn(mean.shape, generator=generator, dtype=mean.dtype,
+                        device=generator.device if generator is not None else mean.device)
+    return mean + std * noise.to(mean.device)
+
+
+def vae_decode(sd: SD, cfg: VAERefConfig, z: Tensor) -> Tensor:
+    """latents [B,4,h,w] (already divided by the scaling factor) -> image [B,3,8h,8w]."""
+    g = cfg.norm_num_groups
+    boc = list(reversed(cfg.block_out_channels))
+    h = _conv(z, sd, "post_quant_conv", padding=0)
+    h = _conv(h, sd, "decoder.conv_in")
+    h = _vae_mid(h, sd, "decoder.mid_block", g)
+    for i in range(len(boc)):
+        for j in range(cfg.layers_per_block + 1):
+            h = resnet_block(h, None, sd, f"decoder.up_blocks.{i}.resnets.{j}", g, 1e-6)
+        if i < len(boc) - 1:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv(h, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+    h = F.silu(_gn(h, sd, "decoder.conv_norm_out", g, 1e-6))
+    return _conv(h, sd, "decoder.conv_out")

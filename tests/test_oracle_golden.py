@@ -1,0 +1,124 @@
+"""Pins the oracle's reference-owned arithmetic against vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import sched_ref as S
+
+
+def gens(seeds):
+    return [torch.Generator().manual_seed(int(s)) for s in seeds]
+
+
+def test_batched_rng(golden):
+    seeds = golden["rng_seeds"]
+    assert np.array_equal(S.batched_randn([2, 4, 8, 8], gens(seeds)).numpy(), golden["randn_2x4x8x8"])
+    assert np.array_equal(S.batched_rand([2, 4, 8, 8], gens(seeds)).numpy(), golden["rand_2x4x8x8"])
+    head = S.batched_randn([1, 4, 64, 64], gens([420420420])).flatten()[:16].numpy()
+    assert np.array_equal(head, golden["randn_seed420420420_1x4x64x64_head"])
+    # SURVEY 8c quotes these first values for seed 420420420
+    assert np.allclose(head[:4], [0.0673095, -1.1366724, -0.3092880, 0.3905116], atol=1e-6)
+
+
+def test_batch_independence_of_rng():
+    a = S.batched_randn([2, 4, 8, 8], gens([5, 6]))
+    b = S.batched_randn([1, 4, 8, 8], gens([6]))
+    assert torch.equal(a[1:], b)
+
+
+def test_sigma_tables(golden):
+    betas = S.get_betas()
+    assert np.array_equal(betas.numpy(), golden["betas"])
+    ac = S.get_alphas_cumprod(betas)
+    assert np.array_equal(ac.numpy(), golden["alphas_cumprod"])
+    sch = S.DiscreteScheduleRef(ac)
+    assert np.allclose([float(sch.sigma_min), float(sch.sigma_max)], golden["sigma_min_max"], rtol=1e-6)
+    assert abs(float(sch.sigma_min) - 0.029168) < 1e-5 and abs(float(sch.sigma_max) - 14.614647) < 1e-4
+    for n in (20, 50):
+        sig = sch.get_sigmas(n)
+        assert np.array_equal(sig.numpy(), golden[f"sigmas_n{n}"])
+        assert np.array_equal(sch.sigma_to_t(sig[:-1]).numpy(), golden[f"sigma_to_t_n{n}"])
+
+
+def test_dpmpp_2m(golden):
+    seeds = golden["rng_seeds"]
+    for n in (20, 50):
+        calls = []
+
+        def toy(x, sigma):
+            calls.append(float(sigma[0]))
+            return x / (1 + sigma.view(-1, 1, 1, 1) ** 2)
+
+        sigmas = torch.from_numpy(golden[f"sigmas_n{n}"])
+        x0 = S.batched_randn([2, 4, 8, 8], gens(seeds)) * sigmas[0]
+        x = S.sample_dpmpp_2m(toy, x0, sigmas, warmup_lms=True, ddim_cutoff=0.1)
+        assert len(calls) == int(golden[f"dpmpp2m_n{n}_evals"]) == n + 1
+        assert np.allclose(calls, golden[f"dpmpp2m_n{n}_eval_sigmas"], rtol=0, atol=0)
+        assert np.array_equal(x.numpy(), golden[f"dpmpp2m_n{n}_x"])
+        x = S.sample_dpmpp_2m(toy, x0, sigmas)
+        assert np.array_equal(x.numpy(), golden[f"dpmpp2m_plain_n{n}_x"])
+
+
+def _fake_f(seen):
+    def f(latents, t):
+        seen["shape"] = tuple(latents.shape)
+        seen["t"] = t.clone()
+        w = torch.arange(1, latents.shape[0] + 1, dtype=latents.dtype).view(-1, 1, 1, 1)
+        return latents * w + t.view(-1, 1, 1, 1).to(latents.dtype) * 0.001
+    return f
+
+
+def test_cfg(golden):
+    seen = {}
+    f = _fake_f(seen)
+    lat = torch.from_numpy(golden["cfg_in"])
+    t = torch.from_numpy(golden["cfg_t"])
+    out = S.cfg_parallel(f, 7.5)(lat, t)
+    assert np.array_equal(out.numpy(), golden["cfg_parallel_out"])
+    assert list(seen["shape"]) == list(golden["cfg_parallel_call_shape"])
+    assert np.array_equal(seen["t"].numpy(), golden["cfg_parallel_call_t"])
+    out = S.cfg_sequential(lambda l, tt: f(l, tt) * 2.0, lambda l, tt: f(l, tt) * 0.5, 7.5)(lat, t)
+    assert np.array_equal(out.numpy(), golden["cfg_sequential_out"])
+
+
+def test_txt2img_latents(golden):
+    seeds = golden["rng_seeds"]
+    for name, (lh, lw) in {"512x512": (64, 64), "512x768": (64, 96), "256x256": (32, 32), "256x768": (32, 96)}.items():
+        lt = S.txt2img_latents(gens(seeds), 4, lh, lw, 64, torch.tensor(14.5))
+        assert list(lt.shape) == list(golden[f"txt2img_{name}_shape"])
+        assert np.array_equal(lt[:, :, ::7, ::5].numpy(), golden[f"txt2img_{name}_sample"])
+        assert abs(lt.double().sum().item() - float(golden[f"txt2img_{name}_sum"])) < 1e-9
+        assert abs(lt.double().abs().sum().item() - float(golden[f"txt2img_{name}_abs_sum"])) < 1e-9
+
+
+def test_mask_helpers(golden):
+    mask = torch.from_numpy(golden["mask_in"])
+    assert np.array_equal(S.downscale_boxop_2d(mask, 8, "min").numpy(), golden["mask_boxmin"])
+    assert np.array_equal(S.downscale_boxop_2d(mask, 8, "max").numpy(), golden["mask_boxmax"])
+    assert np.array_equal(S.mask_to_latent_mask(mask).numpy(), golden["mask_latent"])
+    soft = torch.from_numpy(golden["mask_soft"])
+    assert np.array_equal(S.round_mask(soft).numpy(), golden["mask_round"])
+    assert np.array_equal(S.round_mask(soft, 0.001).numpy(), golden["mask_round_high"])
+    assert np.array_equal(S.round_mask(soft, 0.999).numpy(), golden["mask_round_low"])
+
+
+def test_euler_ancestral_matches_intree_witness():
+    """k-diffusion's Euler-a [3P] vs the arithmetic of the reference's in-tree witness
+    (kschedulers/scheduling_euler_ancestral_discrete.py:132-150), restated inline."""
+    sch = S.DiscreteScheduleRef()
+    sigmas = sch.get_sigmas(20)
+    toy = lambda x, s: x / (1 + s.view(-1, 1, 1, 1) ** 2)
+    g1, g2 = gens([3, 4]), gens([3, 4])
+    x0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0)) * sigmas[0]
+    a = S.sample_euler_ancestral(toy, x0, sigmas, lambda s, sn: S.batched_randn([2, 4, 8, 8], g1))
+    x = x0.clone()
+    for i in range(20):
+        sf, st = sigmas[i], sigmas[i + 1]
+        eps = (x - toy(x, sf * x.new_ones(2))) / sf  # model_output in the witness' epsilon form
+        pred = x - sf * eps
+        up = (st ** 2 * (sf ** 2 - st ** 2) / sf ** 2) ** 0.5
+        down = (st ** 2 - up ** 2) ** 0.5
+        x = x + (x - pred) / sf * (down - sf)
+        if st > 0:
+            x = x + S.batched_randn([2, 4, 8, 8], g2) * up
+    assert torch.allclose(a, x, atol=1e-5)
