@@ -1,0 +1,132 @@
+"""ctypes binding of libgyre_hip.so (C ABI: include/gyre_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, every entry
+point raises.  A silent PyTorch/CPU path would void the parity claims.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first: maps torch's libamdhip64.so.7, which our .so then shares)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgyre_hip.so")
+MAX_LEVELS = 8
+
+F32, BF16, F16 = 0, 1, 2
+_TORCH_DTYPE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+class GyreError(RuntimeError):
+    pass
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("n_levels", C.c_int32),
+                ("block_out_channels", C.c_int32 * MAX_LEVELS), ("layers_per_block", C.c_int32),
+                ("attn_levels", C.c_int32 * MAX_LEVELS), ("num_heads", C.c_int32 * MAX_LEVELS),
+                ("transformer_depth", C.c_int32 * MAX_LEVELS), ("cross_attention_dim", C.c_int32),
+                ("norm_num_groups", C.c_int32), ("use_linear_projection", C.c_int32),
+                ("flip_sin_to_cos", C.c_int32), ("freq_shift", C.c_float)]
+
+
+class VAECfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("latent_channels", C.c_int32),
+                ("n_levels", C.c_int32), ("block_out_channels", C.c_int32 * MAX_LEVELS),
+                ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32)]
+
+
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+_SIGS = {
+    "gyre_abi_version": (C.c_int, []),
+    "gyre_last_error": (C.c_char_p, []),
+    "gyre_last_launch_count": (C.c_int64, []),
+    "gyre_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(_vp)]),
+    "gyre_unet_destroy": (None, [_vp]),
+    "gyre_unet_num_params": (_i, [_vp]),
+    "gyre_unet_param_key": (C.c_char_p, [_vp, _i]),
+    "gyre_unet_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "gyre_unet_finalize": (_i, [_vp, _vp]),
+    "gyre_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "gyre_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
+    "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
+    "gyre_vae_destroy": (None, [_vp]),
+    "gyre_vae_num_params": (_i, [_vp]),
+    "gyre_vae_param_key": (C.c_char_p, [_vp, _i]),
+    "gyre_vae_set_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "gyre_vae_finalize": (_i, [_vp, _vp]),
+    "gyre_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "gyre_vae_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
+    "gyre_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
+    "gyre_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
+    "gyre_op_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
+    "gyre_op_layernorm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp]),
+    "gyre_op_linear": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "gyre_op_linear_t": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "gyre_op_conv3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "gyre_op_repack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gyre_op_repack_linear_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gyre_op_repack_bias": (_i, [_vp, _vp, _i, _i, _vp]),
+    "gyre_op_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "gyre_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gyre_op_copy_probe": (_i, [_vp, _vp, _vp, _sz]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library.  Raises GyreError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GyreError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"(hipcc --offload-arch=gfx950).  There is no non-HIP fallback.")
+        try:
+            l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover
+            raise GyreError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.gyre_abi_version() != 1:
+            raise GyreError("libgyre_hip ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+_EXC = {-1: ValueError, -2: KeyError, -3: GyreError, -4: GyreError, -5: GyreError, -6: NotImplementedError}
+
+
+def check(rc: int) -> None:
+    """Map a gyre_status to the Python exception the reference's error plumbing expects
+    (services/exception_to_grpc: NotImplementedError -> UNIMPLEMENTED, ValueError -> generic)."""
+    if rc != 0:
+        msg = lib().gyre_last_error().decode(errors="replace")
+        raise _EXC.get(rc, GyreError)(f"libgyre_hip: {msg} (status {rc})")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _TORCH_DTYPE[t.dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {t.dtype}; use float32, bfloat16 or float16") from None
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise GyreError(f"{name} must live on the GPU: the native path has no CPU fallback (got {t.device})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")

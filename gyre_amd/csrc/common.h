@@ -1,0 +1,58 @@
+// Shared device/host helpers for libgyre_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all activations are NHWC bf16
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define GYRE_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+    f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// load one element of a boundary tensor of runtime dtype (0 f32, 1 bf16, 2 f16)
+__device__ __forceinline__ float load_as_f32(const void* p, int dtype, size_t i) {
+    if (dtype == 0) return ((const float*)p)[i];
+    if (dtype == 1) return bf16_to_f32(((const bf16_t*)p)[i]);
+    return __half2float(((const __half*)p)[i]);
+}
+__device__ __forceinline__ void store_from_f32(void* p, int dtype, size_t i, float v) {
+    if (dtype == 0) ((float*)p)[i] = v;
+    else if (dtype == 1) ((bf16_t*)p)[i] = f32_to_bf16(v);
+    else ((__half*)p)[i] = __float2half(v);
+}
+
+// ---- host side error plumbing (thread-local message, int status; nothing throws) ----
+void gyre_set_error(const std::string& msg);
+int64_t& gyre_launch_counter();
+#define GYRE_FAIL(code, msg) do { gyre_set_error(std::string(msg)); return (code); } while (0)
+#define GYRE_HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    gyre_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return -5; } } while (0)
+#define GYRE_LAUNCH_CHECK() do { gyre_launch_counter()++; hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    gyre_set_error(std::string("kernel launch: ") + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
+    return -5; } } while (0)

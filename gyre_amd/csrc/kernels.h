@@ -1,0 +1,69 @@
+// Host-side launchers of the hand-written gfx950 kernels.  All enqueue on `st`
+// and return 0 / negative gyre_status (message via gyre_last_error()).
+#pragma once
+#include "common.h"
+
+// ---- layout / small ops (kernels_elem.hip) ----------------------------------
+int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
+int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_t* y);
+int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);
+// out[b][n] = act(sum_k x[b][k] * W[n][k] + bias[n]); x f32 [B][K], W bf16 [N][K], out f32 [B][ldo] (+col offset)
+int launch_rowvec_linear(hipStream_t st, const float* x, int B, int K, const bf16_t* W, const float* bias, int N,
+                         int act_in_silu, float* out, int ldo);
+
+// GroupNorm over NHWC bf16, optional second source for the skip-concat case:
+// channels [0,C1) come from x (pixel stride C1), [C1,C) from x2 (pixel stride C-C1).
+struct GnParams {
+    const bf16_t* x; const bf16_t* x2; int C1;
+    int B, HW, C, G;
+    const float* gamma; const float* beta; float eps; int silu;
+    float* partial;      // [B][nchunks][G][2]
+    float* scale_shift;  // [B][2][C]   (a = rstd*gamma, b = beta - mean*a)
+    int nchunks;
+    bf16_t* y;           // [B][HW][C]
+};
+size_t gn_workspace_bytes(int B, int HW, int C, int G);
+int gn_pick_chunks(int B, int HW, int C);
+int launch_groupnorm_stats(hipStream_t st, const GnParams& p);   // partial sums + finalize -> scale_shift
+int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+b)
+int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
+                     bf16_t* y);
+
+// weight repack: OIHW (any dtype) -> [O][KH][KW][Ipad] bf16 ; linear [O][I] -> bf16 (optionally GEGLU-interleaved)
+int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out);
+int launch_repack_linear(hipStream_t st, const void* w, int dtype, int O, int I, int geglu_interleave, bf16_t* out);
+int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int geglu_interleave, float* out);
+int launch_copy_probe(hipStream_t st, const void* src, void* dst, size_t bytes);
+
+// ---- MFMA GEMM / implicit-GEMM conv (kernels_gemm.hip) -------------------------
+enum { GEMM_LINEAR = 0, GEMM_CONV3 = 1 };
+enum { OUT_BF16 = 0, OUT_NCHW = 1, OUT_BF16_T = 2 };
+struct GemmParams {
+    // A operand: [M][K] rows (linear) or NHWC image gathered through a 3x3 window (conv)
+    const bf16_t* A = nullptr; const bf16_t* A2 = nullptr; int C1 = 0;  // dual source split along K / channel
+    int lda = 0, lda2 = 0;      // row (pixel) stride of each source, elements
+    int mode = GEMM_LINEAR;
+    int Hi = 0, Wi = 0, Cin = 0;  // conv: SOURCE spatial dims (before the fused 2x upsample) and channels (multiple of 8)
+    int Ho = 0, Wo = 0, stride = 1, pad = 1, ups = 0;
+    // B operand: W[N][K] bf16, K contiguous
+    const bf16_t* W = nullptr; int K = 0; int N = 0; int M = 0;
+    // epilogue
+    const float* bias = nullptr;      // [N] (GEGLU: [2N] interleaved like the weight rows)
+    const float* rowbias = nullptr;   // [M / rows_per_sample][ld_rowbias], per-sample per-channel (time embedding)
+    int rows_per_sample = 1; int ld_rowbias = 0;
+    const bf16_t* residual = nullptr; int ldr = 0;
+    int geglu = 0;                    // W has 2*N_out rows interleaved in 16-row value/gate groups; N == 2*N_out
+    void* out = nullptr; int ldc = 0; int out_mode = OUT_BF16; int out_dtype = 1;
+    int tokens_per_batch = 0; int ldt = 0;  // OUT_BF16_T: out[(b*N + col)*ldt + tok]
+};
+int launch_gemm(hipStream_t st, const GemmParams& p);
+
+// ---- flash-style attention (kernels_attn.hip) ------------------------------------
+struct AttnParams {
+    const bf16_t* q; int ldq;   // [B][Nq][ldq], head h at column h*D
+    const bf16_t* k; int ldk;   // [B][Nk][ldk]
+    const bf16_t* vt; int ldvt; // [B][H*D][ldvt] (V transposed: token index contiguous)
+    bf16_t* o; int ldo;         // [B][Nq][ldo]
+    int B, H, Nq, Nk, D;
+};
+int launch_attention(hipStream_t st, const AttnParams& p);

@@ -1,0 +1,400 @@
+// HBM-bound kernels: layout changes at the NCHW boundary, GroupNorm(+SiLU), LayerNorm,
+// timestep embedding, the fp32 row-vector linear used on the time-embedding path, and
+// weight repacking.  All loads/stores of activations are 16-byte (8 x bf16) per lane
+// and coalesced along the NHWC channel axis (guide G2/G13); reductions use wave64
+// shuffles + an LDS cross-wave step (guide Appendix B "Reduction").
+//
+// Replaces, inside the third-party modules the reference calls at
+// gyre/pipeline/unet/core.py:274 and unified_pipeline.py:309,1531:
+//   torch.nn.GroupNorm + SiLU, torch.nn.LayerNorm, diffusers Timesteps/TimestepEmbedding.
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------
+// NCHW (f32/bf16/f16) -> NHWC bf16, channels zero-padded to Cpad (multiple of 8)
+// ------------------------------------------------------------------------------
+__global__ void k_nchw_to_nhwc(const void* __restrict__ x, int dtype, int C, int HW, int Cpad, bf16_t* __restrict__ y,
+                               size_t total_pix) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW
+    if (pix >= total_pix) return;
+    size_t n = pix / HW, p = pix % HW;
+    const size_t base = n * (size_t)C * HW + p;
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c0 + j;
+            f[j] = c < C ? load_as_f32(x, dtype, base + (size_t)c * HW) : 0.0f;
+        }
+        *(uint4*)(y + pix * Cpad + c0) = pack8(f);
+    }
+}
+int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y) {
+    size_t total = (size_t)B * HW;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, dtype, C, HW, Cpad, y,
+                       total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_cast_to_bf16(const void* __restrict__ x, int dtype, size_t n, bf16_t* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f32_to_bf16(load_as_f32(x, dtype, i));
+}
+int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_t* y) {
+    hipLaunchKernelGGL(k_cast_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, dtype, n, y);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// sinusoidal timestep embedding, fp32.  [cos | sin] when flip (SD: flip_sin_to_cos=True,
+// freq_shift=0); exponent = -ln(10000) * i / (half - shift).
+// ------------------------------------------------------------------------------
+__global__ void k_timestep_embedding(const int64_t* __restrict__ t, int dim, int flip, float shift,
+                                     float* __restrict__ out) {
+    int b = blockIdx.x;
+    int half = dim / 2;
+    float tv = (float)t[b];
+    for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+        int i = j < half ? j : j - half;
+        float freq = expf(-9.210340371976184f * (float)i / ((float)half - shift));
+        float a = tv * freq;
+        bool is_cos = flip ? (j < half) : (j >= half);
+        out[(size_t)b * dim + j] = is_cos ? cosf(a) : sinf(a);
+    }
+}
+int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out) {
+    hipLaunchKernelGGL(k_timestep_embedding, dim3(B), dim3(256), 0, st, t, dim, flip, shift, out);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]   (f = SiLU when act_in_silu)
+// One wave per output column n, rows in groups of 8.  Weight-read bound (B <= 32).
+// ------------------------------------------------------------------------------
+#define RV_ROWS 8
+__global__ __launch_bounds__(256) void k_rowvec_linear(const float* __restrict__ x, int B, int K,
+                                                       const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                       int N, int act_in_silu, float* __restrict__ out, int ldo) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const bf16_t* wrow = W + (size_t)n * K;
+    for (int b0 = 0; b0 < B; b0 += RV_ROWS) {
+        float acc[RV_ROWS];
+#pragma unroll
+        for (int r = 0; r < RV_ROWS; ++r) acc[r] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            float w[8];
+            unpack8(*(const uint4*)(wrow + k), w);
+#pragma unroll
+            for (int r = 0; r < RV_ROWS; ++r) {
+                if (b0 + r < B) {
+                    const float* xr = x + (size_t)(b0 + r) * K + k;
+                    float4 x0 = *(const float4*)xr, x1 = *(const float4*)(xr + 4);
+                    float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = act_in_silu ? silu_f(xv[j]) : xv[j];
+                        acc[r] = fmaf(v, w[j], acc[r]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RV_ROWS; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && b0 + r < B) out[(size_t)(b0 + r) * ldo + n] = v + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+int launch_rowvec_linear(hipStream_t st, const float* x, int B, int K, const bf16_t* W, const float* bias, int N,
+                         int act_in_silu, float* out, int ldo) {
+    if (K % 8) GYRE_FAIL(-1, "rowvec_linear: K must be a multiple of 8");
+    hipLaunchKernelGGL(k_rowvec_linear, dim3((N + 3) / 4), dim3(256), 0, st, x, B, K, W, bias, N, act_in_silu, out, ldo);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// GroupNorm.  Stage 1: per (sample, pixel-chunk) block accumulates per-channel sum / sumsq over
+// its pixels with fully coalesced row reads, folds channels into groups through LDS and writes
+// one (sum, sumsq) pair per group - deterministic (no float atomics; bit-identical for any batch
+// composition, the reference's batch-independence property tests/batch_independance.py:15-27).
+// Stage 2: per sample, fixed-order reduction over chunks -> mean/rstd -> per-channel a,b.
+// Stage 3 (apply): y = act(a*x+b).
+// ------------------------------------------------------------------------------
+#define GN_MAXV 4  // channel vectors per thread: supports C <= 8*256*4
+__global__ __launch_bounds__(256) void k_gn_partial(GnParams p, int TX, int PY, int pix_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [PY][C][2]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int CV = p.C / 8;
+    const int C2 = p.C - p.C1;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(p.HW, p0 + pix_per_chunk);
+    float s[GN_MAXV][8], ss[GN_MAXV][8];
+#pragma unroll
+    for (int v = 0; v < GN_MAXV; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[v][j] = 0.f; ss[v][j] = 0.f; }
+    if (ty < PY) {
+        for (int pix = p0 + ty; pix < p1; pix += PY) {
+            size_t gp = (size_t)n * p.HW + pix;
+#pragma unroll
+            for (int v = 0; v < GN_MAXV; ++v) {
+                int cv = tx + v * TX;
+                if (cv < CV) {
+                    int c = cv * 8;
+                    const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
+                    float f[8];
+                    unpack8(*(const uint4*)src, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[v][j] += f[j]; ss[v][j] = fmaf(f[j], f[j], ss[v][j]); }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < GN_MAXV; ++v) {
+            int cv = tx + v * TX;
+            if (cv < CV) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[((size_t)ty * p.C + cv * 8 + j) * 2 + 0] = s[v][j];
+                    red[((size_t)ty * p.C + cv * 8 + j) * 2 + 1] = ss[v][j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cpg = p.C / p.G;
+    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int y = 0; y < PY; ++y)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                a += red[((size_t)y * p.C + c) * 2 + 0];
+                b += red[((size_t)y * p.C + c) * 2 + 1];
+            }
+        float* dst = p.partial + (((size_t)n * p.nchunks + chunk) * p.G + g) * 2;
+        dst[0] = a; dst[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_finalize(GnParams p) {
+    __shared__ float mean_s[256], rstd_s[256];
+    const int n = blockIdx.x;
+    const int cpg = p.C / p.G;
+    const float cnt = (float)p.HW * (float)cpg;
+    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+            a += src[0]; b += src[1];
+        }
+        float mean = a / cnt;
+        float var = fmaxf(b / cnt - mean * mean, 0.f);
+        mean_s[g] = mean;
+        rstd_s[g] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    float* sc = p.scale_shift + (size_t)n * 2 * p.C;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        int g = c / cpg;
+        float a = rstd_s[g] * p.gamma[c];
+        sc[c] = a;
+        sc[p.C + c] = p.beta[c] - mean_s[g] * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(GnParams p, size_t total_vec) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int CV = p.C / 8;
+    size_t gp = idx / CV;             // global pixel index over B*HW
+    int c = (int)(idx % CV) * 8;
+    int n = (int)(gp / p.HW);
+    const int C2 = p.C - p.C1;
+    const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
+    float f[8];
+    unpack8(*(const uint4*)src, f);
+    const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
+    float4 a0 = *(const float4*)sc, a1 = *(const float4*)(sc + 4);
+    float4 b0 = *(const float4*)(sc + p.C), b1 = *(const float4*)(sc + p.C + 4);
+    float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = fmaf(a[j], f[j], b[j]);
+        f[j] = p.silu ? silu_f(v) : v;
+    }
+    *(uint4*)(p.y + gp * p.C + c) = pack8(f);
+}
+
+int gn_pick_chunks(int B, int HW, int C) {
+    // aim for >= ~1024 blocks, chunks of >= 16 pixels
+    int want = (1024 + B - 1) / B;
+    int maxc = (HW + 15) / 16;
+    int n = want < maxc ? want : maxc;
+    return n < 1 ? 1 : n;
+}
+size_t gn_workspace_bytes(int B, int HW, int C, int G) {
+    int nch = gn_pick_chunks(B, HW, C);
+    size_t partial = (size_t)B * nch * G * 2 * sizeof(float);
+    size_t ss = (size_t)B * 2 * C * sizeof(float);
+    return ((partial + 255) & ~(size_t)255) + ((ss + 255) & ~(size_t)255);
+}
+int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
+    if (p.C % 8 || p.C1 % 8 || p.C % p.G) GYRE_FAIL(-1, "groupnorm: C, C1 must be multiples of 8 and C of groups");
+    if (p.G > 256) GYRE_FAIL(-1, "groupnorm: at most 256 groups");
+    int CV = p.C / 8;
+    int TX = CV < 256 ? CV : 256;
+    if ((CV + TX - 1) / TX > GN_MAXV) GYRE_FAIL(-6, "groupnorm: C too large");
+    int PY = 256 / TX; if (PY < 1) PY = 1;
+    int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
+    size_t lds = (size_t)PY * p.C * 2 * sizeof(float);
+    if (lds > 160 * 1024) GYRE_FAIL(-6, "groupnorm: LDS budget exceeded");
+    hipLaunchKernelGGL(k_gn_partial, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    GYRE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gn_finalize, dim3(p.B), dim3(256), 0, st, p);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
+    size_t total = (size_t)p.B * p.HW * (p.C / 8);
+    hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// LayerNorm over the last axis of [M][C] bf16, one wave per row, two-pass in registers
+// (mean, then centred sum of squares - same arithmetic order class as ATen's).
+// ------------------------------------------------------------------------------
+#define LN_MAXV 4  // C <= 8*64*4 = 2048
+__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x, int M, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float eps, bf16_t* __restrict__ y) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    size_t row = (size_t)blockIdx.x * 4 + wave;
+    if (row >= (size_t)M) return;
+    const int CV = C / 8;
+    const bf16_t* xr = x + row * C;
+    float f[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+        int cv = lane + v * 64;
+        if (cv < CV) {
+            unpack8(*(const uint4*)(xr + cv * 8), f[v]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[v][j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+        int cv = lane + v * 64;
+        if (cv < CV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = f[v][j] - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int v = 0; v < LN_MAXV; ++v) {
+        int cv = lane + v * 64;
+        if (cv < CV) {
+            const float* g = gamma + cv * 8;
+            const float* b = beta + cv * 8;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f[v][j] - mean) * rstd * g[j] + b[j];
+            *(uint4*)(y + row * C + cv * 8) = pack8(o);
+        }
+    }
+}
+int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
+                     bf16_t* y) {
+    if (C % 8 || C > 8 * 64 * LN_MAXV) GYRE_FAIL(-6, "layernorm: C must be a multiple of 8 and <= 2048");
+    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, gamma, beta, eps, y);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// weight repack (once, at load): conv OIHW -> [O][KH][KW][Ipad] bf16 (K contiguous for the
+// implicit GEMM); linear [O][I] -> bf16, optionally with the GEGLU 16-row value/gate interleave:
+// new row 32p+i = value row 16p+i, new row 32p+16+i = gate row F+16p+i  (F = O/2).
+// ------------------------------------------------------------------------------
+__global__ void k_repack_conv(const void* __restrict__ w, int dtype, int O, int I, int KH, int KW, int Ipad,
+                              bf16_t* __restrict__ out, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int ci = (int)(idx % Ipad);
+    size_t r = idx / Ipad;
+    int kx = (int)(r % KW); r /= KW;
+    int ky = (int)(r % KH); r /= KH;
+    int o = (int)r;
+    float v = ci < I ? load_as_f32(w, dtype, (((size_t)o * I + ci) * KH + ky) * KW + kx) : 0.f;
+    out[idx] = f32_to_bf16(v);
+}
+int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out) {
+    size_t total = (size_t)O * KH * KW * Ipad;
+    hipLaunchKernelGGL(k_repack_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dtype, O, I, KH, KW,
+                       Ipad, out, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+__device__ __forceinline__ int geglu_src_row(int r, int F) {
+    int p = r >> 5, i = r & 31;
+    return i < 16 ? p * 16 + i : F + p * 16 + (i - 16);
+}
+__global__ void k_repack_linear(const void* __restrict__ w, int dtype, int O, int I, int inter,
+                                bf16_t* __restrict__ out, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int k = (int)(idx % I);
+    int r = (int)(idx / I);
+    int sr = inter ? geglu_src_row(r, O / 2) : r;
+    out[idx] = f32_to_bf16(load_as_f32(w, dtype, (size_t)sr * I + k));
+}
+int launch_repack_linear(hipStream_t st, const void* w, int dtype, int O, int I, int inter, bf16_t* out) {
+    if (inter && (O % 32)) GYRE_FAIL(-1, "geglu interleave needs O % 32 == 0");
+    size_t total = (size_t)O * I;
+    hipLaunchKernelGGL(k_repack_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dtype, O, I, inter,
+                       out, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_cast_f32(const void* __restrict__ w, int dtype, size_t n, int inter, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t s = inter ? (size_t)geglu_src_row((int)i, (int)(n / 2)) : i;
+    out[i] = load_as_f32(w, dtype, s);
+}
+int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int inter, float* out) {
+    hipLaunchKernelGGL(k_cast_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, dtype, n, inter, out);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// 16 B/lane streaming copy: calibrates the achievable HBM rate on the box (bench.py roofline).
+__global__ __launch_bounds__(256) void k_copy_probe(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+int launch_copy_probe(hipStream_t st, const void* src, void* dst, size_t bytes) {
+    size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy_probe, dim3(2048), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}

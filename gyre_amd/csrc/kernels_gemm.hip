@@ -1,0 +1,331 @@
+// bf16 MFMA GEMM with an implicit-GEMM 3x3 convolution front end and fused epilogues.
+//
+//   C[M][N] = epilogue( A[M][K] * W[N][K]^T )
+//
+// A is either a row-major activation matrix (Linear / 1x1 conv over NHWC tokens) or an NHWC
+// image gathered on the fly through a 3x3 window (stride 1|2, zero padding, optional fused
+// nearest-2x upsample, optional second source for the UNet skip-concat), so a 3x3 conv is nine
+// shifted K-slices accumulating into the same MFMA tile - the im2col matrix is never
+// materialised.  W is the weight in its natural [out][K] order (K contiguous), i.e. both MFMA
+// operands are "K-contiguous per lane" and are staged identically.
+//
+// CDNA4 mapping (guides: cdna_hip_programming.md section 5, MI355X_MICROARCH.md LDS):
+//   * v_mfma_f32_16x16x32_bf16, 4 waves (256 threads) per workgroup, wave tile (BM/WM)x(BN/WN)
+//   * K step 64: global -> registers (16 B/lane, coalesced along K) -> LDS, double buffered, one
+//     barrier per K step; the loads of step k+1 are issued before the MFMAs of step k and written
+//     to the other LDS buffer after them (async-STAGE split, T14)
+//   * LDS rows are 128 B (64 bf16); 16-byte slots are XOR-swizzled with (row & 7) so the
+//     ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct slots (T2)
+//   * operands are issued swapped (weights as MFMA-A, activations as MFMA-B) so that each lane
+//     ends up with 4 consecutive output channels of one output row -> 8-byte epilogue accesses;
+//     the transposed-output variant (V^T for attention) uses the natural order instead
+//   * XCD-aware tile order: consecutive tiles (same A rows, different N) go to the same XCD L2
+//
+// Replaces cuBLAS/cuDNN (hipBLASLt/MIOpen) GEMM+conv reached through torch.nn.Linear /
+// torch.nn.Conv2d inside the third-party UNet/VAE the reference calls at
+// gyre/pipeline/unet/core.py:274 and gyre/pipeline/unified_pipeline.py:309,1531.
+#include "kernels.h"
+
+#define BK 64
+
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool TRANS>
+__global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int tiles_n) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte vectors per thread per K step (A, B)
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = (uint4*)smem_raw;  // stage s: A at s*(BM+BN)*8, B right after A; 8 x uint4 per row
+    constexpr int STAGE = (BM + BN) * 8;
+
+    // ---- XCD-aware, bijective tile order: tile id -> (tm, tn) with tn fastest -------------
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kv = tid & 7;    // which 16-byte vector of the 128-byte K slice this thread stages
+    const int r0 = tid >> 3;   // base row (0..31); rows r0 + 32*i
+
+    // ---- per-row gather state for A ----------------------------------------------------------
+    int a_base[AR];   // linear: row index (or -1); conv: sample base pixel index n*Hi*Wi (or -1)
+    int a_y0[AR], a_x0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int row = m0 + r0 + 32 * i;
+        bool ok = row < p.M;
+        if (MODE == GEMM_LINEAR) {
+            a_base[i] = ok ? row : -1;
+            a_y0[i] = 0; a_x0[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int n = row / hw, rem = row - n * hw;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = ok ? n * p.Hi * p.Wi : -1;
+            a_y0[i] = oy * p.stride - p.pad;
+            a_x0[i] = ox * p.stride - p.pad;
+        }
+    }
+    const int C2 = p.Cin - p.C1;
+    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+
+    uint4 ra[AR], rb[BR];
+    auto load_stage = [&](int kc) {
+        const int k = kc * BK + kv * 8;
+        if (MODE == GEMM_LINEAR) {
+            const bool kok = k < p.K;
+            const bool first = k < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kok && a_base[i] >= 0) {
+                    const bf16_t* src = first ? p.A + (size_t)a_base[i] * p.lda + k
+                                              : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
+                    v = *(const uint4*)src;
+                }
+                ra[i] = v;
+            }
+        } else {
+            int tap, c;
+            if (UNIFORM_TAP) {
+                const int kb = kc * BK;
+                tap = kb / p.Cin;           // scalar: same tap for the whole K step
+                c = kb - tap * p.Cin + kv * 8;
+            } else {
+                tap = k / p.Cin;
+                c = k - tap * p.Cin;
+            }
+            const bool kok = k < p.K;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool first = c < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
+                    const bf16_t* src = first ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
+                    v = *(const uint4*)src;
+                }
+                ra[i] = v;
+            }
+        }
+        {
+            const bool kok = k < p.K;
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                int n = n0 + r0 + 32 * i;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kok && n < p.N) v = *(const uint4*)(p.W + (size_t)n * p.K + k);
+                rb[i] = v;
+            }
+        }
+    };
+    auto store_stage = [&](int s) {
+        uint4* a = lds + s * STAGE;
+        uint4* b = a + BM * 8;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int r = r0 + 32 * i;
+            a[r * 8 + (kv ^ (r & 7))] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            int r = r0 + 32 * i;
+            b[r * 8 + (kv ^ (r & 7))] = rb[i];
+        }
+    };
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) load_stage(kc + 1);
+        const uint4* a = lds + cur * STAGE;
+        const uint4* b = a + BM * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int r = wm * TM + i * 16 + fr;
+                af[i] = __builtin_bit_cast(bf16x8_t, a[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int r = wn * TN + j * 16 + fr;
+                bfr[j] = __builtin_bit_cast(bf16x8_t, b[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    else       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    if (!TRANS) {
+        // lane holds, per fragment, row m = ..+fr and 4 consecutive columns n = ..+4*fq+{0..3}
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * TM + i * 16 + fr;
+            if (m >= p.M) continue;
+            const float* rbias = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+            if (p.geglu) {
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) {
+                    const int nin = n0 + wn * TN + j * 16 + 4 * fq;  // column in the interleaved 2N space
+                    if (nin >= p.N) continue;
+                    float4 bv = p.bias ? *(const float4*)(p.bias + nin) : make_float4(0, 0, 0, 0);
+                    float4 bg = p.bias ? *(const float4*)(p.bias + nin + 16) : make_float4(0, 0, 0, 0);
+                    float o[4];
+                    o[0] = (acc[i][j][0] + bv.x) * gelu_erf_f(acc[i][j + 1][0] + bg.x);
+                    o[1] = (acc[i][j][1] + bv.y) * gelu_erf_f(acc[i][j + 1][1] + bg.y);
+                    o[2] = (acc[i][j][2] + bv.z) * gelu_erf_f(acc[i][j + 1][2] + bg.z);
+                    o[3] = (acc[i][j][3] + bv.w) * gelu_erf_f(acc[i][j + 1][3] + bg.w);
+                    const int nout = (n0 + wn * TN + j * 16) / 2 + 4 * fq;
+                    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                    *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + nout) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = n0 + wn * TN + j * 16 + 4 * fq;
+                    if (n >= p.N) continue;
+                    float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (p.out_mode == OUT_NCHW) {
+                        // tiny-N output conv: out[(b*N + n)*HW + pix], runtime dtype
+                        const int hw = p.rows_per_sample;
+                        const int b = m / hw, pix = m - b * hw;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e < p.N) {
+                                float v = o[e] + (p.bias ? p.bias[n + e] : 0.f);
+                                store_from_f32(p.out, p.out_dtype, ((size_t)b * p.N + n + e) * hw + pix, v);
+                            }
+                        }
+                        continue;
+                    }
+                    // N is a multiple of 4 on this path (checked by the launcher)
+                    if (p.bias) {
+                        float4 bv = *(const float4*)(p.bias + n);
+                        o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                    }
+                    if (rbias) {
+                        float4 tv = *(const float4*)(rbias + n);
+                        o[0] += tv.x; o[1] += tv.y; o[2] += tv.z; o[3] += tv.w;
+                    }
+                    if (p.residual) {
+                        uint2 rv = *(const uint2*)(p.residual + (size_t)m * p.ldr + n);
+                        o[0] += bf16lo(rv.x); o[1] += bf16hi(rv.x); o[2] += bf16lo(rv.y); o[3] += bf16hi(rv.y);
+                    }
+                    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                    *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = pk;
+                }
+            }
+        }
+    } else {
+        // natural operand order: lane holds column n = ..+fr and 4 consecutive rows m = ..+4*fq+{0..3}
+        // -> transposed store out[(b*N + n)*ldt + tok], 4 consecutive tokens = 8 bytes
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * TN + j * 16 + fr;
+            if (n >= p.N) continue;
+            const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * TM + i * 16 + 4 * fq;
+                if (m >= p.M) continue;
+                const int b = m / p.tokens_per_batch, tok = m - b * p.tokens_per_batch;
+                bf16_t* dst = (bf16_t*)p.out + ((size_t)b * p.N + n) * p.ldt + tok;
+                if (m + 3 < p.M && tok + 3 < p.tokens_per_batch && ((p.ldt | tok) & 3) == 0) {
+                    uint2 pk = make_uint2(pack_bf16x2(acc[i][j][0] + bn, acc[i][j][1] + bn),
+                                          pack_bf16x2(acc[i][j][2] + bn, acc[i][j][3] + bn));
+                    *(uint2*)dst = pk;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int mm = m + e;
+                        if (mm < p.M) {
+                            int bb = mm / p.tokens_per_batch, tt = mm - bb * p.tokens_per_batch;
+                            ((bf16_t*)p.out)[((size_t)bb * p.N + n) * p.ldt + tt] = f32_to_bf16(acc[i][j][e] + bn);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(hipStream_t st, const GemmParams& p) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int grid = tiles_m * tiles_n;
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    const bool trans = p.out_mode == OUT_BF16_T;
+#define GYRE_GEMM_GO(MODE_, UNI_, TR_)                                                                              \
+    do {                                                                                                            \
+        auto kern = k_gemm<BM, BN, WM, WN, MODE_, UNI_, TR_>;                                                       \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n);                              \
+    } while (0)
+    if (p.mode == GEMM_LINEAR) {
+        if (trans) GYRE_GEMM_GO(GEMM_LINEAR, true, true); else GYRE_GEMM_GO(GEMM_LINEAR, true, false);
+    } else {
+        const bool uni = (p.Cin % BK == 0) && (p.C1 % BK == 0);
+        if (trans) GYRE_FAIL(-6, "conv with transposed output is not supported");
+        if (uni) GYRE_GEMM_GO(GEMM_CONV3, true, false); else GYRE_GEMM_GO(GEMM_CONV3, false, false);
+    }
+#undef GYRE_GEMM_GO
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm(hipStream_t st, const GemmParams& p0) {
+    GemmParams p = p0;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) GYRE_FAIL(-1, "gemm: empty problem");
+    if (p.K % 8) GYRE_FAIL(-1, "gemm: K must be a multiple of 8");
+    if (!p.A2) { p.C1 = p.mode == GEMM_LINEAR ? p.K : p.Cin; p.A2 = p.A; p.lda2 = p.lda; }
+    if (p.C1 % 8) GYRE_FAIL(-1, "gemm: source split must be a multiple of 8");
+    if (p.mode == GEMM_CONV3) {
+        if (p.Cin % 8 || p.K != 9 * p.Cin) GYRE_FAIL(-1, "conv3x3: Cin must be a multiple of 8 and K == 9*Cin");
+    }
+    if (p.out_mode == OUT_BF16 && (p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)))
+        GYRE_FAIL(-1, "gemm: N / ldc / ldr must be multiples of 4 for bf16 row-major output");
+    if (p.geglu && (p.N % 32)) GYRE_FAIL(-1, "gemm: GEGLU needs N % 32 == 0");
+    if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
+    if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
+    // tile choice: 128x128 when N divides, 256x64 for the N % 128 != 0 widths (320, 960, ...),
+    // 64x64 when the big tiles would leave most of the 256 CUs idle.
+    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (big_tiles < 192 || p.N < 64) return launch_cfg<64, 64, 2, 2>(st, p);
+    if (p.N % 128 == 0) return launch_cfg<128, 128, 2, 2>(st, p);
+    return launch_cfg<256, 64, 4, 1>(st, p);
+}

@@ -1,0 +1,987 @@
+// libgyre_hip model runtime: weight store, workspace arena, UNet2DCondition / AutoencoderKL
+// forward graphs over the hand-written kernels, and the C ABI declared in include/gyre_hip.h.
+//
+// Topology restates the third-party modules the reference drives
+//   gyre/pipeline/unet/core.py:262-274       unet(latents, t, encoder_hidden_states=...).sample
+//   gyre/pipeline/unified_pipeline.py:309    vae.encode(image).latent_dist
+//   gyre/pipeline/unified_pipeline.py:1531   vae.decode(latents).sample
+// with hyper-parameters from gyre/ldm_config/v1-inference.yaml:29-64; weights are addressed by
+// their diffusers state-dict keys (gyre/manager.py:1068-1112, gyre/ckpt_utils.py:259-285).
+#include "../../include/gyre_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static thread_local int64_t g_launches = 0;
+void gyre_set_error(const std::string& msg) { g_err = msg; }
+int64_t& gyre_launch_counter() { return g_launches; }
+extern "C" const char* gyre_last_error(void) { return g_err.c_str(); }
+extern "C" int gyre_abi_version(void) { return GYRE_ABI_VERSION; }
+extern "C" int64_t gyre_last_launch_count(void) { return g_launches; }
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int pad8(int c) { return (c + 7) / 8 * 8; }
+
+// ------------------------------------------------------------------------------------------
+// workspace arena: first-fit free list over a caller-provided buffer.  The same call sequence
+// gives the same offsets, so a dry run (no launches) yields the exact peak requirement.
+// ------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool dry = false;
+    std::map<size_t, size_t> free_;  // offset -> size
+    void reset(char* b, size_t c, bool d) {
+        base = b; cap = c; dry = d; peak = 0;
+        free_.clear();
+        free_[0] = d ? ((size_t)1 << 60) : c;
+    }
+    // returns offset or (size_t)-1
+    size_t alloc(size_t bytes) {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            if (it->second >= bytes) {
+                size_t off = it->first, rem = it->second - bytes;
+                free_.erase(it);
+                if (rem) free_[off + bytes] = rem;
+                peak = std::max(peak, off + bytes);
+                return off;
+            }
+        }
+        return (size_t)-1;
+    }
+    void release(size_t off, size_t bytes) {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        auto it = free_.emplace(off, bytes).first;
+        auto nx = std::next(it);
+        if (nx != free_.end() && it->first + it->second == nx->first) { it->second += nx->second; free_.erase(nx); }
+        if (it != free_.begin()) {
+            auto pv = std::prev(it);
+            if (pv->first + pv->second == it->first) { pv->second += it->second; free_.erase(it); }
+        }
+    }
+};
+
+struct Tn {  // NHWC bf16 activation (or a raw byte buffer when C == 0)
+    bf16_t* p = nullptr; size_t off = (size_t)-1, bytes = 0;
+    int B = 0, H = 0, W = 0, C = 0;
+    int rows() const { return B * H * W; }
+    bool valid() const { return off != (size_t)-1; }
+};
+
+// ------------------------------------------------------------------------------------------
+// weight store
+// ------------------------------------------------------------------------------------------
+enum ParamKind { PK_CONV3 = 0, PK_MAT = 1, PK_VEC = 2, PK_MAT_GEGLU = 3, PK_VEC_GEGLU = 4 };
+struct Param {
+    std::string key;
+    std::vector<int64_t> shape;  // PyTorch shape expected from the caller
+    int kind = PK_VEC;
+    int o_pad = 0, i_pad = 0;    // padded out / in channels of the repacked matrix
+    void* dev = nullptr;         // destination (inside `owner` allocation)
+    bool set = false;
+};
+
+struct Store {
+    int device = 0;
+    std::vector<std::unique_ptr<Param>> params;
+    std::unordered_map<std::string, Param*> by_key;
+    std::vector<void*> allocs;
+    ~Store() { for (void* a : allocs) (void)hipFree(a); }
+    void* dmalloc(size_t bytes, bool zero) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        if (zero) (void)hipMemset(p, 0, bytes);
+        allocs.push_back(p);
+        return p;
+    }
+    Param* add(const std::string& key, std::vector<int64_t> shape, int kind, void* dev, int o_pad = 0, int i_pad = 0) {
+        auto p = std::make_unique<Param>();
+        p->key = key; p->shape = std::move(shape); p->kind = kind; p->dev = dev; p->o_pad = o_pad; p->i_pad = i_pad;
+        Param* raw = p.get();
+        by_key[key] = raw;
+        params.push_back(std::move(p));
+        return raw;
+    }
+    // --- convenience creators: allocate + register -------------------------------------------------
+    bf16_t* conv3(const std::string& pfx, int O, int I, float** bias) {
+        int ip = pad8(I), op = pad8(O);  // zero rows up to a multiple of 8: the consumer's C % 8 == 0
+        bf16_t* w = (bf16_t*)dmalloc((size_t)op * 9 * ip * 2, true);
+        add(pfx + ".weight", {O, I, 3, 3}, PK_CONV3, w, op, ip);
+        float* b = (float*)dmalloc((size_t)pad8(O) * 4, true);
+        add(pfx + ".bias", {O}, PK_VEC, b);
+        *bias = b;
+        return w;
+    }
+    // linear or 1x1 conv; rows padded to a multiple of 8 with zeros so the output tensor can feed
+    // kernels that need C % 8 == 0
+    bf16_t* mat(const std::string& pfx, int O, int I, bool conv1x1, bool has_bias, float** bias, int kind = PK_MAT) {
+        int ip = pad8(I), op = pad8(O);
+        bf16_t* w = (bf16_t*)dmalloc((size_t)op * ip * 2, true);
+        std::vector<int64_t> shp = conv1x1 ? std::vector<int64_t>{O, I, 1, 1} : std::vector<int64_t>{O, I};
+        add(pfx + ".weight", shp, kind, w, op, ip);
+        if (bias) *bias = nullptr;
+        if (has_bias) {
+            float* b = (float*)dmalloc((size_t)op * 4, true);
+            add(pfx + ".bias", {O}, kind == PK_MAT_GEGLU ? PK_VEC_GEGLU : PK_VEC, b);
+            *bias = b;
+        }
+        return w;
+    }
+    void vec(const std::string& key, int n, float** out) {
+        float* b = (float*)dmalloc((size_t)n * 4, true);
+        add(key, {n}, PK_VEC, b);
+        *out = b;
+    }
+    int set_weight(const char* key, const void* src, int dtype, const int64_t* shape, int ndim, hipStream_t st) {
+        auto it = by_key.find(key);
+        if (it == by_key.end()) GYRE_FAIL(GYRE_ERR_KEY, std::string("unknown weight key: ") + key);
+        Param& p = *it->second;
+        if (dtype < 0 || dtype > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+        bool ok = (int)p.shape.size() == ndim;
+        for (int i = 0; ok && i < ndim; ++i) ok = p.shape[i] == shape[i];
+        if (!ok) {
+            std::string m = std::string("shape mismatch for ") + key + ": expected [";
+            for (auto d : p.shape) m += std::to_string(d) + ",";
+            m += "] got [";
+            for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
+            GYRE_FAIL(GYRE_ERR_KEY, m + "]");
+        }
+        int O = (int)p.shape[0];
+        switch (p.kind) {
+            case PK_CONV3: TRY(launch_repack_conv(st, src, dtype, O, (int)p.shape[1], 3, 3, p.i_pad, (bf16_t*)p.dev)); break;
+            case PK_MAT: case PK_MAT_GEGLU: {
+                int I = (int)p.shape[1];
+                // [O][I] -> [O][i_pad] (reuse the conv repack with a 1x1 window for the padding case)
+                if (p.i_pad != I || p.kind == PK_MAT) {
+                    if (p.kind == PK_MAT_GEGLU) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "geglu weight with padded K");
+                    TRY(launch_repack_conv(st, src, dtype, O, I, 1, 1, p.i_pad, (bf16_t*)p.dev));
+                } else {
+                    TRY(launch_repack_linear(st, src, dtype, O, I, 1, (bf16_t*)p.dev));
+                }
+                break;
+            }
+            case PK_VEC: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 0, (float*)p.dev)); break;
+            case PK_VEC_GEGLU: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 1, (float*)p.dev)); break;
+        }
+        p.set = true;
+        return 0;
+    }
+    int finalize() {
+        for (auto& p : params)
+            if (!p->set) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "weight not set: " + p->key);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// layer weights
+// ------------------------------------------------------------------------------------------
+struct ResW {
+    int cin = 0, cout = 0;
+    float *n1g, *n1b, *n2g, *n2b;
+    bf16_t *c1w, *c2w, *scw = nullptr;
+    float *c1b, *c2b, *scb = nullptr;
+    int temb_off = -1;  // column offset into the batched time_emb_proj output
+};
+struct AttnW {
+    int c = 0, heads = 1, kv_dim = 0;
+    bf16_t *wqk = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    float *bqk = nullptr, *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;
+};
+struct TBlockW {
+    float *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b;
+    AttnW a1, a2;
+    bf16_t *ff1, *ff2;
+    float *ff1b, *ff2b;
+};
+struct TransW {
+    int c = 0, heads = 1;
+    float *ng, *nb;
+    bf16_t *pin, *pout;
+    float *pinb, *poutb;
+    std::vector<TBlockW> blocks;
+};
+struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+
+// ------------------------------------------------------------------------------------------
+// execution context: arena + stream + dry-run switch; every op allocates its output
+// ------------------------------------------------------------------------------------------
+struct Exec {
+    Arena arena;
+    hipStream_t st = nullptr;
+    int groups = 32;
+    std::string fail;
+
+    bool dry() const { return arena.dry; }
+    int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        t.bytes = (size_t)B * H * W * C * elt;
+        t.off = arena.alloc(t.bytes);
+        if (t.off == (size_t)-1 || (!arena.dry && t.off + t.bytes > arena.cap))
+            GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small");
+        t.p = arena.dry ? nullptr : (bf16_t*)(arena.base + t.off);
+        return 0;
+    }
+    int alloc_raw(Tn& t, size_t bytes) { return alloc(t, 1, 1, 1, (int)((bytes + 1) / 2)); }
+    void free(Tn& t) { if (t.valid()) { arena.release(t.off, t.bytes); t.off = (size_t)-1; t.p = nullptr; } }
+
+    // GroupNorm (+SiLU) of x (optionally concatenated with x2 along C)
+    int groupnorm(const Tn& x, const Tn* x2, const float* g, const float* b, float eps, int silu, Tn& y) {
+        int C = x.C + (x2 ? x2->C : 0);
+        int HW = x.H * x.W;
+        Tn ws;
+        TRY(alloc_raw(ws, gn_workspace_bytes(x.B, HW, C, groups)));
+        TRY(alloc(y, x.B, x.H, x.W, C));
+        if (!dry()) {
+            GnParams p;
+            p.x = x.p; p.x2 = x2 ? x2->p : x.p; p.C1 = x.C; p.B = x.B; p.HW = HW; p.C = C; p.G = groups;
+            p.gamma = g; p.beta = b; p.eps = eps; p.silu = silu;
+            p.nchunks = gn_pick_chunks(x.B, HW, C);
+            p.partial = (float*)ws.p;
+            p.scale_shift = (float*)((char*)ws.p + align_up((size_t)x.B * p.nchunks * groups * 2 * sizeof(float), 256));
+            p.y = y.p;
+            TRY(launch_groupnorm_stats(st, p));
+            TRY(launch_groupnorm_apply(st, p));
+        }
+        free(ws);
+        return 0;
+    }
+    // 3x3 conv; x2 = second channel source (skip concat), rowbias = per-sample channel bias (temb)
+    int conv3(const Tn& x, const ConvW& w, int stride, int pad, int ups, const float* rowbias, int ld_rowbias,
+              const Tn* residual, Tn& y) {
+        int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
+        int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
+        TRY(alloc(y, x.B, Ho, Wo, pad8(w.cout)));
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
+        p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad; p.ups = ups;
+        p.W = w.w; p.K = 9 * x.C; p.N = pad8(w.cout); p.M = x.B * Ho * Wo;
+        p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
+        if (residual) { p.residual = residual->p; p.ldr = residual->C; }
+        p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
+        return launch_gemm(st, p);
+    }
+    // final 3x3 conv straight to the caller's NCHW buffer
+    int conv3_nchw(const Tn& x, const ConvW& w, void* out, int out_dtype) {
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
+        p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = x.H; p.Wo = x.W; p.stride = 1; p.pad = 1;
+        p.W = w.w; p.K = 9 * x.C; p.N = w.cout; p.M = x.rows();
+        p.bias = w.b; p.rows_per_sample = x.H * x.W;
+        p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = out_dtype;
+        return launch_gemm(st, p);
+    }
+    // y[M][N] = x[M][K] (|| x2) @ w^T + bias (+ residual); geglu halves N
+    int linear(const bf16_t* x, int lda, const bf16_t* x2, int lda2, int C1, int M, int K, const bf16_t* w, int N,
+               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc) {
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
+        p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
+        p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
+        return launch_gemm(st, p);
+    }
+    int linear_t(const bf16_t* x, int lda, int M, int K, const bf16_t* w, int N, const float* bias, int tokens, int ldt,
+                 bf16_t* y) {
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x; p.lda = lda; p.mode = GEMM_LINEAR; p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias;
+        p.out = y; p.out_mode = OUT_BF16_T; p.tokens_per_batch = tokens; p.ldt = ldt;
+        return launch_gemm(st, p);
+    }
+    int layernorm(const Tn& x, const float* g, const float* b, Tn& y) {
+        TRY(alloc(y, x.B, x.H, x.W, x.C));
+        if (dry()) return 0;
+        return launch_layernorm(st, x.p, x.rows(), x.C, g, b, 1e-5f, y.p);
+    }
+    // multi-head attention of tokens x against kv source (self: kv == nullptr); out = proj(attn) + residual
+    int mha(const Tn& xq, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w, const Tn& residual,
+            Tn& out) {
+        const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
+        Tn q, k, vt, ao;
+        const bf16_t *qp, *kp; int ldq, ldk, Nk, ldvt;
+        if (!kvsrc) {  // self attention: fused Q|K projection, V projected straight into V^T
+            Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, 2 * C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
+            TRY(alloc(vt, B, C, 1, ldvt));
+            TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
+            qp = q.p; kp = dry() ? nullptr : q.p + C; ldq = ldk = 2 * C;
+        } else {
+            Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wq, C, w.bq, nullptr, 0, 0, q.p, C));
+            TRY(alloc(k, B, Nk, 1, C));
+            TRY(linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wk, C, w.bk, nullptr, 0, 0, k.p, C));
+            TRY(alloc(vt, B, C, 1, ldvt));
+            TRY(linear_t(kvsrc, kv_dim, B * Nk, kv_dim, w.wv, C, w.bv, Nk, ldvt, vt.p));
+            qp = q.p; kp = k.p; ldq = ldk = C;
+        }
+        TRY(alloc(ao, B, xq.H, xq.W, C));
+        if (!dry()) {
+            AttnParams a;
+            a.q = qp; a.ldq = ldq; a.k = kp; a.ldk = ldk; a.vt = vt.p; a.ldvt = ldvt; a.o = ao.p; a.ldo = C;
+            a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
+            TRY(launch_attention(st, a));
+        }
+        free(q); free(k); free(vt);
+        TRY(alloc(out, B, xq.H, xq.W, C));
+        TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C));
+        free(ao);
+        return 0;
+    }
+    int resnet(const Tn& x, const Tn* skip, const ResW& w, const float* tproj, int ld_tproj, float eps, Tn& out) {
+        Tn a, h1, b, sc;
+        TRY(groupnorm(x, skip, w.n1g, w.n1b, eps, 1, a));
+        ConvW c1{w.c1w, w.c1b, w.cin, w.cout};
+        TRY(conv3(a, c1, 1, 1, 0, (tproj && w.temb_off >= 0) ? tproj + w.temb_off : nullptr, ld_tproj, nullptr, h1));
+        free(a);
+        TRY(groupnorm(h1, nullptr, w.n2g, w.n2b, eps, 1, b));
+        free(h1);
+        const Tn* res = &x;
+        if (w.scw) {
+            TRY(alloc(sc, x.B, x.H, x.W, w.cout));
+            TRY(linear(x.p, x.C, skip ? skip->p : nullptr, skip ? skip->C : 0, x.C, x.rows(), w.cin, w.scw, w.cout,
+                       w.scb, nullptr, 0, 0, sc.p, w.cout));
+            res = &sc;
+        } else if (skip) {
+            GYRE_FAIL(GYRE_ERR_INVALID, "resnet: concat input needs a shortcut conv");
+        }
+        ConvW c2{w.c2w, w.c2b, w.cout, w.cout};
+        TRY(conv3(b, c2, 1, 1, 0, nullptr, 0, res, out));
+        free(b); free(sc);
+        return 0;
+    }
+    int transformer(const Tn& x, const Tn& ctx, int S, int ctx_dim, const TransW& w, Tn& out) {
+        const int B = x.B, M = x.rows(), C = w.c;
+        Tn a, h;
+        TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
+        TRY(alloc(h, B, x.H, x.W, C));
+        TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C));
+        free(a);
+        for (const TBlockW& bw : w.blocks) {
+            Tn n, h2, ff;
+            TRY(layernorm(h, bw.ln1g, bw.ln1b, n));
+            TRY(mha(n, nullptr, 0, 0, bw.a1, h, h2));
+            free(n); free(h); h = h2;
+            TRY(layernorm(h, bw.ln2g, bw.ln2b, n));
+            TRY(mha(n, ctx.p, S, ctx_dim, bw.a2, h, h2));
+            free(n); free(h); h = h2;
+            TRY(layernorm(h, bw.ln3g, bw.ln3b, n));
+            TRY(alloc(ff, B, x.H, x.W, 4 * C));
+            TRY(linear(n.p, C, nullptr, 0, 0, M, C, bw.ff1, 8 * C, bw.ff1b, nullptr, 0, 1, ff.p, 4 * C));
+            free(n);
+            TRY(alloc(h2, B, x.H, x.W, C));
+            TRY(linear(ff.p, 4 * C, nullptr, 0, 0, M, 4 * C, bw.ff2, C, bw.ff2b, h.p, C, 0, h2.p, C));
+            free(ff); free(h); h = h2;
+        }
+        TRY(alloc(out, B, x.H, x.W, C));
+        TRY(linear(h.p, C, nullptr, 0, 0, M, C, w.pout, C, w.poutb, x.p, C, 0, out.p, C));
+        free(h);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// weight registration helpers
+// ------------------------------------------------------------------------------------------
+static void reg_resnet(Store& s, const std::string& p, int cin, int cout, bool temb, bf16_t* temb_w, float* temb_b,
+                       int temb_dim, int& temb_cols, ResW& w) {
+    w.cin = cin; w.cout = cout;
+    s.vec(p + ".norm1.weight", cin, &w.n1g); s.vec(p + ".norm1.bias", cin, &w.n1b);
+    w.c1w = s.conv3(p + ".conv1", cout, cin, &w.c1b);
+    if (temb) {
+        w.temb_off = temb_cols;
+        s.add(p + ".time_emb_proj.weight", {cout, temb_dim}, PK_MAT, temb_w + (size_t)temb_cols * temb_dim, cout, temb_dim);
+        s.add(p + ".time_emb_proj.bias", {cout}, PK_VEC, temb_b + temb_cols);
+        temb_cols += cout;
+    }
+    s.vec(p + ".norm2.weight", cout, &w.n2g); s.vec(p + ".norm2.bias", cout, &w.n2b);
+    w.c2w = s.conv3(p + ".conv2", cout, cout, &w.c2b);
+    if (cin != cout) w.scw = s.mat(p + ".conv_shortcut", cout, cin, true, true, &w.scb);
+}
+static void reg_attn(Store& s, const std::string& p, int c, int heads, int kv_dim, bool self, AttnW& w) {
+    w.c = c; w.heads = heads; w.kv_dim = kv_dim;
+    if (self) {
+        w.wqk = (bf16_t*)s.dmalloc((size_t)2 * c * c * 2, true);
+        s.add(p + ".to_q.weight", {c, c}, PK_MAT, w.wqk, c, c);
+        s.add(p + ".to_k.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c);
+    } else {
+        w.wq = s.mat(p + ".to_q", c, c, false, false, nullptr);
+        w.wk = s.mat(p + ".to_k", c, kv_dim, false, false, nullptr);
+    }
+    w.wv = s.mat(p + ".to_v", c, kv_dim, false, false, nullptr);
+    w.wo = s.mat(p + ".to_out.0", c, c, false, true, &w.bo);
+}
+static void reg_transformer(Store& s, const std::string& p, int c, int heads, int ctx_dim, int depth, bool linproj,
+                            TransW& w) {
+    w.c = c; w.heads = heads;
+    s.vec(p + ".norm.weight", c, &w.ng); s.vec(p + ".norm.bias", c, &w.nb);
+    w.pin = s.mat(p + ".proj_in", c, c, !linproj, true, &w.pinb);
+    w.blocks.resize(depth);
+    for (int d = 0; d < depth; ++d) {
+        std::string b = p + ".transformer_blocks." + std::to_string(d);
+        TBlockW& bw = w.blocks[d];
+        s.vec(b + ".norm1.weight", c, &bw.ln1g); s.vec(b + ".norm1.bias", c, &bw.ln1b);
+        s.vec(b + ".norm2.weight", c, &bw.ln2g); s.vec(b + ".norm2.bias", c, &bw.ln2b);
+        s.vec(b + ".norm3.weight", c, &bw.ln3g); s.vec(b + ".norm3.bias", c, &bw.ln3b);
+        reg_attn(s, b + ".attn1", c, heads, c, true, bw.a1);
+        reg_attn(s, b + ".attn2", c, heads, ctx_dim, false, bw.a2);
+        bw.ff1 = s.mat(b + ".ff.net.0.proj", 8 * c, c, false, true, &bw.ff1b, PK_MAT_GEGLU);
+        bw.ff2 = s.mat(b + ".ff.net.2", c, 4 * c, false, true, &bw.ff2b);
+    }
+    w.pout = s.mat(p + ".proj_out", c, c, !linproj, true, &w.poutb);
+}
+
+// ------------------------------------------------------------------------------------------
+// UNet
+// ------------------------------------------------------------------------------------------
+struct gyre_unet {
+    gyre_unet_cfg cfg;
+    Store store;
+    Exec ex;
+    bool finalized = false;
+    int temb_dim = 0, temb_cols = 0;
+    bf16_t *te1w, *te2w; float *te1b, *te2b;
+    bf16_t* tproj_w = nullptr; float* tproj_b = nullptr;
+    ConvW conv_in, conv_out;
+    float *ong, *onb;
+    struct Level { std::vector<ResW> res; std::vector<TransW> attn; ConvW resample; bool has_resample = false; };
+    std::vector<Level> down, up;
+    ResW mid0, mid1; TransW mid_attn;
+
+    int build() {
+        const gyre_unet_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (n < 1 || n > GYRE_MAX_LEVELS) GYRE_FAIL(GYRE_ERR_INVALID, "n_levels out of range");
+        for (int i = 0; i < n; ++i) {
+            if (c.block_out_channels[i] % c.norm_num_groups || c.block_out_channels[i] % 8)
+                GYRE_FAIL(GYRE_ERR_INVALID, "block_out_channels must be multiples of norm_num_groups and 8");
+            if (c.attn_levels[i] && (c.block_out_channels[i] % c.num_heads[i] || (c.block_out_channels[i] / c.num_heads[i]) % 8))
+                GYRE_FAIL(GYRE_ERR_INVALID, "head dim must be a multiple of 8");
+        }
+        if (c.cross_attention_dim % 8) GYRE_FAIL(GYRE_ERR_INVALID, "cross_attention_dim must be a multiple of 8");
+        ex.groups = c.norm_num_groups;
+        const int c0 = c.block_out_channels[0];
+        temb_dim = 4 * c0;
+        // total columns of the batched time_emb_proj
+        int total_cols = 0;
+        for (int i = 0; i < n; ++i) total_cols += c.layers_per_block * c.block_out_channels[i];
+        total_cols += 2 * c.block_out_channels[n - 1];
+        for (int i = 0; i < n; ++i) total_cols += (c.layers_per_block + 1) * c.block_out_channels[n - 1 - i];
+        tproj_w = (bf16_t*)store.dmalloc((size_t)total_cols * temb_dim * 2, true);
+        tproj_b = (float*)store.dmalloc((size_t)total_cols * 4, true);
+        if (!tproj_w || !tproj_b) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+
+        te1w = store.mat("time_embedding.linear_1", temb_dim, c0, false, true, &te1b);
+        te2w = store.mat("time_embedding.linear_2", temb_dim, temb_dim, false, true, &te2b);
+        conv_in.cin = pad8(c.in_channels); conv_in.cout = c0;
+        conv_in.w = store.conv3("conv_in", c0, c.in_channels, &conv_in.b);
+        std::vector<int> skip_ch{c0};
+        int cin = c0;
+        down.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[i];
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                std::string p = "down_blocks." + std::to_string(i);
+                down[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, true, tproj_w, tproj_b, temb_dim, temb_cols,
+                           down[i].res.back());
+                cin = co;
+                if (c.attn_levels[i]) {
+                    down[i].attn.emplace_back();
+                    reg_transformer(store, p + ".attentions." + std::to_string(j), cin, c.num_heads[i], c.cross_attention_dim,
+                                    c.transformer_depth[i], c.use_linear_projection != 0, down[i].attn.back());
+                }
+                skip_ch.push_back(cin);
+            }
+            if (i < n - 1) {
+                down[i].has_resample = true;
+                down[i].resample.cin = cin; down[i].resample.cout = cin;
+                down[i].resample.w = store.conv3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin,
+                                                 &down[i].resample.b);
+                skip_ch.push_back(cin);
+            }
+        }
+        reg_resnet(store, "mid_block.resnets.0", cin, cin, true, tproj_w, tproj_b, temb_dim, temb_cols, mid0);
+        reg_transformer(store, "mid_block.attentions.0", cin, c.num_heads[n - 1], c.cross_attention_dim,
+                        c.transformer_depth[n - 1], c.use_linear_projection != 0, mid_attn);
+        reg_resnet(store, "mid_block.resnets.1", cin, cin, true, tproj_w, tproj_b, temb_dim, temb_cols, mid1);
+        up.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int lvl = n - 1 - i, co = c.block_out_channels[lvl];
+            std::string p = "up_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                int sk = skip_ch.back(); skip_ch.pop_back();
+                up[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin + sk, co, true, tproj_w, tproj_b, temb_dim,
+                           temb_cols, up[i].res.back());
+                cin = co;
+                if (c.attn_levels[lvl]) {
+                    up[i].attn.emplace_back();
+                    reg_transformer(store, p + ".attentions." + std::to_string(j), cin, c.num_heads[lvl],
+                                    c.cross_attention_dim, c.transformer_depth[lvl], c.use_linear_projection != 0,
+                                    up[i].attn.back());
+                }
+            }
+            if (i < n - 1) {
+                up[i].has_resample = true;
+                up[i].resample.cin = cin; up[i].resample.cout = cin;
+                up[i].resample.w = store.conv3(p + ".upsamplers.0.conv", cin, cin, &up[i].resample.b);
+            }
+        }
+        store.vec("conv_norm_out.weight", cin, &ong); store.vec("conv_norm_out.bias", cin, &onb);
+        conv_out.cin = cin; conv_out.cout = c.out_channels;
+        conv_out.w = store.conv3("conv_out", c.out_channels, cin, &conv_out.b);
+        if (temb_cols != total_cols) GYRE_FAIL(GYRE_ERR_INVALID, "internal: temb column count mismatch");
+        for (void* a : store.allocs) if (!a) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+        return 0;
+    }
+
+    int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
+            int W, int S, void* ws, size_t ws_bytes, void* out, int odt) {
+        const gyre_unet_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
+        if ((H % (1 << (n - 1))) || (W % (1 << (n - 1))))
+            GYRE_FAIL(GYRE_ERR_INVALID, "unet: latent H, W must be multiples of 2^(n_levels-1)");
+        ex.arena.reset((char*)ws, ws_bytes, dry);
+        ex.st = st;
+        Exec& e = ex;
+        const int D = c.cross_attention_dim;
+        Tn xin, cx, emb, t1, t2, tp;
+        TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
+        TRY(e.alloc(cx, B, S, 1, D));
+        TRY(e.alloc(emb, B, 1, 1, c.block_out_channels[0], 4));
+        TRY(e.alloc(t1, B, 1, 1, temb_dim, 4));
+        TRY(e.alloc(t2, B, 1, 1, temb_dim, 4));
+        TRY(e.alloc(tp, B, 1, 1, temb_cols, 4));
+        if (!dry) {
+            TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
+            TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
+            TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
+            TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
+            TRY(launch_rowvec_linear(st, (float*)t1.p, B, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
+            // every resnet's Linear(SiLU(temb)) in one launch
+            TRY(launch_rowvec_linear(st, (float*)t2.p, B, temb_dim, tproj_w, tproj_b, temb_cols, 1, (float*)tp.p, temb_cols));
+        }
+        e.free(emb); e.free(t1); e.free(t2);
+        const float* tproj = (const float*)tp.p;
+
+        std::vector<Tn> skips;
+        Tn h;
+        TRY(e.conv3(xin, conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
+        e.free(xin);
+        skips.push_back(h);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                Tn r;
+                TRY(e.resnet(skips.back(), nullptr, down[i].res[j], tproj, temb_cols, 1e-5f, r));
+                if (c.attn_levels[i]) {
+                    Tn a;
+                    TRY(e.transformer(r, cx, S, D, down[i].attn[j], a));
+                    e.free(r); r = a;
+                }
+                skips.push_back(r);
+            }
+            if (down[i].has_resample) {
+                Tn d;
+                TRY(e.conv3(skips.back(), down[i].resample, 2, 1, 0, nullptr, 0, nullptr, d));
+                skips.push_back(d);
+            }
+        }
+        {
+            Tn a, b2;
+            TRY(e.resnet(skips.back(), nullptr, mid0, tproj, temb_cols, 1e-5f, a));
+            TRY(e.transformer(a, cx, S, D, mid_attn, b2));
+            e.free(a);
+            TRY(e.resnet(b2, nullptr, mid1, tproj, temb_cols, 1e-5f, h));
+            e.free(b2);
+        }
+        for (int i = 0; i < n; ++i) {
+            const int lvl = n - 1 - i;
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                Tn sk = skips.back(); skips.pop_back();
+                Tn r;
+                TRY(e.resnet(h, &sk, up[i].res[j], tproj, temb_cols, 1e-5f, r));
+                e.free(h); e.free(sk);
+                if (c.attn_levels[lvl]) {
+                    Tn a;
+                    TRY(e.transformer(r, cx, S, D, up[i].attn[j], a));
+                    e.free(r); r = a;
+                }
+                h = r;
+            }
+            if (up[i].has_resample) {
+                Tn u;
+                TRY(e.conv3(h, up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u));
+                e.free(h); h = u;
+            }
+        }
+        Tn a;
+        TRY(e.groupnorm(h, nullptr, ong, onb, 1e-5f, 1, a));
+        e.free(h);
+        TRY(e.conv3_nchw(a, conv_out, out, odt));
+        e.free(a); e.free(tp); e.free(cx);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// VAE
+// ------------------------------------------------------------------------------------------
+struct gyre_vae {
+    gyre_vae_cfg cfg;
+    Store store;
+    Exec ex;
+    struct Blk { std::vector<ResW> res; ConvW resample; bool has_resample = false; };
+    // encoder
+    ConvW e_in, e_out; std::vector<Blk> e_down; ResW e_mid0, e_mid1; AttnW e_attn; float *e_ag, *e_ab, *e_ng, *e_nb;
+    bf16_t* quant_w; float* quant_b;
+    // decoder
+    ConvW d_in, d_out; std::vector<Blk> d_up; ResW d_mid0, d_mid1; AttnW d_attn; float *d_ag, *d_ab, *d_ng, *d_nb;
+    bf16_t* pq_w; float* pq_b;
+
+    void reg_vattn(const std::string& p, int c, AttnW& w, float** g, float** b) {
+        w.c = c; w.heads = 1; w.kv_dim = c;
+        store.vec(p + ".group_norm.weight", c, g); store.vec(p + ".group_norm.bias", c, b);
+        w.wqk = (bf16_t*)store.dmalloc((size_t)2 * c * c * 2, true);
+        w.bqk = (float*)store.dmalloc((size_t)2 * c * 4, true);
+        store.add(p + ".query.weight", {c, c}, PK_MAT, w.wqk, c, c);
+        store.add(p + ".query.bias", {c}, PK_VEC, w.bqk);
+        store.add(p + ".key.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c);
+        store.add(p + ".key.bias", {c}, PK_VEC, w.bqk + c);
+        w.wv = store.mat(p + ".value", c, c, false, true, &w.bv);
+        w.wo = store.mat(p + ".proj_attn", c, c, false, true, &w.bo);
+    }
+    int build() {
+        const gyre_vae_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (n < 1 || n > GYRE_MAX_LEVELS) GYRE_FAIL(GYRE_ERR_INVALID, "n_levels out of range");
+        for (int i = 0; i < n; ++i)
+            if (c.block_out_channels[i] % c.norm_num_groups || c.block_out_channels[i] % 8)
+                GYRE_FAIL(GYRE_ERR_INVALID, "block_out_channels must be multiples of norm_num_groups and 8");
+        ex.groups = c.norm_num_groups;
+        int dummy = 0;
+        const int z = c.latent_channels;
+        // ---- encoder ----
+        int cin = c.block_out_channels[0];
+        e_in.cin = pad8(c.in_channels); e_in.cout = cin;
+        e_in.w = store.conv3("encoder.conv_in", cin, c.in_channels, &e_in.b);
+        e_down.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[i];
+            std::string p = "encoder.down_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                e_down[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, false, nullptr, nullptr, 0, dummy,
+                           e_down[i].res.back());
+                cin = co;
+            }
+            if (i < n - 1) {
+                e_down[i].has_resample = true;
+                e_down[i].resample.cin = cin; e_down[i].resample.cout = cin;
+                e_down[i].resample.w = store.conv3(p + ".downsamplers.0.conv", cin, cin, &e_down[i].resample.b);
+            }
+        }
+        reg_resnet(store, "encoder.mid_block.resnets.0", cin, cin, false, nullptr, nullptr, 0, dummy, e_mid0);
+        reg_vattn("encoder.mid_block.attentions.0", cin, e_attn, &e_ag, &e_ab);
+        reg_resnet(store, "encoder.mid_block.resnets.1", cin, cin, false, nullptr, nullptr, 0, dummy, e_mid1);
+        store.vec("encoder.conv_norm_out.weight", cin, &e_ng); store.vec("encoder.conv_norm_out.bias", cin, &e_nb);
+        e_out.cin = cin; e_out.cout = 2 * z;
+        e_out.w = store.conv3("encoder.conv_out", 2 * z, cin, &e_out.b);
+        quant_w = store.mat("quant_conv", 2 * z, 2 * z, true, true, &quant_b);
+        // ---- decoder ----
+        pq_w = store.mat("post_quant_conv", z, z, true, true, &pq_b);
+        cin = c.block_out_channels[n - 1];
+        d_in.cin = pad8(z); d_in.cout = cin;
+        d_in.w = store.conv3("decoder.conv_in", cin, z, &d_in.b);
+        reg_resnet(store, "decoder.mid_block.resnets.0", cin, cin, false, nullptr, nullptr, 0, dummy, d_mid0);
+        reg_vattn("decoder.mid_block.attentions.0", cin, d_attn, &d_ag, &d_ab);
+        reg_resnet(store, "decoder.mid_block.resnets.1", cin, cin, false, nullptr, nullptr, 0, dummy, d_mid1);
+        d_up.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[n - 1 - i];
+            std::string p = "decoder.up_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                d_up[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, false, nullptr, nullptr, 0, dummy,
+                           d_up[i].res.back());
+                cin = co;
+            }
+            if (i < n - 1) {
+                d_up[i].has_resample = true;
+                d_up[i].resample.cin = cin; d_up[i].resample.cout = cin;
+                d_up[i].resample.w = store.conv3(p + ".upsamplers.0.conv", cin, cin, &d_up[i].resample.b);
+            }
+        }
+        store.vec("decoder.conv_norm_out.weight", cin, &d_ng); store.vec("decoder.conv_norm_out.bias", cin, &d_nb);
+        d_out.cin = cin; d_out.cout = c.out_channels;
+        d_out.w = store.conv3("decoder.conv_out", c.out_channels, cin, &d_out.b);
+        for (void* a : store.allocs) if (!a) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+        return 0;
+    }
+    // GN -> fused QK / V^T projections -> single-head attention -> proj + residual
+    int vattn(Exec& e, const Tn& x, const AttnW& w, const float* g, const float* b, Tn& out) {
+        Tn a;
+        TRY(e.groupnorm(x, nullptr, g, b, 1e-6f, 0, a));
+        TRY(e.mha(a, nullptr, 0, 0, w, x, out));
+        e.free(a);
+        return 0;
+    }
+    int mid(Exec& e, Tn& h, const ResW& r0, const AttnW& aw, const float* g, const float* b, const ResW& r1) {
+        Tn a, b2, c2;
+        TRY(e.resnet(h, nullptr, r0, nullptr, 0, 1e-6f, a)); e.free(h);
+        TRY(vattn(e, a, aw, g, b, b2)); e.free(a);
+        TRY(e.resnet(b2, nullptr, r1, nullptr, 0, 1e-6f, c2)); e.free(b2);
+        h = c2;
+        return 0;
+    }
+    int run_encode(bool dry, hipStream_t st, const void* img, int idt, int B, int H, int W, void* ws, size_t wsb,
+                   void* out, int odt) {
+        const int n = cfg.n_levels;
+        if (B < 1 || H < 1 || W < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: empty input");
+        if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: H, W must be multiples of 8");
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st;
+        Exec& e = ex;
+        Tn x, h;
+        TRY(e.alloc(x, B, H, W, pad8(cfg.in_channels)));
+        if (!dry) TRY(launch_nchw_to_nhwc(st, img, idt, B, cfg.in_channels, H * W, x.C, x.p));
+        TRY(e.conv3(x, e_in, 1, 1, 0, nullptr, 0, nullptr, h)); e.free(x);
+        for (int i = 0; i < n; ++i) {
+            for (auto& rw : e_down[i].res) {
+                Tn r; TRY(e.resnet(h, nullptr, rw, nullptr, 0, 1e-6f, r)); e.free(h); h = r;
+            }
+            if (e_down[i].has_resample) {  // pad (0,1,0,1) + stride-2 conv, pad 0
+                Tn d; TRY(e.conv3(h, e_down[i].resample, 2, 0, 0, nullptr, 0, nullptr, d)); e.free(h); h = d;
+            }
+        }
+        TRY(mid(e, h, e_mid0, e_attn, e_ag, e_ab, e_mid1));
+        Tn a, m;
+        TRY(e.groupnorm(h, nullptr, e_ng, e_nb, 1e-6f, 1, a)); e.free(h);
+        TRY(e.conv3(a, e_out, 1, 1, 0, nullptr, 0, nullptr, m)); e.free(a);
+        if (!dry) {
+            GemmParams p;
+            p.A = m.p; p.lda = m.C; p.mode = GEMM_LINEAR; p.W = quant_w; p.K = m.C; p.N = 2 * cfg.latent_channels;
+            p.M = m.rows(); p.bias = quant_b; p.rows_per_sample = m.H * m.W;
+            p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = odt;
+            TRY(launch_gemm(st, p));
+        }
+        e.free(m);
+        return 0;
+    }
+    int run_decode(bool dry, hipStream_t st, const void* z, int idt, int B, int h_, int w_, void* ws, size_t wsb,
+                   void* out, int odt) {
+        const int n = cfg.n_levels;
+        if (B < 1 || h_ < 1 || w_ < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.decode: empty input");
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st;
+        Exec& e = ex;
+        Tn x, q, h;
+        const int zc = pad8(cfg.latent_channels);
+        TRY(e.alloc(x, B, h_, w_, zc));
+        if (!dry) TRY(launch_nchw_to_nhwc(st, z, idt, B, cfg.latent_channels, h_ * w_, zc, x.p));
+        TRY(e.alloc(q, B, h_, w_, zc));
+        TRY(e.linear(x.p, zc, nullptr, 0, 0, x.rows(), zc, pq_w, zc, pq_b, nullptr, 0, 0, q.p, zc)); e.free(x);
+        TRY(e.conv3(q, d_in, 1, 1, 0, nullptr, 0, nullptr, h)); e.free(q);
+        TRY(mid(e, h, d_mid0, d_attn, d_ag, d_ab, d_mid1));
+        for (int i = 0; i < n; ++i) {
+            for (auto& rw : d_up[i].res) {
+                Tn r; TRY(e.resnet(h, nullptr, rw, nullptr, 0, 1e-6f, r)); e.free(h); h = r;
+            }
+            if (d_up[i].has_resample) {
+                Tn u; TRY(e.conv3(h, d_up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u)); e.free(h); h = u;
+            }
+        }
+        Tn a;
+        TRY(e.groupnorm(h, nullptr, d_ng, d_nb, 1e-6f, 1, a)); e.free(h);
+        TRY(e.conv3_nchw(a, d_out, out, odt)); e.free(a);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int gyre_unet_create(const gyre_unet_cfg* cfg, int device, gyre_unet** out) {
+    if (!cfg || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GYRE_HIP_CHECK(hipSetDevice(device));
+    auto* h = new gyre_unet();
+    h->cfg = *cfg; h->store.device = device;
+    int rc = h->build();
+    if (rc) { delete h; return rc; }
+    GYRE_HIP_CHECK(hipDeviceSynchronize());  // creation only: zero-fills of the weight buffers are complete
+    *out = h;
+    return 0;
+}
+void gyre_unet_destroy(gyre_unet* h) { delete h; }
+int gyre_unet_num_params(const gyre_unet* h) { return h ? (int)h->store.params.size() : 0; }
+const char* gyre_unet_param_key(const gyre_unet* h, int i) {
+    return (h && i >= 0 && i < (int)h->store.params.size()) ? h->store.params[i]->key.c_str() : nullptr;
+}
+int gyre_unet_set_weight(gyre_unet* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* st) {
+    if (!h || !key || !p || !shape) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    h->finalized = false;
+    return h->store.set_weight(key, p, dtype, shape, ndim, (hipStream_t)st);
+}
+int gyre_unet_finalize(gyre_unet* h, void* st) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null handle");
+    TRY(h->store.finalize());
+    h->finalized = true;
+    return 0;
+}
+size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
+    if (!h) return 0;
+    if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0)) return 0;
+    return h->ex.arena.peak;
+}
+int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
+                      int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {
+    if (!h || !x || !t || !ctx || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    if (xdt < 0 || xdt > 2 || cdt < 0 || cdt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    g_launches = 0;
+    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt);
+}
+
+int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out) {
+    if (!cfg || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GYRE_HIP_CHECK(hipSetDevice(device));
+    auto* h = new gyre_vae();
+    h->cfg = *cfg; h->store.device = device;
+    int rc = h->build();
+    if (rc) { delete h; return rc; }
+    GYRE_HIP_CHECK(hipDeviceSynchronize());
+    *out = h;
+    return 0;
+}
+void gyre_vae_destroy(gyre_vae* h) { delete h; }
+int gyre_vae_num_params(const gyre_vae* h) { return h ? (int)h->store.params.size() : 0; }
+const char* gyre_vae_param_key(const gyre_vae* h, int i) {
+    return (h && i >= 0 && i < (int)h->store.params.size()) ? h->store.params[i]->key.c_str() : nullptr;
+}
+int gyre_vae_set_weight(gyre_vae* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* st) {
+    if (!h || !key || !p || !shape) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return h->store.set_weight(key, p, dtype, shape, ndim, (hipStream_t)st);
+}
+// encoder-only / decoder-only use is allowed: finalize checks everything, the run paths only need their half
+int gyre_vae_finalize(gyre_vae* h, void* st) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null handle");
+    return h->store.finalize();
+}
+size_t gyre_vae_workspace_bytes(gyre_vae* h, int B, int H, int W, int decode) {
+    if (!h) return 0;
+    int rc = decode ? h->run_decode(true, nullptr, nullptr, 0, B, H, W, nullptr, 0, nullptr, 0)
+                    : h->run_encode(true, nullptr, nullptr, 0, B, H, W, nullptr, 0, nullptr, 0);
+    return rc ? 0 : h->ex.arena.peak;
+}
+int gyre_vae_encode(gyre_vae* h, void* st, const void* img, int idt, int B, int H, int W, void* ws, size_t wsb,
+                    void* out, int odt) {
+    if (!h || !img || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (idt < 0 || idt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    g_launches = 0;
+    return h->run_encode(false, (hipStream_t)st, img, idt, B, H, W, ws, wsb, out, odt);
+}
+int gyre_vae_decode(gyre_vae* h, void* st, const void* z, int idt, int B, int hl, int wl, void* ws, size_t wsb,
+                    void* out, int odt) {
+    if (!h || !z || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (idt < 0 || idt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    g_launches = 0;
+    return h->run_decode(false, (hipStream_t)st, z, idt, B, hl, wl, ws, wsb, out, odt);
+}
+
+// ---- single operators -----------------------------------------------------------------------
+size_t gyre_op_groupnorm_workspace(int B, int HW, int C, int groups) { return gn_workspace_bytes(B, HW, C, groups); }
+int gyre_op_groupnorm(void* st, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
+                      const float* gamma, const float* beta, float eps, int silu, void* ws, size_t wsb, void* y) {
+    if (!x || !gamma || !beta || !ws || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (wsb < gn_workspace_bytes(B, HW, C, groups)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "groupnorm workspace too small");
+    GnParams p;
+    p.x = (const bf16_t*)x; p.x2 = x2 ? (const bf16_t*)x2 : (const bf16_t*)x; p.C1 = x2 ? C1 : C;
+    p.B = B; p.HW = HW; p.C = C; p.G = groups; p.gamma = gamma; p.beta = beta; p.eps = eps; p.silu = silu;
+    p.nchunks = gn_pick_chunks(B, HW, C);
+    p.partial = (float*)ws;
+    p.scale_shift = (float*)((char*)ws + align_up((size_t)B * p.nchunks * groups * 2 * sizeof(float), 256));
+    p.y = (bf16_t*)y;
+    TRY(launch_groupnorm_stats((hipStream_t)st, p));
+    return launch_groupnorm_apply((hipStream_t)st, p);
+}
+int gyre_op_layernorm(void* st, const void* x, int M, int C, const float* g, const float* b, float eps, void* y) {
+    if (!x || !g || !b || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_layernorm((hipStream_t)st, (const bf16_t*)x, M, C, g, b, eps, (bf16_t*)y);
+}
+int gyre_op_linear(void* st, const void* x, int M, int K, const void* w, int N, const float* bias, const void* residual,
+                   int geglu, void* y) {
+    if (!x || !w || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K;
+    p.N = geglu ? 2 * N : N; p.M = M; p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = N; p.geglu = geglu;
+    p.out = y; p.ldc = N; p.out_mode = OUT_BF16;
+    return launch_gemm((hipStream_t)st, p);
+}
+int gyre_op_linear_t(void* st, const void* x, int M, int K, const void* w, int N, const float* bias, int tokens, int ldt,
+                     void* y) {
+    if (!x || !w || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K; p.N = N; p.M = M;
+    p.bias = bias; p.out = y; p.out_mode = OUT_BF16_T; p.tokens_per_batch = tokens; p.ldt = ldt;
+    return launch_gemm((hipStream_t)st, p);
+}
+int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, const void* w, int Cout, const float* bias,
+                    const void* residual, int stride, int ups, int asym, void* y) {
+    if (!x || !w || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    int pad = asym ? 0 : 1;
+    int Hin = ups ? 2 * Hi : Hi, Win = ups ? 2 * Wi : Wi;
+    int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = Cin; p.mode = GEMM_CONV3; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
+    p.stride = stride; p.pad = pad; p.ups = ups; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * Ho * Wo;
+    p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = Cout; p.rows_per_sample = Ho * Wo;
+    p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
+    return launch_gemm((hipStream_t)st, p);
+}
+int gyre_op_repack_conv_weight(void* st, const float* w, int Cout, int Cin, int KH, int KW, int Cin_pad, void* out) {
+    if (!w || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_repack_conv((hipStream_t)st, w, 0, Cout, Cin, KH, KW, Cin_pad, (bf16_t*)out);
+}
+int gyre_op_repack_linear_weight(void* st, const float* w, int O, int I, int geglu, void* out) {
+    if (!w || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_repack_linear((hipStream_t)st, w, 0, O, I, geglu, (bf16_t*)out);
+}
+int gyre_op_repack_bias(void* st, const float* b, int n, int geglu, float* out) {
+    if (!b || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_cast_f32((hipStream_t)st, b, 0, (size_t)n, geglu, out);
+}
+int gyre_op_attention(void* st, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int B, int heads,
+                      int Nq, int Nk, int D, void* o, int ldo) {
+    if (!q || !k || !vt || !o) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    AttnParams a;
+    a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vt = (const bf16_t*)vt; a.ldvt = ldvt;
+    a.o = (bf16_t*)o; a.ldo = ldo; a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    return launch_attention((hipStream_t)st, a);
+}
+int gyre_op_nchw_to_nhwc(void* st, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y) {
+    if (!x || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_nchw_to_nhwc((hipStream_t)st, x, dtype, B, C, HW, Cpad, (bf16_t*)y);
+}
+int gyre_op_copy_probe(void* st, const void* src, void* dst, size_t bytes) {
+    if (!src || !dst) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    return launch_copy_probe((hipStream_t)st, src, dst, bytes);
+}
+
+}  // extern "C"

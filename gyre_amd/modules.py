@@ -1,0 +1,367 @@
+"""nn.Module shells over the native UNet / VAE (the drop-in boundary).
+
+The reference swaps model classes through engines.yaml ``class: "pkg.mod.Class"``
+(gyre/manager.py:1024-1066,1114-1143) and then only touches this surface:
+
+  UNet   ``unet(latents, t, encoder_hidden_states=...).sample``   unet/core.py:262-274
+         ``unet.config.in_channels / sample_size / _diffusers_version``, ``unet.dtype``,
+         ``.modules()`` sweeps (LoRA removal, unified_pipeline.py:2193-2200), ``clone_model``
+         (model_utils.py:172-259: ordinary nn.Module parameters)
+  VAE    ``vae.encode(x).latent_dist.sample(generator=g)``         unified_pipeline.py:309-313
+         ``vae.decode(z).sample``                                   unified_pipeline.py:1531-1533
+         ``vae.config.block_out_channels``, ``vae.dtype``, enable/disable_slicing/tiling
+
+so these classes are plain ``nn.Module`` trees whose ``state_dict()`` keys are exactly
+the diffusers checkpoint names (manager.py:1068-1112 ``load_state_dict`` fallback).
+The parameters are the host/torch master copy; the first forward on a GPU uploads
++ repacks them into libgyre_hip's own bf16 NHWC/KRSC buffers.  All compute happens
+in the HIP library - there is no PyTorch fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .config import UNetConfig, VAEConfig, sd15_unet, sd15_vae
+from .weights import synthetic_state_dict, unet_param_shapes, vae_param_shapes
+
+
+class _Node(nn.Module):
+    """Anonymous container; the tree only exists to give parameters diffusers names."""
+
+
+def _build_tree(root: nn.Module, shapes) -> None:
+    for key, shape in shapes.items():
+        parts = key.split(".")
+        node = root
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape), requires_grad=False))
+
+
+class _NativeModule(nn.Module):
+    """Common weight-sync / workspace machinery."""
+
+    _kind = ""
+
+    def __init__(self):
+        super().__init__()
+        self._handle: Optional[int] = None
+        self._handle_device: Optional[torch.device] = None
+        self._dirty = True
+        self._ws: Optional[torch.Tensor] = None
+        self.register_load_state_dict_post_hook(lambda m, ik: m._invalidate())
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def _invalidate(self):
+        self._dirty = True
+
+    def _apply(self, fn, *a, **k):  # .to() / .half() / .cuda(): the native copy is stale afterwards
+        r = super()._apply(fn, *a, **k)
+        self._dirty = True
+        return r
+
+    def _destroy(self):
+        if getattr(self, "_handle", None):
+            getattr(_lib.lib(), f"gyre_{self._kind}_destroy")(C.c_void_p(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _c_cfg(self):
+        raise NotImplementedError
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _sync(self, device: torch.device) -> int:
+        """Create the native handle on `device` if needed and (re)upload dirty weights."""
+        L = _lib.lib()
+        if device.type != "cuda":
+            raise _lib.GyreError(f"{type(self).__name__} runs on the MI355X HIP path only; move it to a GPU "
+                                 f"(no CPU fallback)")
+        if self._handle is not None and self._handle_device != device:
+            self._destroy()
+        with torch.cuda.device(device):
+            if self._handle is None:
+                h = C.c_void_p()
+                cfg = self._c_cfg()
+                _lib.check(getattr(L, f"gyre_{self._kind}_create")(C.byref(cfg), device.index or 0, C.byref(h)))
+                self._handle, self._handle_device, self._dirty = h.value, device, True
+            if self._dirty:
+                st = _lib.stream_ptr(device)
+                setw = getattr(L, f"gyre_{self._kind}_set_weight")
+                for key, p in self.state_dict().items():
+                    t = p.detach()
+                    if t.device != device:
+                        t = t.to(device)
+                    t = t.contiguous()
+                    shape = (C.c_int64 * t.ndim)(*t.shape)
+                    _lib.check(setw(C.c_void_p(self._handle), key.encode(), C.c_void_p(t.data_ptr()),
+                                    _lib.dtype_code(t), shape, t.ndim, C.c_void_p(st)))
+                _lib.check(getattr(L, f"gyre_{self._kind}_finalize")(C.c_void_p(self._handle), C.c_void_p(st)))
+                torch.cuda.current_stream(device).synchronize()  # load time only: temporaries may now be freed
+                self._dirty = False
+        return self._handle
+
+    def _workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        if nbytes == 0:
+            raise _lib.GyreError("libgyre_hip: " + _lib.lib().gyre_last_error().decode())
+        if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # -- loading -----------------------------------------------------------------------------
+    @classmethod
+    def from_config(cls, config=None, **kw):
+        return cls(config, **kw) if config is not None else cls(**kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = None, **_ignored):
+        """Reads the HF diffusers folder layout (config.json + *.safetensors) without diffusers;
+        signature subset of what gyre/manager.py:1176-1242 passes."""
+        from safetensors.torch import load_file
+        cfg = None
+        cj = os.path.join(path, "config.json")
+        if os.path.exists(cj):
+            with open(cj) as f:
+                cfg = cls._config_from_json(json.load(f))
+        model = cls(cfg) if cfg is not None else cls()
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors in {path}")
+        model.load_state_dict(load_file(os.path.join(path, files[0])))
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        model._source = path
+        return model.eval()
+
+    def load_synthetic(self, seed: int = 0):
+        """Seeded synthetic weights of the exact architecture (no SD checkpoints exist offline)."""
+        self.load_state_dict(synthetic_state_dict(self._shapes(), seed))
+        return self
+
+
+class GyreHipUNet(_NativeModule):
+    """Drop-in for diffusers.UNet2DConditionModel on the reference's hot path."""
+
+    _kind = "unet"
+
+    def __init__(self, config: Optional[UNetConfig] = None):
+        super().__init__()
+        self.config = config or sd15_unet()
+        _build_tree(self, unet_param_shapes(self.config))
+
+    def _shapes(self):
+        return unet_param_shapes(self.config)
+
+    @staticmethod
+    def _config_from_json(j: dict) -> UNetConfig:
+        boc = tuple(j.get("block_out_channels", (320, 640, 1280, 1280)))
+        n = len(boc)
+        down = j.get("down_block_types", ["CrossAttnDownBlock2D"] * (n - 1) + ["DownBlock2D"])
+        ahd = j.get("attention_head_dim", 8)
+        heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * n
+        return UNetConfig(in_channels=j.get("in_channels", 4), out_channels=j.get("out_channels", 4),
+                          block_out_channels=boc, layers_per_block=j.get("layers_per_block", 2),
+                          attn_levels=tuple("CrossAttn" in d for d in down), num_heads=heads,
+                          cross_attention_dim=j.get("cross_attention_dim", 768),
+                          norm_num_groups=j.get("norm_num_groups", 32), transformer_depth=(1,) * n,
+                          use_linear_projection=bool(j.get("use_linear_projection", False)),
+                          sample_size=j.get("sample_size", 64), flip_sin_to_cos=j.get("flip_sin_to_cos", True),
+                          freq_shift=float(j.get("freq_shift", 0)))
+
+    def _c_cfg(self):
+        c, cfg = self.config, _lib.UNetCfg()
+        n = len(c.block_out_channels)
+        cfg.in_channels, cfg.out_channels, cfg.n_levels = c.in_channels, c.out_channels, n
+        for i in range(n):
+            cfg.block_out_channels[i] = c.block_out_channels[i]
+            cfg.attn_levels[i] = int(c.attn_levels[i])
+            cfg.num_heads[i] = c.num_heads[i]
+            cfg.transformer_depth[i] = c.transformer_depth[i]
+        cfg.layers_per_block = c.layers_per_block
+        cfg.cross_attention_dim = c.cross_attention_dim
+        cfg.norm_num_groups = c.norm_num_groups
+        cfg.use_linear_projection = int(c.use_linear_projection)
+        cfg.flip_sin_to_cos = int(c.flip_sin_to_cos)
+        cfg.freq_shift = c.freq_shift
+        return cfg
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, adapter_states=None,
+                return_dict: bool = True, **_ignored):
+        if encoder_hidden_states is None:
+            raise ValueError("encoder_hidden_states is required")
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None \
+                or adapter_states is not None:
+            raise NotImplementedError("ControlNet / T2I residual injection is outside the native hot path")
+        if sample.ndim != 4 or sample.shape[1] != self.config.in_channels:
+            raise ValueError(f"expected latents [B,{self.config.in_channels},H,W], got {tuple(sample.shape)}")
+        B, _, H, W = sample.shape
+        if encoder_hidden_states.ndim != 3 or encoder_hidden_states.shape[0] != B \
+                or encoder_hidden_states.shape[2] != self.config.cross_attention_dim:
+            raise ValueError(f"expected encoder_hidden_states [{B},S,{self.config.cross_attention_dim}], "
+                             f"got {tuple(encoder_hidden_states.shape)}")
+        dev = sample.device
+        h = self._sync(dev)
+        x = sample.contiguous()
+        ctx = encoder_hidden_states.to(dev).contiguous()
+        _lib.require_gpu_tensor(x, "latents")
+        t = torch.as_tensor(timestep, device=dev)
+        t = t.to(torch.int64).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        if t.numel() != B:
+            raise ValueError(f"timestep must be a scalar or have {B} elements")
+        t = t.contiguous()
+        S = ctx.shape[1]
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            need = L.gyre_unet_workspace_bytes(C.c_void_p(h), B, H, W, S)
+            if need == 0:
+                _lib.check(-1 if "unet:" in L.gyre_last_error().decode() else -4)
+            ws = self._workspace(need, dev)
+            wp = (ws.data_ptr() + 255) & ~255
+            out = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
+            _lib.check(L.gyre_unet_forward(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                           _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                                           _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
+                                           C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+
+class DiagonalGaussian:
+    """diffusers DiagonalGaussianDistribution [3P] as used at unified_pipeline.py:309-313."""
+
+    def __init__(self, moments: torch.Tensor):
+        self.parameters = moments
+        self.mean, self.logvar = torch.chunk(moments, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        gdev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype)
+        return self.mean + self.std * noise.to(self.mean.device)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+class GyreHipVAE(_NativeModule):
+    """Drop-in for diffusers.AutoencoderKL on the reference's hot path."""
+
+    _kind = "vae"
+
+    def __init__(self, config: Optional[VAEConfig] = None):
+        super().__init__()
+        self.config = config or sd15_vae()
+        _build_tree(self, vae_param_shapes(self.config))
+
+    def _shapes(self):
+        return vae_param_shapes(self.config)
+
+    @staticmethod
+    def _config_from_json(j: dict) -> VAEConfig:
+        return VAEConfig(in_channels=j.get("in_channels", 3), out_channels=j.get("out_channels", 3),
+                         latent_channels=j.get("latent_channels", 4),
+                         block_out_channels=tuple(j.get("block_out_channels", (128, 256, 512, 512))),
+                         layers_per_block=j.get("layers_per_block", 2), norm_num_groups=j.get("norm_num_groups", 32),
+                         scaling_factor=j.get("scaling_factor", 0.18215), sample_size=j.get("sample_size", 512))
+
+    def _c_cfg(self):
+        c, cfg = self.config, _lib.VAECfg()
+        n = len(c.block_out_channels)
+        cfg.in_channels, cfg.out_channels, cfg.latent_channels, cfg.n_levels = c.in_channels, c.out_channels, \
+            c.latent_channels, n
+        for i in range(n):
+            cfg.block_out_channels[i] = c.block_out_channels[i]
+        cfg.layers_per_block = c.layers_per_block
+        cfg.norm_num_groups = c.norm_num_groups
+        return cfg
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # accept the post-0.16 attention key names (to_q/to_k/to_v/to_out.0) as aliases
+        ren = {".to_q.": ".query.", ".to_k.": ".key.", ".to_v.": ".value.", ".to_out.0.": ".proj_attn."}
+        fixed = {}
+        for k, v in state_dict.items():
+            if ".attentions." in k:
+                for a, b in ren.items():
+                    k = k.replace(a, b)
+            fixed[k] = v
+        return super().load_state_dict(fixed, strict=strict, **kw)
+
+    # the reference toggles these for small-VRAM GPUs (pipeline_wrapper.py:171-186); with 288 GB
+    # of HBM the whole batch is decoded in one pass, so they are accepted and ignored.
+    def enable_slicing(self): pass
+    def disable_slicing(self): pass
+    def enable_tiling(self): pass
+    def disable_tiling(self): pass
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        if x.ndim != 4 or x.shape[1] != self.config.in_channels:
+            raise ValueError(f"expected image [B,{self.config.in_channels},H,W], got {tuple(x.shape)}")
+        dev = x.device
+        h = self._sync(dev)
+        x = x.contiguous()
+        _lib.require_gpu_tensor(x, "image")
+        B, _, H, W = x.shape
+        L = _lib.lib()
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        with torch.cuda.device(dev):
+            need = L.gyre_vae_workspace_bytes(C.c_void_p(h), B, H, W, 0)
+            if need == 0:
+                _lib.check(-1)
+            ws = self._workspace(need, dev)
+            wp = (ws.data_ptr() + 255) & ~255
+            out = torch.empty((B, 2 * self.config.latent_channels, H // f, W // f), dtype=x.dtype, device=dev)
+            _lib.check(L.gyre_vae_encode(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                         _lib.dtype_code(x), B, H, W, C.c_void_p(wp), need,
+                                         C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
+        dist = DiagonalGaussian(out)
+        return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        if z.ndim != 4 or z.shape[1] != self.config.latent_channels:
+            raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
+        dev = z.device
+        h = self._sync(dev)
+        z = z.contiguous()
+        _lib.require_gpu_tensor(z, "latents")
+        B, _, hl, wl = z.shape
+        L = _lib.lib()
+        f = 2 ** (len(self.config.block_out_channels) - 1)
+        with torch.cuda.device(dev):
+            need = L.gyre_vae_workspace_bytes(C.c_void_p(h), B, hl, wl, 1)
+            if need == 0:
+                _lib.check(-1)
+            ws = self._workspace(need, dev)
+            wp = (ws.data_ptr() + 255) & ~255
+            out = torch.empty((B, self.config.out_channels, hl * f, wl * f), dtype=z.dtype, device=dev)
+            _lib.check(L.gyre_vae_decode(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(z.data_ptr()),
+                                         _lib.dtype_code(z), B, hl, wl, C.c_void_p(wp), need,
+                                         C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
+        return SimpleNamespace(sample=out) if return_dict else (out,)

@@ -1,0 +1,174 @@
+/*
+ * gyre_hip.h - C ABI of libgyre_hip.so, the MI355X (gfx950) native UNet / VAE
+ * for Gyre's diffusion generation path.
+ *
+ * Nothing like this exists in the reference (it is pure Python and crosses into
+ * third-party diffusers modules); each entry point below replaces one of the
+ * reference's Python call sites across that boundary:
+ *
+ *   gyre_unet_forward     <- gyre/pipeline/unet/core.py:262-274
+ *                            `self.unet(latents, t, encoder_hidden_states=...).sample`
+ *                            (Protocol gyre/pipeline/unet/types.py:26-39)
+ *   gyre_vae_encode       <- gyre/pipeline/unified_pipeline.py:309
+ *                            `self.pipeline.vae.encode(image).latent_dist`  (returns the moments;
+ *                            the per-generator posterior sample :311-313 stays host PyTorch)
+ *   gyre_vae_decode       <- gyre/pipeline/unified_pipeline.py:1531-1533  `self.vae.decode(latents).sample`
+ *   gyre_*_create         <- gyre/manager.py:1068-1112  `Class(**config)`
+ *   gyre_*_set_weight     <- gyre/manager.py:1068-1112  `load_state_dict` (keys = diffusers names,
+ *                            the key space gyre/ckpt_utils.py:259-285 produces)
+ *   gyre_*_destroy        <- gyre/pipeline/pipeline_wrapper.py:144-158 deactivate()
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer marked "dev" is a device pointer
+ *     valid on the handle's device.  No torch / C++ types cross this boundary.
+ *   - every function returns 0 on success or a negative gyre_status; on failure
+ *     gyre_last_error() (thread-local) holds a message.  Nothing throws.
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void* here so the
+ *     header needs no HIP include).  No function calls hipDeviceSynchronize; the
+ *     caller owns synchronisation.  Handles hold no global mutable state: different
+ *     handles may be used concurrently from different threads (one in-flight call
+ *     per handle, the reference's one-thread-per-device-slot rule,
+ *     gyre/manager.py:2107-2139).
+ *   - activations cross the boundary in the reference's own layout: NCHW for
+ *     latents/images, [B,S,D] for text embeddings; dtype per call (gyre_dtype).
+ *     Internally everything is NHWC bf16 with fp32 accumulation.
+ *   - `workspace` is caller-allocated device scratch (e.g. from the torch caching
+ *     allocator) of at least gyre_*_workspace_bytes(...) bytes, 256-byte aligned.
+ */
+#ifndef GYRE_HIP_H
+#define GYRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYRE_ABI_VERSION 1
+
+typedef enum { GYRE_F32 = 0, GYRE_BF16 = 1, GYRE_F16 = 2 } gyre_dtype;
+
+typedef enum {
+    GYRE_OK = 0,
+    GYRE_ERR_INVALID = -1,     /* bad argument / shape / dtype            -> Python ValueError */
+    GYRE_ERR_KEY = -2,         /* unknown or shape-mismatched weight key -> Python KeyError   */
+    GYRE_ERR_INCOMPLETE = -3,  /* forward before every weight was set    -> RuntimeError      */
+    GYRE_ERR_WORKSPACE = -4,   /* workspace too small                    -> RuntimeError      */
+    GYRE_ERR_HIP = -5,         /* a HIP runtime call failed              -> RuntimeError      */
+    GYRE_ERR_UNSUPPORTED = -6  /* configuration not implemented          -> NotImplementedError */
+} gyre_status;
+
+#define GYRE_MAX_LEVELS 8
+
+/* Mirrors the diffusers UNet2DConditionModel config.json fields the reference
+ * relies on (SD1.x values from gyre/ldm_config/v1-inference.yaml:29-47). */
+typedef struct {
+    int32_t in_channels;             /* 4, or 9 for the runway inpaint UNet (unified_pipeline.py:668-690) */
+    int32_t out_channels;            /* 4 */
+    int32_t n_levels;                /* 4 */
+    int32_t block_out_channels[GYRE_MAX_LEVELS]; /* 320,640,1280,1280 */
+    int32_t layers_per_block;        /* 2 */
+    int32_t attn_levels[GYRE_MAX_LEVELS];        /* 1,1,1,0 */
+    int32_t num_heads[GYRE_MAX_LEVELS];          /* 8,8,8,8 */
+    int32_t transformer_depth[GYRE_MAX_LEVELS];  /* 1,1,1,1 */
+    int32_t cross_attention_dim;     /* 768 */
+    int32_t norm_num_groups;         /* 32 */
+    int32_t use_linear_projection;   /* 0 for SD1.x */
+    int32_t flip_sin_to_cos;         /* 1 */
+    float   freq_shift;              /* 0 */
+} gyre_unet_cfg;
+
+typedef struct {
+    int32_t in_channels;             /* 3 */
+    int32_t out_channels;            /* 3 */
+    int32_t latent_channels;         /* 4 */
+    int32_t n_levels;                /* 4 */
+    int32_t block_out_channels[GYRE_MAX_LEVELS]; /* 128,256,512,512 */
+    int32_t layers_per_block;        /* 2 */
+    int32_t norm_num_groups;         /* 32 */
+} gyre_vae_cfg;
+
+typedef struct gyre_unet gyre_unet;
+typedef struct gyre_vae gyre_vae;
+
+/* ---- library ---------------------------------------------------------- */
+int gyre_abi_version(void);
+const char* gyre_last_error(void);
+/* number of distinct kernel launches issued by this thread's last forward/encode/decode */
+int64_t gyre_last_launch_count(void);
+
+/* ---- UNet --------------------------------------------------------------- */
+int gyre_unet_create(const gyre_unet_cfg* cfg, int device, gyre_unet** out);
+void gyre_unet_destroy(gyre_unet* h);
+/* Number of parameter tensors the handle expects / key of the i-th one (diffusers name). */
+int gyre_unet_num_params(const gyre_unet* h);
+const char* gyre_unet_param_key(const gyre_unet* h, int i);
+/* Copy+repack one tensor (PyTorch layout: conv OIHW, linear [out,in], vectors [n]) from
+ * `dev_ptr` (contiguous, `dtype`) into library-owned bf16/f32 buffers.  Asynchronous on `stream`;
+ * the source may be released once the stream has passed this point. */
+int gyre_unet_set_weight(gyre_unet* h, const char* diffusers_key, const void* dev_ptr, int dtype,
+                         const int64_t* shape, int ndim, void* stream);
+/* 0 when every expected key has been set; otherwise GYRE_ERR_INCOMPLETE (message lists a missing key). */
+int gyre_unet_finalize(gyre_unet* h, void* stream);
+size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S);
+/* eps[B,out_ch,H,W] = unet(x[B,in_ch,H,W], t[B] (int64, dev), ctx[B,S,cross_dim]).
+ * H, W are latent sizes and must be multiples of 2^(n_levels-1). */
+int gyre_unet_forward(gyre_unet* h, void* stream,
+                      const void* x_nchw, int x_dtype,
+                      const int64_t* t_dev,
+                      const void* ctx, int ctx_dtype,
+                      int B, int H, int W, int S,
+                      void* workspace, size_t workspace_bytes,
+                      void* eps_out_nchw, int out_dtype);
+
+/* ---- VAE ---------------------------------------------------------------- */
+int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out);
+void gyre_vae_destroy(gyre_vae* h);
+int gyre_vae_num_params(const gyre_vae* h);
+const char* gyre_vae_param_key(const gyre_vae* h, int i);
+int gyre_vae_set_weight(gyre_vae* h, const char* diffusers_key, const void* dev_ptr, int dtype,
+                        const int64_t* shape, int ndim, void* stream);
+int gyre_vae_finalize(gyre_vae* h, void* stream);
+size_t gyre_vae_workspace_bytes(gyre_vae* h, int B, int H, int W, int decode);
+/* moments[B,2*z,H/8,W/8] (mean | logvar, f32) = quant_conv(encoder(image[B,3,H,W] in -1..1)) */
+int gyre_vae_encode(gyre_vae* h, void* stream, const void* image_nchw, int in_dtype, int B, int H, int W,
+                    void* workspace, size_t workspace_bytes, void* moments_out_nchw, int out_dtype);
+/* image[B,3,8h,8w] = decoder(post_quant_conv(z[B,z,h,w])) */
+int gyre_vae_decode(gyre_vae* h, void* stream, const void* z_nchw, int in_dtype, int B, int h_lat, int w_lat,
+                    void* workspace, size_t workspace_bytes, void* image_out_nchw, int out_dtype);
+
+/* ---- single operators (kernel-level parity tests and profiling) --------- */
+/* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */
+int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
+                      const float* gamma, const float* beta, float eps, int silu,
+                      void* workspace, size_t workspace_bytes, void* y);
+size_t gyre_op_groupnorm_workspace(int B, int HW, int C, int groups);
+int gyre_op_layernorm(void* stream, const void* x, int M, int C, const float* gamma, const float* beta,
+                      float eps, void* y);
+/* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (+residual); geglu!=0: w holds [2N,K], y = val*gelu(gate) */
+int gyre_op_linear(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N,
+                   const float* bias, const void* residual, int geglu, void* y);
+/* V^T form used by attention: y[(b*N + n)*ldt + tok] = (x @ w^T + bias)[b*tokens + tok][n] */
+int gyre_op_linear_t(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N,
+                     const float* bias, int tokens_per_batch, int ldt, void* y);
+/* 3x3 conv NHWC, weights already repacked [Cout][3][3][Cin] bf16; ups!=0 fuses nearest-2x upsample
+ * of the input; stride 1|2; pad 1 (pad 0 + bottom/right zero pad when asym!=0, VAE downsample). */
+int gyre_op_conv3x3(void* stream, const void* x, int B, int Hi, int Wi, int Cin, const void* w_krsc, int Cout,
+                    const float* bias, const void* residual, int stride, int ups, int asym, void* y);
+/* Repack helpers used by the tests to build the layouts above from PyTorch-layout f32 tensors */
+int gyre_op_repack_conv_weight(void* stream, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                               void* w_krsc_bf16);
+int gyre_op_repack_linear_weight(void* stream, const float* w_oi, int O, int I, int geglu_interleave, void* w_bf16);
+int gyre_op_repack_bias(void* stream, const float* b, int n, int geglu_interleave, float* out);
+/* o[B,Nq,H*D] = softmax(q k^T * D^-1/2) v ; q[B,Nq,H*D] (ldq), k[B,Nk,H*D] (ldk), vt[B,H*D,ldvt] (V transposed) */
+int gyre_op_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                      int B, int heads, int Nq, int Nk, int D, void* o, int ldo);
+int gyre_op_nchw_to_nhwc(void* stream, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y_bf16);
+/* Device-side memcpy-rate probe used by bench.py to calibrate the HBM roofline on the box. */
+int gyre_op_copy_probe(void* stream, const void* src, void* dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYRE_HIP_H */

@@ -1,0 +1,71 @@
+"""Helpers for the -m gpu parity tests: call libgyre_hip through its C ABI on torch-allocated
+device buffers and compare with fp32 ATen references."""
+import ctypes as C
+
+import torch
+
+from gyre_amd import _lib
+
+DEV = "cuda:0"
+
+
+def vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def report(name, got, ref, tol):
+    e = rel_l2(got, ref)
+    d = (got.double().cpu() - ref.double().cpu()).abs()
+    print(f"[parity] {name}: rel_l2={e:.3e} max_abs={float(d.max()):.3e} ref_absmax={float(ref.abs().max()):.3e} tol={tol}")
+    if not e <= tol:
+        idx = int(d.flatten().argmax())
+        print(f"   worst at flat index {idx}: got {float(got.flatten()[idx]):.5f} ref {float(ref.flatten()[idx]):.5f}")
+        # error distribution along the last axis helps to spot layout bugs
+        if d.ndim >= 2:
+            print("   per-last-axis mean abs err (first 16):", d.reshape(-1, d.shape[-1]).mean(0)[:16].tolist())
+    assert e <= tol, f"{name}: rel_l2 {e:.3e} > {tol}"
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def repack_conv(w_oihw: torch.Tensor, cin_pad=None) -> torch.Tensor:
+    L = _lib.lib()
+    O, I, KH, KW = w_oihw.shape
+    cin_pad = cin_pad or (I + 7) // 8 * 8
+    src = w_oihw.float().contiguous().to(DEV)
+    out = torch.zeros(O * KH * KW * cin_pad, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_repack_conv_weight(st(), vp(src), O, I, KH, KW, cin_pad, vp(out)))
+    return out
+
+
+def repack_linear(w: torch.Tensor, geglu=False) -> torch.Tensor:
+    L = _lib.lib()
+    O, I = w.shape
+    src = w.float().contiguous().to(DEV)
+    out = torch.zeros(O * I, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_repack_linear_weight(st(), vp(src), O, I, int(geglu), vp(out)))
+    return out
+
+
+def repack_bias(b: torch.Tensor, geglu=False) -> torch.Tensor:
+    L = _lib.lib()
+    src = b.float().contiguous().to(DEV)
+    out = torch.zeros(b.numel(), dtype=torch.float32, device=DEV)
+    _lib.check(L.gyre_op_repack_bias(st(), vp(src), b.numel(), int(geglu), vp(out)))
+    return out

@@ -1,0 +1,127 @@
+"""Model-level parity (-m gpu): the native UNet / VAE behind the nn.Module shells against the
+fp32 CPU oracle on the same seeded weights and inputs.
+
+Tolerances (bf16 storage / fp32 accumulate vs fp32 oracle; SURVEY.md section 8d parity gates):
+single UNet call rel-L2 <= 3e-2, VAE <= 3e-2.
+"""
+import pytest
+import torch
+
+from gyre_amd import config as gcfg
+from gyre_amd import weights
+from gyre_amd.modules import GyreHipUNet, GyreHipVAE
+from gpu_util import DEV, randn, report
+from oracle import models_ref as M
+
+pytestmark = pytest.mark.gpu
+
+
+def make_unet(cfg, seed=0):
+    sd = weights.synthetic_state_dict(weights.unet_param_shapes(cfg), seed)
+    net = GyreHipUNet(cfg)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+def make_vae(cfg, seed=0):
+    sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg), seed)
+    net = GyreHipVAE(cfg)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+@pytest.mark.parametrize("inch,H,W,S", [(4, 16, 16, 77), (9, 16, 24, 77), (4, 8, 8, 154)])
+def test_tiny_unet_parity(inch, H, W, S):
+    cfg = gcfg.tiny_unet(inch)
+    net, sd = make_unet(cfg)
+    x = randn(2, inch, H, W, seed=1)
+    t = torch.tensor([981, 17])
+    ctx = randn(2, S, cfg.cross_attention_dim, seed=2)
+    ref = M.unet_forward(sd, cfg, x, t, ctx)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    report(f"tiny unet in{inch} {H}x{W} S{S}", got.cpu(), ref, 3e-2)
+
+
+def test_tiny_unet_dtypes_and_scalar_t():
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 16, 16, seed=1)
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    ref = M.unet_forward(sd, cfg, x, torch.tensor([500, 500]), ctx)
+    for dt in (torch.bfloat16, torch.float16):
+        got = net(x.to(DEV, dt), 500, encoder_hidden_states=ctx.to(DEV, dt)).sample
+        assert got.dtype == dt
+        report(f"tiny unet io {dt}", got.float().cpu(), ref, 4e-2)
+
+
+def test_unet_batch_independence_bit_exact():
+    """reference property tests/batch_independance.py:15-27, as a bit-exact check."""
+    cfg = gcfg.tiny_unet()
+    net, _ = make_unet(cfg)
+    x = randn(3, 4, 16, 16, seed=3).to(DEV)
+    t = torch.tensor([900, 500, 20], device=DEV)
+    ctx = randn(3, 77, cfg.cross_attention_dim, seed=4).to(DEV)
+    full = net(x, t, encoder_hidden_states=ctx).sample
+    for i in range(3):
+        one = net(x[i:i + 1].contiguous(), t[i:i + 1], encoder_hidden_states=ctx[i:i + 1].contiguous()).sample
+        assert torch.equal(full[i:i + 1], one), f"sample {i} differs between batch compositions"
+    again = net(x, t, encoder_hidden_states=ctx).sample
+    assert torch.equal(full, again)
+
+
+def test_unet_errors():
+    cfg = gcfg.tiny_unet()
+    net, _ = make_unet(cfg)
+    x = randn(1, 4, 16, 16).to(DEV)
+    ctx = randn(1, 77, cfg.cross_attention_dim).to(DEV)
+    with pytest.raises(ValueError):
+        net(x[:, :3].contiguous(), 1, encoder_hidden_states=ctx)
+    with pytest.raises(ValueError):
+        net(randn(1, 4, 12, 12).to(DEV), 1, encoder_hidden_states=ctx)  # 12 is not a multiple of 8
+    with pytest.raises(NotImplementedError):
+        net(x, 1, encoder_hidden_states=ctx, mid_block_additional_residual=x)
+    with pytest.raises(RuntimeError):
+        GyreHipUNet(cfg)(x.cpu(), 1, encoder_hidden_states=ctx.cpu())  # no CPU fallback
+
+
+def test_tiny_vae_parity():
+    cfg = gcfg.tiny_vae()
+    net, sd = make_vae(cfg)
+    z = randn(2, 4, 8, 12, seed=5)
+    ref = M.vae_decode(sd, cfg, z)
+    got = net.decode(z.to(DEV)).sample
+    report("tiny vae decode", got.cpu(), ref, 3e-2)
+    img = randn(2, 3, 64, 96, seed=6).clamp(-1, 1)
+    ref = M.vae_encode_moments(sd, cfg, img)
+    dist = net.encode(img.to(DEV)).latent_dist
+    report("tiny vae encode moments", dist.parameters.cpu(), ref, 3e-2)
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    s = dist.sample(generator=g1)
+    ref_s = M.vae_posterior_sample(ref, g2)
+    report("tiny vae posterior sample", s.cpu(), ref_s, 3e-2)
+
+
+def test_sd15_unet_parity_full_size():
+    """Full SD1.5 UNet (859.5 M params), CFG pair at 64x64 latents, vs the fp32 CPU oracle."""
+    cfg = gcfg.sd15_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 64, 64, seed=7)
+    t = torch.tensor([981, 981])
+    ctx = randn(2, 77, 768, seed=8)
+    ref = M.unet_forward(sd, cfg, x, t, ctx)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    report("SD1.5 unet 2x4x64x64", got.cpu(), ref, 3e-2)
+
+
+def test_sd15_vae_decode_full_size():
+    cfg = gcfg.sd15_vae()
+    sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg), 0)
+    net = GyreHipVAE(cfg)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    z = randn(1, 4, 64, 64, seed=9)
+    ref = M.vae_decode(sd, cfg, z)
+    got = net.decode(z.to(DEV)).sample
+    assert got.shape == (1, 3, 512, 512)
+    report("SD1.5 vae decode 1x4x64x64", got.cpu(), ref, 3e-2)

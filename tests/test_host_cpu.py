@@ -1,0 +1,67 @@
+"""CPU-only checks of the host side: library exports, module trees, error behaviour."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from gyre_amd import _lib, config as gcfg, weights
+from gyre_amd.modules import GyreHipUNet, GyreHipVAE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gyre_hip.h")).read()
+    declared = set(re.findall(r"\b(gyre_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()  # loads and binds every symbol of _SIGS
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in gyre_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert L.gyre_abi_version() == 1
+
+
+def test_unet_state_dict_is_diffusers_keyed():
+    net = GyreHipUNet(gcfg.tiny_unet())
+    keys = list(net.state_dict().keys())
+    assert sorted(keys) == sorted(weights.unet_param_shapes(gcfg.tiny_unet()).keys())
+    assert "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight" in keys
+    assert "up_blocks.3.resnets.2.conv_shortcut.weight" in keys
+    assert net.config.in_channels == 4 and net.config.sample_size == 16
+    assert sum(1 for _ in net.modules()) > 100  # LoRA sweep walks .modules()
+
+
+def test_sd15_param_counts():
+    n = sum(torch.Size(s).numel() for s in weights.unet_param_shapes(gcfg.sd15_unet()).values())
+    assert n == 859_520_964  # SD1.x UNet
+    n = sum(torch.Size(s).numel() for s in weights.vae_param_shapes(gcfg.sd15_vae()).values())
+    assert n == 83_653_863   # SD1.x AutoencoderKL
+
+
+def test_vae_accepts_new_attention_key_names():
+    cfg = gcfg.tiny_vae()
+    sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg))
+    ren = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+    new = {}
+    for k, v in sd.items():
+        for a, b in ren.items():
+            k = k.replace(a, b)
+        new[k] = v
+    net = GyreHipVAE(cfg)
+    net.load_state_dict(new)
+    assert torch.equal(net.state_dict()["decoder.mid_block.attentions.0.query.weight"],
+                       sd["decoder.mid_block.attentions.0.query.weight"])
+
+
+def test_no_cpu_fallback():
+    net = GyreHipUNet(gcfg.tiny_unet())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 4, 16, 16), 1, encoder_hidden_states=torch.zeros(1, 77, 64))
+
+
+def test_product_does_not_import_oracle():
+    out = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "gyre_amd")],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", f"product code imports the oracle: {out}"
