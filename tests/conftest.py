@@ -16,3 +16,11 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz")))
+
+
+@pytest.fixture(autouse=True)
+def _gpu_keepalive(request):
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gpu_util
+        gpu_util.release_kept()

@@ -9,8 +9,19 @@ from gyre_amd import _lib
 DEV = "cuda:0"
 
 
+_KEEP = []  # device tensors whose raw pointers were handed to the library; cleared (after a sync) per test
+
+
 def vp(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    _KEEP.append(t)  # the C ABI sees raw pointers only: keep the tensor alive until the kernel has run
+    return C.c_void_p(t.data_ptr())
+
+
+def release_kept():
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def st():
