@@ -230,7 +230,9 @@ struct Exec {
         t.bytes = (size_t)B * H * W * C * elt;
         t.off = arena.alloc(t.bytes);
         if (t.off == (size_t)-1 || (!arena.dry && t.off + t.bytes > arena.cap))
-            GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small");
+            GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small: need " + std::to_string(t.bytes) + " B at offset " +
+                      std::to_string((long long)t.off) + ", capacity " + std::to_string(arena.cap) + " B (tensor " +
+                      std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" + std::to_string(C) + ")");
         t.p = arena.dry ? nullptr : (bf16_t*)(arena.base + t.off);
         return 0;
     }
@@ -309,12 +311,12 @@ struct Exec {
         return launch_layernorm(st, x.p, x.rows(), x.C, g, b, 1e-5f, y.p);
     }
     // multi-head attention of tokens x against kv source (self: kv == nullptr); out = proj(attn) + residual
-    int mha(const Tn& xq, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w, const Tn& residual,
-            Tn& out) {
+    int mha(const Tn& xq, bool cross, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w,
+            const Tn& residual, Tn& out) {
         const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
         Tn q, k, vt, ao;
         const bf16_t *qp, *kp; int ldq, ldk, Nk, ldvt;
-        if (!kvsrc) {  // self attention: fused Q|K projection, V projected straight into V^T
+        if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, 2 * C));
             TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
@@ -376,10 +378,10 @@ struct Exec {
         for (const TBlockW& bw : w.blocks) {
             Tn n, h2, ff;
             TRY(layernorm(h, bw.ln1g, bw.ln1b, n));
-            TRY(mha(n, nullptr, 0, 0, bw.a1, h, h2));
+            TRY(mha(n, false, nullptr, 0, 0, bw.a1, h, h2));
             free(n); free(h); h = h2;
             TRY(layernorm(h, bw.ln2g, bw.ln2b, n));
-            TRY(mha(n, ctx.p, S, ctx_dim, bw.a2, h, h2));
+            TRY(mha(n, true, ctx.p, S, ctx_dim, bw.a2, h, h2));
             free(n); free(h); h = h2;
             TRY(layernorm(h, bw.ln3g, bw.ln3b, n));
             TRY(alloc(ff, B, x.H, x.W, 4 * C));
@@ -739,7 +741,7 @@ struct gyre_vae {
     int vattn(Exec& e, const Tn& x, const AttnW& w, const float* g, const float* b, Tn& out) {
         Tn a;
         TRY(e.groupnorm(x, nullptr, g, b, 1e-6f, 0, a));
-        TRY(e.mha(a, nullptr, 0, 0, w, x, out));
+        TRY(e.mha(a, false, nullptr, 0, 0, w, x, out));
         e.free(a);
         return 0;
     }

@@ -1,0 +1,210 @@
+"""CPU tests of the product's host code (schedulers / samplers / CFG / pipeline) against the golden
+vectors from the reference and against the oracle pipeline, using oracle-backed model adapters
+(so no GPU is needed: this checks orchestration, not kernels)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from gyre_amd import config as gcfg, weights
+from gyre_amd import schedulers as PS
+from gyre_amd.modules import DiagonalGaussian
+from gyre_amd.pipeline import GyrePipeline, mask_to_latent_mask, round_mask, txt2img_latents
+from oracle import models_ref as M
+from oracle import pipeline_ref as PR
+from oracle import sched_ref as S
+
+
+def gens(seeds):
+    return [torch.Generator().manual_seed(int(s)) for s in seeds]
+
+
+def test_product_rng_matches_reference(golden):
+    seeds = golden["rng_seeds"]
+    assert np.array_equal(PS.batched_randn([2, 4, 8, 8], gens(seeds), "cpu", torch.float32).numpy(), golden["randn_2x4x8x8"])
+    assert np.array_equal(PS.batched_rand([2, 4, 8, 8], gens(seeds), "cpu", torch.float32).numpy(), golden["rand_2x4x8x8"])
+    with pytest.raises(ValueError):
+        PS.batched_randn([3, 4, 8, 8], gens(seeds), "cpu", torch.float32)
+
+
+def test_product_schedule_matches_reference(golden):
+    sch = PS.DiscreteSchedule()
+    assert np.array_equal(sch.alphas_cumprod.numpy(), golden["alphas_cumprod"])
+    for n in (20, 50):
+        ks = PS.KDiffusionScheduler("dpmpp_2m", gens([1]), "cpu")
+        ks.set_eps_unet(lambda x, t: x)
+        ks.set_timesteps(n)
+        assert np.array_equal(ks.sigmas.numpy(), golden[f"sigmas_n{n}"])
+        assert np.array_equal(sch.sigma_to_t(ks.sigmas[:-1]).numpy(), golden[f"sigma_to_t_n{n}"])
+
+
+def test_product_dpmpp_2m_matches_reference(golden):
+    seeds = golden["rng_seeds"]
+    for n in (20, 50):
+        calls = []
+
+        def toy(x, sigma):
+            calls.append(float(sigma))
+            return x / (1 + float(sigma) ** 2)
+
+        sigmas = torch.from_numpy(golden[f"sigmas_n{n}"])
+        x0 = PS.batched_randn([2, 4, 8, 8], gens(seeds), "cpu", torch.float32) * sigmas[0]
+        x = PS.sample_dpmpp_2m(toy, x0, sigmas, warmup_lms=True, ddim_cutoff=0.1)
+        assert len(calls) == n + 1
+        assert np.allclose(calls, golden[f"dpmpp2m_n{n}_eval_sigmas"], rtol=1e-7)
+        assert np.allclose(x.numpy(), golden[f"dpmpp2m_n{n}_x"], rtol=2e-6, atol=1e-7)
+        x = PS.sample_dpmpp_2m(toy, x0, sigmas)
+        assert np.allclose(x.numpy(), golden[f"dpmpp2m_plain_n{n}_x"], rtol=2e-6, atol=1e-7)
+
+
+def test_product_cfg_matches_reference(golden):
+    def f(latents, t):
+        w = torch.arange(1, latents.shape[0] + 1, dtype=latents.dtype).view(-1, 1, 1, 1)
+        return latents * w + t.view(-1, 1, 1, 1).to(latents.dtype) * 0.001
+
+    lat, t = torch.from_numpy(golden["cfg_in"]), torch.from_numpy(golden["cfg_t"])
+    assert np.array_equal(PS.CFGUNet_Parallel(f, 7.5, 2)(lat, t).numpy(), golden["cfg_parallel_out"])
+    out = PS.CFGUNet_Sequential(lambda l, tt: f(l, tt) * 2.0, lambda l, tt: f(l, tt) * 0.5, 7.5, 2)(lat, t)
+    assert np.array_equal(out.numpy(), golden["cfg_sequential_out"])
+
+
+def test_product_extra_channels_match_reference(golden):
+    got = {}
+
+    def rec(latents, t):
+        got["x"] = latents
+        return latents[:, :4]
+
+    lat = torch.from_numpy(golden["cfg_in"])
+    PS.UnetWithExtraChannels(rec, torch.from_numpy(golden["extra_channels_in"]))(lat, torch.tensor([1, 1]))
+    assert np.array_equal(got["x"].numpy(), golden["extra_channels_cat"])
+
+
+def test_product_txt2img_latents_and_masks_match_reference(golden):
+    seeds = golden["rng_seeds"]
+    for name, (lh, lw) in {"512x512": (64, 64), "512x768": (64, 96), "256x256": (32, 32), "256x768": (32, 96)}.items():
+        lt = txt2img_latents(gens(seeds), 4, lh, lw, 64, "cpu") * 14.5
+        assert np.array_equal(lt[:, :, ::7, ::5].numpy(), golden[f"txt2img_{name}_sample"])
+    mask = torch.from_numpy(golden["mask_in"])
+    assert np.array_equal(mask_to_latent_mask(mask).numpy(), golden["mask_latent"])
+    soft = torch.from_numpy(golden["mask_soft"])
+    assert np.array_equal(round_mask(soft, 0.001).numpy(), golden["mask_round_high"])
+
+
+def test_samplers_agree_with_oracle():
+    sch = S.DiscreteScheduleRef()
+    sigmas = sch.get_sigmas(12)
+    toy_o = lambda x, s: x / (1 + s.view(-1, 1, 1, 1) ** 2)
+    toy_p = lambda x, s: x / (1 + float(s) ** 2)
+    x0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1)) * sigmas[0]
+    g1, g2 = gens([3, 4]), gens([3, 4])
+    a = S.sample_euler_ancestral(toy_o, x0, sigmas, lambda s, sn: S.batched_randn([2, 4, 8, 8], g1))
+    b = PS.sample_euler_ancestral(toy_p, x0, sigmas, lambda s, sn: PS.batched_randn([2, 4, 8, 8], g2, "cpu", torch.float32))
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(S.sample_euler(toy_o, x0, sigmas), PS.sample_euler(toy_p, x0, sigmas), rtol=1e-5, atol=1e-6)
+    # second-order samplers: converge to the same fixed point as Euler on this linear toy problem
+    for fn in (PS.sample_heun, PS.sample_dpm_2):
+        out = fn(toy_p, x0, sigmas)
+        assert torch.isfinite(out).all() and out.abs().max() < x0.abs().max()
+
+
+class OracleUNet:
+    def __init__(self, sd, cfg):
+        self.sd, self.config = sd, cfg
+
+    def __call__(self, latents, t, encoder_hidden_states=None):
+        t = torch.as_tensor(t)
+        if t.ndim == 0:
+            t = t.expand(latents.shape[0])
+        return SimpleNamespace(sample=M.unet_forward(self.sd, self.config, latents, t, encoder_hidden_states))
+
+
+class OracleVAE:
+    def __init__(self, sd, cfg):
+        self.sd, self.config = sd, cfg
+
+    def decode(self, z):
+        return SimpleNamespace(sample=M.vae_decode(self.sd, self.config, z))
+
+    def encode(self, x):
+        return SimpleNamespace(latent_dist=DiagonalGaussian(M.vae_encode_moments(self.sd, self.config, x)))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    ucfg, vcfg = gcfg.tiny_unet(), gcfg.tiny_vae()
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    g = torch.Generator().manual_seed(5)
+    text = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g)
+    unc = torch.randn(1, 77, ucfg.cross_attention_dim, generator=g).expand(2, -1, -1).contiguous()
+    return ucfg, vcfg, usd, vsd, text, unc
+
+
+@pytest.mark.parametrize("sampler,steps", [("dpmpp_2m", 6), ("euler_a", 5)])
+def test_pipeline_txt2img_matches_oracle(tiny, sampler, steps):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    img = pipe(seeds=[420420420, 420420421], text_embeddings=text, uncond_embeddings=unc, height=128, width=128,
+               num_inference_steps=steps, guidance_scale=7.5, sampler=sampler)
+    ref, evals = PR.generate_ref(usd, ucfg, vsd, vcfg, text, unc, [420420420, 420420421], 128, 128, steps, 7.5, sampler,
+                                 unet_sample_size=ucfg.sample_size)
+    assert img.shape == (2, 3, 128, 128)
+    assert pipe.last_unet_evals == evals == (steps + 1 if sampler == "dpmpp_2m" else steps)
+    assert PR.psnr(img, ref) > 60.0  # same fp32 ops, only scalar-vs-tensor coefficient rounding differs
+
+
+def test_pipeline_batch_independence_cpu(tiny):
+    """reference tests/batch_independance.py:15-27: same seed, same image, whatever the batch."""
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    kw = dict(height=128, width=128, num_inference_steps=3, sampler="euler_a", output_type="latent")
+    both = pipe(seeds=[7, 8], text_embeddings=text, uncond_embeddings=unc, **kw)
+    one = pipe(seeds=[8], text_embeddings=text[1:], uncond_embeddings=unc[1:], **kw)
+    assert torch.allclose(both[1:], one, rtol=1e-4, atol=1e-3)  # ATen CPU kernels are not bit-exact across batch sizes
+
+
+def test_pipeline_img2img_matches_oracle(tiny):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    out = pipe(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=8,
+               sampler="euler", image=image, strength=0.5, output_type="latent")
+    ref, evals = PR.generate_ref(usd, ucfg, vsd, vcfg, text, unc, [1, 2], 128, 128, 8, 7.5, "euler", image=image,
+                                 strength=0.5, decode=False, unet_sample_size=ucfg.sample_size)
+    assert pipe.last_unet_evals == evals == 4
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_pipeline_runway_inpaint_assembles_nine_channels(tiny):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    seen = {}
+
+    class Spy:
+        config = SimpleNamespace(in_channels=9, sample_size=16)
+
+        def __call__(self, latents, t, encoder_hidden_states=None):
+            seen["shape"] = tuple(latents.shape)
+            seen["mask_vals"] = latents[:, 4].unique().tolist()
+            return SimpleNamespace(sample=latents[:, :4] * 0.1)
+
+    pipe = GyrePipeline(Spy(), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0  # 1 = repaint (0K1D)
+    out = pipe(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=4,
+               sampler="euler", image=image, mask_image=mask, strength=0.75, output_type="latent")
+    assert seen["shape"] == (4, 9, 16, 16) and seen["mask_vals"] == [0.0, 1.0]
+    assert out.shape == (2, 4, 16, 16)
+
+
+def test_pipeline_errors(tiny):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=100, width=128)
+    with pytest.raises(ValueError):
+        pipe(seeds=[], text_embeddings=text, uncond_embeddings=unc)
+    with pytest.raises(NotImplementedError):
+        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, sampler="plms")
