@@ -60,6 +60,10 @@ _SIGS = {
     "gyre_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_vae_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
+    "gyre_prof_set_mask": (_i, [C.c_uint]),
+    "gyre_prof_num_classes": (_i, []),
+    "gyre_prof_class_name": (C.c_char_p, [_i]),
+    "gyre_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gyre_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
     "gyre_op_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
     "gyre_op_layernorm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp]),
@@ -130,3 +134,26 @@ def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
         raise GyreError(f"{name} must live on the GPU: the native path has no CPU fallback (got {t.device})")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
+
+
+def prof_enable(class_prefixes=None) -> None:
+    """Enable HIP-event timing for the kernel classes whose name starts with one of the prefixes
+    (None = all, [] = off)."""
+    L = lib()
+    n = L.gyre_prof_num_classes()
+    mask = 0
+    for k in range(n):
+        name = L.gyre_prof_class_name(k).decode()
+        if class_prefixes is None or any(name.startswith(p) for p in class_prefixes):
+            mask |= 1 << k
+    L.gyre_prof_set_mask(mask)
+
+
+def prof_collect() -> dict:
+    """{class name: dict(launches, ms, flops, bytes)}; call after synchronising the stream."""
+    L = lib()
+    n = L.gyre_prof_num_classes()
+    la, ms, fl, by = (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    L.gyre_prof_collect(la, ms, fl, by)
+    return {L.gyre_prof_class_name(k).decode(): dict(launches=int(la[k]), ms=float(ms[k]), flops=float(fl[k]),
+                                                       bytes=float(by[k])) for k in range(n) if la[k]}

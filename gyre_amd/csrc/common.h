@@ -56,3 +56,16 @@ int64_t& gyre_launch_counter();
 #define GYRE_LAUNCH_CHECK() do { gyre_launch_counter()++; hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     gyre_set_error(std::string("kernel launch: ") + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); \
     return -5; } } while (0)
+
+// ---- optional per-launch timing (HIP events on the launch stream), used by bench.py's roofline leg ----
+// Kernel classes; a launch is timed only when profiling is enabled for its class.
+enum GyreKernelClass {
+    KC_GEMM_CONV_128 = 0, KC_GEMM_CONV_256x64, KC_GEMM_CONV_64, KC_GEMM_LIN_128, KC_GEMM_LIN_256x64, KC_GEMM_LIN_64,
+    KC_ATTN, KC_GN_STATS, KC_GN_APPLY, KC_LAYERNORM, KC_OTHER, KC_COUNT
+};
+struct GyreProfScope {  // RAII: records start/stop events around one launch when enabled
+    int slot = -1;
+    GyreProfScope(int kclass, hipStream_t st, double flops, double bytes);
+    ~GyreProfScope();
+    hipStream_t st_;
+};

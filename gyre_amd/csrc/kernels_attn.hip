@@ -211,6 +211,8 @@ static int launch_attn_t(hipStream_t st, const AttnParams& p) {
         attr_set = true;
     }
     dim3 grid((p.Nq + 64 * QI - 1) / (64 * QI), p.B * p.H);
+    GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
+                        2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     GYRE_LAUNCH_CHECK();
     return 0;

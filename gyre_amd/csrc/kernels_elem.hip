@@ -257,6 +257,7 @@ int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
     int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
     size_t lds = (size_t)PY * p.C * 2 * sizeof(float);
     if (lds > 160 * 1024) GYRE_FAIL(-6, "groupnorm: LDS budget exceeded");
+    GyreProfScope prof_(KC_GN_STATS, st, 0.0, (double)p.B * p.HW * p.C * 2.0);
     hipLaunchKernelGGL(k_gn_partial, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
     GYRE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gn_finalize, dim3(p.B), dim3(256), 0, st, p);
@@ -265,6 +266,7 @@ int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
 }
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
     size_t total = (size_t)p.B * p.HW * (p.C / 8);
+    GyreProfScope prof_(KC_GN_APPLY, st, 0.0, (double)p.B * p.HW * p.C * 4.0);
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, total);
     GYRE_LAUNCH_CHECK();
     return 0;
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x,
 int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
                      bf16_t* y) {
     if (C % 8 || C > 8 * 64 * LN_MAXV) GYRE_FAIL(-6, "layernorm: C must be a multiple of 8 and <= 2048");
+    GyreProfScope prof_(KC_LAYERNORM, st, 0.0, (double)M * C * 4.0);
     hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, gamma, beta, eps, y);
     GYRE_LAUNCH_CHECK();
     return 0;

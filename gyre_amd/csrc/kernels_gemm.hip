@@ -286,6 +286,13 @@ static int launch_cfg(hipStream_t st, const GemmParams& p) {
     const int grid = tiles_m * tiles_n;
     const size_t lds = (size_t)2 * (BM + BN) * 128;
     const bool trans = p.out_mode == OUT_BF16_T;
+    // algorithmic work of this launch (unpadded): 2*M*N*K flops; bytes = A read once + W + C written (+ residual)
+    const int kcls = (p.mode == GEMM_CONV3 ? 0 : 3) + (BM == 128 ? 0 : BM == 256 ? 1 : 2);
+    const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
+    const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
+                                                : (double)p.M * p.K * 2.0;
+    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
+                        a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
 #define GYRE_GEMM_GO(MODE_, UNI_, TR_)                                                                              \
     do {                                                                                                            \
         auto kern = k_gemm<BM, BN, WM, WN, MODE_, UNI_, TR_>;                                                       \

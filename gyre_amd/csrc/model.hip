@@ -29,6 +29,38 @@ extern "C" const char* gyre_last_error(void) { return g_err.c_str(); }
 extern "C" int gyre_abi_version(void) { return GYRE_ABI_VERSION; }
 extern "C" int64_t gyre_last_launch_count(void) { return g_launches; }
 
+// ------------------------------------------------------------------------------------------
+// per-launch timing
+// ------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int kclass; double flops, bytes; };
+struct ProfState {
+    unsigned mask = 0;  // bit per GyreKernelClass
+    std::vector<ProfRec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+thread_local ProfState g_prof;
+}  // namespace
+GyreProfScope::GyreProfScope(int kclass, hipStream_t st, double flops, double bytes) : st_(st) {
+    if (!(g_prof.mask >> kclass & 1u)) return;
+    hipEvent_t a, b;
+    if (!g_prof.pool.empty()) { a = g_prof.pool.back().first; b = g_prof.pool.back().second; g_prof.pool.pop_back(); }
+    else { if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return; }
+    (void)hipEventRecord(a, st);
+    slot = (int)g_prof.recs.size();
+    g_prof.recs.push_back({a, b, kclass, flops, bytes});
+}
+GyreProfScope::~GyreProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, st_);
+}
+static const char* kclass_name(int k) {
+    static const char* n[KC_COUNT] = {
+        "k_gemm<128, 128, 2, 2, 1", "k_gemm<256, 64, 4, 1, 1", "k_gemm<64, 64, 2, 2, 1",
+        "k_gemm<128, 128, 2, 2, 0", "k_gemm<256, 64, 4, 1, 0", "k_gemm<64, 64, 2, 2, 0",
+        "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other"};
+    return (k >= 0 && k < KC_COUNT) ? n[k] : "?";
+}
+
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int pad8(int c) { return (c + 7) / 8 * 8; }
@@ -905,6 +937,25 @@ int gyre_vae_decode(gyre_vae* h, void* st, const void* z, int idt, int B, int hl
     if (idt < 0 || idt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
     return h->run_decode(false, (hipStream_t)st, z, idt, B, hl, wl, ws, wsb, out, odt);
+}
+
+// ---- per-launch timing (bench.py roofline leg) -------------------------------------------------
+int gyre_prof_set_mask(unsigned mask) { g_prof.mask = mask; return 0; }
+int gyre_prof_num_classes(void) { return KC_COUNT; }
+const char* gyre_prof_class_name(int k) { return kclass_name(k); }
+// Collects (and clears) the records of this thread: per class launches, total ms, algorithmic flops / bytes.
+// The caller must have synchronised the stream.  Arrays have KC_COUNT entries.
+int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes) {
+    for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; }
+    for (auto& r : g_prof.recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            launches[r.kclass]++; ms[r.kclass] += t; flops[r.kclass] += r.flops; bytes[r.kclass] += r.bytes;
+        }
+        g_prof.pool.emplace_back(r.a, r.b);
+    }
+    g_prof.recs.clear();
+    return 0;
 }
 
 // ---- single operators -----------------------------------------------------------------------

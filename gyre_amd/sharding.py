@@ -1,0 +1,67 @@
+"""Data-parallel sharding of one request batch across the GPUs of a node.
+
+The reference only parallelises at request granularity (a queue of device slots,
+gyre/manager.py:648-651,2106-2141; sub-batches of one request run sequentially,
+gyre/services/generate.py:1049-1091).  Here one process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI) takes a contiguous slice of the images - same split rule as the
+reference's batched_seeds (generate.py:977-990: even split, remainder spread over the first
+ranks) - runs the whole denoising loop on its slice with its own per-image generators, and
+the only collective is one all_gather of the finished latents (32 KB / image at 512^2).
+Weights are replicated.  Because every random draw is per image (randtools.py:39-64) and no
+kernel's arithmetic depends on batch position, the result is bit-identical for any split.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [start, end) per rank; sizes differ by at most one, larger shards first."""
+    if total < 0 or world < 1:
+        raise ValueError("total >= 0 and world >= 1 required")
+    base, rem = divmod(total, world)
+    out, s = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((s, s + n))
+        s += n
+    return out
+
+
+def gather_batches(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
+    """all_gather of per-rank [b_r, ...] tensors with ragged b_r (padded to the largest shard)."""
+    world = dist.get_world_size(group)
+    mx = max(sizes)
+    pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous(), group=group)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+
+
+def generate_sharded(pipe, *, seeds: Sequence[int], text_embeddings: torch.Tensor,
+                     uncond_embeddings: Optional[torch.Tensor] = None, group=None, gather: bool = True, **kw):
+    """Run pipe(...) on this rank's slice of the batch and gather the finished latents.
+
+    Returns (latents_full [B,4,h,w] on every rank, (start, end) of the local slice).
+    Ranks with an empty slice (more GPUs than images) only take part in the collective."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    bounds = shard_bounds(len(seeds), world)
+    s, e = bounds[rank]
+    kw = dict(kw)
+    kw["output_type"] = "latent"
+    if e > s:
+        te = text_embeddings if text_embeddings.shape[0] == 1 else text_embeddings[s:e]
+        ue = uncond_embeddings
+        if ue is not None and ue.shape[0] != 1:
+            ue = ue[s:e]
+        local = pipe(seeds=list(seeds[s:e]), text_embeddings=te, uncond_embeddings=ue, **kw)
+    else:
+        h, w = kw.get("height", 512) // 8, kw.get("width", 512) // 8
+        local = torch.zeros((0, 4, h, w), dtype=torch.float32, device=pipe.device)
+    if not gather:
+        return local, (s, e)
+    return gather_batches(local, [b - a for a, b in bounds], group), (s, e)

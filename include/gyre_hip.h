@@ -138,6 +138,16 @@ int gyre_vae_encode(gyre_vae* h, void* stream, const void* image_nchw, int in_dt
 int gyre_vae_decode(gyre_vae* h, void* stream, const void* z_nchw, int in_dtype, int B, int h_lat, int w_lat,
                     void* workspace, size_t workspace_bytes, void* image_out_nchw, int out_dtype);
 
+/* ---- per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
+ * mask: bit k enables kernel class k (names from gyre_prof_class_name; they equal the prefix of the
+ * kernel's demangled name as rocprofv3 prints it).  collect(): after the caller synchronised the
+ * stream, returns per class the number of timed launches, the summed event-to-event milliseconds and
+ * the summed ALGORITHMIC flops / bytes (unpadded problem sizes) and clears the records. */
+int gyre_prof_set_mask(unsigned mask);
+int gyre_prof_num_classes(void);
+const char* gyre_prof_class_name(int kclass);
+int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes);
+
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */
 int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,

@@ -1,0 +1,86 @@
+"""End-to-end parity (-m gpu): the product pipeline on the native UNet/VAE against the oracle
+pipeline on the same seeds / embeddings.  Tolerance: bf16 compute vs fp32 oracle, image PSNR
+(peak 1.0) >= 30 dB (SURVEY.md 8d parity gate; the achieved value is printed)."""
+import pytest
+import torch
+
+from gyre_amd import config as gcfg, weights
+from gyre_amd.modules import GyreHipUNet, GyreHipVAE
+from gyre_amd.pipeline import GyrePipeline
+from gpu_util import DEV
+from oracle import pipeline_ref as PR
+
+pytestmark = pytest.mark.gpu
+
+
+def build(ucfg, vcfg):
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    unet, vae = GyreHipUNet(ucfg), GyreHipVAE(vcfg)
+    unet.load_state_dict(usd)
+    vae.load_state_dict(vsd)
+    return usd, vsd, GyrePipeline(unet.to(DEV), vae.to(DEV), device=DEV)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    ucfg, vcfg = gcfg.tiny_unet(), gcfg.tiny_vae()
+    usd, vsd, pipe = build(ucfg, vcfg)
+    g = torch.Generator().manual_seed(5)
+    text = torch.randn(3, 77, ucfg.cross_attention_dim, generator=g)
+    unc = torch.randn(1, 77, ucfg.cross_attention_dim, generator=g).expand(3, -1, -1).contiguous()
+    return ucfg, vcfg, usd, vsd, pipe, text, unc
+
+
+@pytest.mark.parametrize("sampler,steps", [("dpmpp_2m", 8), ("euler_a", 6)])
+def test_tiny_txt2img_psnr(tiny, sampler, steps):
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    seeds = [420420420, 420420421]
+    img = pipe(seeds=seeds, text_embeddings=text[:2], uncond_embeddings=unc[:2], height=128, width=128,
+               num_inference_steps=steps, sampler=sampler).cpu()
+    ref, evals = PR.generate_ref(usd, ucfg, vsd, vcfg, text[:2], unc[:2], seeds, 128, 128, steps, 7.5, sampler,
+                                 unet_sample_size=ucfg.sample_size)
+    p = PR.psnr(img, ref)
+    print(f"[parity] tiny txt2img {sampler} {steps} steps: PSNR {p:.1f} dB, evals {pipe.last_unet_evals}")
+    assert pipe.last_unet_evals == evals
+    assert p >= 30.0
+
+
+def test_tiny_img2img_psnr(tiny):
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    img = pipe(seeds=[1, 2], text_embeddings=text[:2], uncond_embeddings=unc[:2], height=128, width=128,
+               num_inference_steps=8, sampler="euler", image=image.to(DEV), strength=0.5).cpu()
+    ref, _ = PR.generate_ref(usd, ucfg, vsd, vcfg, text[:2], unc[:2], [1, 2], 128, 128, 8, 7.5, "euler", image=image,
+                             strength=0.5, unet_sample_size=ucfg.sample_size)
+    p = PR.psnr(img, ref)
+    print(f"[parity] tiny img2img: PSNR {p:.1f} dB")
+    assert p >= 30.0
+
+
+def test_batch_split_is_bit_exact(tiny):
+    """Any split of the batch (= any data-parallel sharding) gives bit-identical latents."""
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    kw = dict(height=128, width=128, num_inference_steps=5, sampler="euler_a", output_type="latent")
+    seeds = [11, 12, 13]
+    full = pipe(seeds=seeds, text_embeddings=text, uncond_embeddings=unc, **kw)
+    for i in range(3):
+        one = pipe(seeds=seeds[i:i + 1], text_embeddings=text[i:i + 1], uncond_embeddings=unc[i:i + 1], **kw)
+        assert torch.equal(full[i:i + 1], one), f"image {i} changed with the batch split"
+    two = pipe(seeds=seeds[1:], text_embeddings=text[1:], uncond_embeddings=unc[1:], **kw)
+    assert torch.equal(full[1:], two)
+
+
+def test_sd15_txt2img_psnr_vs_cpu_oracle():
+    """Full-size SD1.5 (synthetic weights), 512x512, 4 Euler-a steps, CFG: GPU image vs fp32 CPU oracle."""
+    ucfg, vcfg = gcfg.sd15_unet(), gcfg.sd15_vae()
+    usd, vsd, pipe = build(ucfg, vcfg)
+    g = torch.Generator().manual_seed(9)
+    text = torch.randn(1, 77, 768, generator=g)
+    unc = torch.randn(1, 77, 768, generator=g)
+    img = pipe(seeds=[420420420], text_embeddings=text, uncond_embeddings=unc, height=512, width=512,
+               num_inference_steps=4, sampler="euler_a").cpu()
+    ref, _ = PR.generate_ref(usd, ucfg, vsd, vcfg, text, unc, [420420420], 512, 512, 4, 7.5, "euler_a")
+    p = PR.psnr(img, ref)
+    print(f"[parity] SD1.5 512x512 4-step euler_a: PSNR {p:.1f} dB")
+    assert img.shape == (1, 3, 512, 512) and p >= 30.0
