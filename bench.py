@@ -55,7 +55,6 @@ def cpu_baseline(threads):
     """Bounded CPU sample of the same workload with the oracle (kind = "port")."""
     from gyre_amd import config as gcfg, weights
     from oracle import models_ref as M
-    torch.set_num_threads(threads)
     ucfg, vcfg = gcfg.sd15_unet(), gcfg.sd15_vae()
     usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
     vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg, encoder=False))
@@ -195,7 +194,8 @@ def main():
                                          "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                                          "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)} for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            # torch's default intra-op thread count (oversubscribing all logical CPUs is several x slower)
+            out["cpu_baseline"] = cpu_baseline(torch.get_num_threads())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -18,7 +18,10 @@ LIB = os.path.join(HERE, "libgyre_hip.so")
 SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_attn.hip", "model.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "gyre_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
-         "-Wno-unused-result", "-fno-gpu-rdc"]
+         "-Wno-unused-result", "-fno-gpu-rdc",
+         # the fully unrolled MFMA epilogues (up to 40 fragments per wave) exceed clang's default pragma-unroll
+         # budget; without this the accumulator array stays indexable and is spilled to scratch every K step
+         "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 
 def _hipcc() -> str:

@@ -61,6 +61,8 @@ int64_t& gyre_launch_counter();
 // Kernel classes; a launch is timed only when profiling is enabled for its class.
 enum GyreKernelClass {
     KC_GEMM_CONV_128 = 0, KC_GEMM_CONV_256x64, KC_GEMM_CONV_64, KC_GEMM_LIN_128, KC_GEMM_LIN_256x64, KC_GEMM_LIN_64,
+    KC_G8_CONV_256x320, KC_G8_CONV_128x320, KC_G8_CONV_256x256, KC_G8_CONV_128x256,
+    KC_G8_LIN_256x320, KC_G8_LIN_128x320, KC_G8_LIN_256x256, KC_G8_LIN_128x256,
     KC_ATTN, KC_GN_STATS, KC_GN_APPLY, KC_LAYERNORM, KC_OTHER, KC_COUNT
 };
 struct GyreProfScope {  // RAII: records start/stop events around one launch when enabled

@@ -55,6 +55,8 @@ struct GemmParams {
     int geglu = 0;                    // W has 2*N_out rows interleaved in 16-row value/gate groups; N == 2*N_out
     void* out = nullptr; int ldc = 0; int out_mode = OUT_BF16; int out_dtype = 1;
     int tokens_per_batch = 0; int ldt = 0;  // OUT_BF16_T: out[(b*N + col)*ldt + tok]
+    const bf16_t* zero_page = nullptr;      // >= 16 zero bytes in global memory (filled in by launch_gemm)
+    int force_cfg = 0;                      // tests/tuning: 0 auto, else tile-config id (see launch_gemm)
 };
 int launch_gemm(hipStream_t st, const GemmParams& p);
 

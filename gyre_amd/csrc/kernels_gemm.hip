@@ -28,6 +28,216 @@
 
 #define BK 64
 
+// Non-transposed epilogue shared by the 4-wave and 8-wave kernels.  Operands were issued swapped, so a
+// lane holds, per 16x16 fragment, output row m = m_base + 16*i + fr and 4 consecutive columns
+// n = n_base + 16*j + 4*fq + {0..3}: bias / time-embedding bias / residual / store are 8- or 16-byte accesses.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
+                                              int fr, int fq) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + fr;
+        if (m >= p.M) continue;
+        const float* rbias = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        if (p.geglu) {
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const int nin = n_base + j * 16 + 4 * fq;  // column in the interleaved 2N space
+                if (nin >= p.N) continue;
+                float4 bv = p.bias ? *(const float4*)(p.bias + nin) : make_float4(0, 0, 0, 0);
+                float4 bg = p.bias ? *(const float4*)(p.bias + nin + 16) : make_float4(0, 0, 0, 0);
+                float o[4];
+                o[0] = (acc[i][j][0] + bv.x) * gelu_erf_f(acc[i][j + 1][0] + bg.x);
+                o[1] = (acc[i][j][1] + bv.y) * gelu_erf_f(acc[i][j + 1][1] + bg.y);
+                o[2] = (acc[i][j][2] + bv.z) * gelu_erf_f(acc[i][j + 1][2] + bg.z);
+                o[3] = (acc[i][j][3] + bv.w) * gelu_erf_f(acc[i][j + 1][3] + bg.w);
+                const int nout = (n_base + j * 16) / 2 + 4 * fq;
+                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + nout) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n_base + j * 16 + 4 * fq;
+                if (n >= p.N) continue;
+                float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.out_mode == OUT_NCHW) {
+                    // tiny-N output conv: out[(b*N + n)*HW + pix], runtime dtype
+                    const int hw = p.rows_per_sample;
+                    const int b = m / hw, pix = m - b * hw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.N) {
+                            float v = o[e] + (p.bias ? p.bias[n + e] : 0.f);
+                            store_from_f32(p.out, p.out_dtype, ((size_t)b * p.N + n + e) * hw + pix, v);
+                        }
+                    }
+                    continue;
+                }
+                // N is a multiple of 4 on this path (checked by the launcher)
+                if (p.bias) {
+                    float4 bv = *(const float4*)(p.bias + n);
+                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                }
+                if (rbias) {
+                    float4 tv = *(const float4*)(rbias + n);
+                    o[0] += tv.x; o[1] += tv.y; o[2] += tv.z; o[3] += tv.w;
+                }
+                if (p.residual) {
+                    uint2 rv = *(const uint2*)(p.residual + (size_t)m * p.ldr + n);
+                    o[0] += bf16lo(rv.x); o[1] += bf16hi(rv.x); o[2] += bf16lo(rv.y); o[3] += bf16hi(rv.y);
+                }
+                uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = pk;
+            }
+        }
+    }
+}
+
+// XCD-aware, bijective tile order: blocks b, b+8, ... run on the same XCD (private L2); give each XCD a
+// contiguous chunk of tile ids, tile id -> (tm, tn) with tn fastest so neighbours share the A rows.
+__device__ __forceinline__ int xcd_tile_id(int bid, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// ------------------------------------------------------------------------------------------------
+// 8-wave, LDS-DMA staged variant for the big problems (tiles BM x BN with BN = 320 or 256).
+// The 4-wave 128x128 kernel above tops out near 750 TFLOP/s because its operand traffic
+// (64 FLOP per byte fetched into LDS) saturates the L2->LDS path (~11-12 TB/s measured); every SD
+// UNet width is a multiple of 320, so a 256x320 tile (142 FLOP/B) reads each activation row once per
+// tap for the 320-wide layers.  Staging uses global_load_lds (16 B per lane straight into LDS, no
+// VGPR round trip and no ds_write pass); the LDS image is lane-linear per wave instruction (8 rows x
+// 128 B), so the XOR swizzle is applied to the per-lane SOURCE address and mirrored on the ds_read
+// (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
+__global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int AR = BM / 64, BR = BN / 64;  // 8-row groups per wave per K step (A, B)
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static_assert(WM * WN == 8 && BM % 64 == 0 && BN % 64 == 0, "8 waves, 64-row staging granules");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int bid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r0 = tid >> 3;                 // 0..63: row inside a 64-row staging granule
+    const int kvs = (tid & 7) ^ (r0 & 7);    // global k-vector this lane fetches into LDS slot (tid & 7)
+
+    int a_base[AR], a_y0[AR], a_x0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int row = m0 + r0 + 64 * i;
+        bool ok = row < p.M;
+        if (MODE == GEMM_LINEAR) {
+            a_base[i] = ok ? row : -1;
+            a_y0[i] = 0; a_x0[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int n = row / hw, rem = row - n * hw;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = ok ? n * p.Hi * p.Wi : -1;
+            a_y0[i] = oy * p.stride - p.pad;
+            a_x0[i] = ox * p.stride - p.pad;
+        }
+    }
+    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+    const bf16_t* zero = p.zero_page;
+
+    auto issue_stage = [&](int kc, int s) {
+        char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
+        const int k = kc * BK + kvs * 8;
+        const bool kok = k < p.K;
+        if (MODE == GEMM_LINEAR) {
+            const bool first = k < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bf16_t* src = zero;
+                if (kok && a_base[i] >= 0)
+                    src = first ? p.A + (size_t)a_base[i] * p.lda + k : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 8192), 16, 0, 0);
+            }
+        } else {
+            int tap, c;
+            if (UNIFORM_TAP) {
+                const int kb = kc * BK;
+                tap = kb / p.Cin;
+                c = kb - tap * p.Cin + kvs * 8;
+            } else {
+                tap = k / p.Cin;
+                c = k - tap * p.Cin;
+            }
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool first = c < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bf16_t* src = zero;
+                int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
+                    src = first ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
+                }
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 8192), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + r0 + 64 * i;
+            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + k : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+    issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) issue_stage(kc + 1, cur ^ 1);
+        const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
+        const uint4* b = a + BM * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int r = wm * TM + i * 16 + fr;
+                af[i] = __builtin_bit_cast(bf16x8_t, a[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int r = wn * TN + j * 16 + fr;
+                bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool TRANS>
 __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int tiles_n) {
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -39,13 +249,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
     constexpr int STAGE = (BM + BN) * 8;
 
     // ---- XCD-aware, bijective tile order: tile id -> (tm, tn) with tn fastest -------------
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    const int bid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -188,65 +392,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
 
     // ---- epilogue ---------------------------------------------------------------------------
     if (!TRANS) {
-        // lane holds, per fragment, row m = ..+fr and 4 consecutive columns n = ..+4*fq+{0..3}
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * TM + i * 16 + fr;
-            if (m >= p.M) continue;
-            const float* rbias = p.rowbias ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-            if (p.geglu) {
-#pragma unroll
-                for (int j = 0; j < NI; j += 2) {
-                    const int nin = n0 + wn * TN + j * 16 + 4 * fq;  // column in the interleaved 2N space
-                    if (nin >= p.N) continue;
-                    float4 bv = p.bias ? *(const float4*)(p.bias + nin) : make_float4(0, 0, 0, 0);
-                    float4 bg = p.bias ? *(const float4*)(p.bias + nin + 16) : make_float4(0, 0, 0, 0);
-                    float o[4];
-                    o[0] = (acc[i][j][0] + bv.x) * gelu_erf_f(acc[i][j + 1][0] + bg.x);
-                    o[1] = (acc[i][j][1] + bv.y) * gelu_erf_f(acc[i][j + 1][1] + bg.y);
-                    o[2] = (acc[i][j][2] + bv.z) * gelu_erf_f(acc[i][j + 1][2] + bg.z);
-                    o[3] = (acc[i][j][3] + bv.w) * gelu_erf_f(acc[i][j + 1][3] + bg.w);
-                    const int nout = (n0 + wn * TN + j * 16) / 2 + 4 * fq;
-                    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                    *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + nout) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int n = n0 + wn * TN + j * 16 + 4 * fq;
-                    if (n >= p.N) continue;
-                    float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if (p.out_mode == OUT_NCHW) {
-                        // tiny-N output conv: out[(b*N + n)*HW + pix], runtime dtype
-                        const int hw = p.rows_per_sample;
-                        const int b = m / hw, pix = m - b * hw;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (n + e < p.N) {
-                                float v = o[e] + (p.bias ? p.bias[n + e] : 0.f);
-                                store_from_f32(p.out, p.out_dtype, ((size_t)b * p.N + n + e) * hw + pix, v);
-                            }
-                        }
-                        continue;
-                    }
-                    // N is a multiple of 4 on this path (checked by the launcher)
-                    if (p.bias) {
-                        float4 bv = *(const float4*)(p.bias + n);
-                        o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
-                    }
-                    if (rbias) {
-                        float4 tv = *(const float4*)(rbias + n);
-                        o[0] += tv.x; o[1] += tv.y; o[2] += tv.z; o[3] += tv.w;
-                    }
-                    if (p.residual) {
-                        uint2 rv = *(const uint2*)(p.residual + (size_t)m * p.ldr + n);
-                        o[0] += bf16lo(rv.x); o[1] += bf16hi(rv.x); o[2] += bf16lo(rv.y); o[3] += bf16hi(rv.y);
-                    }
-                    uint2 pk = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                    *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = pk;
-                }
-            }
-        }
+        gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
     } else {
         // natural operand order: lane holds column n = ..+fr and 4 consecutive rows m = ..+4*fq+{0..3}
         // -> transposed store out[(b*N + n)*ldt + tok], 4 consecutive tokens = 8 bytes
@@ -315,8 +461,91 @@ static int launch_cfg(hipStream_t st, const GemmParams& p) {
     return 0;
 }
 
+#include <mutex>
+#include <unordered_map>
+// 256-byte zero page per device: source of the zero padding for the LDS-DMA kernel (read-only after creation)
+static const bf16_t* zero_page_for_current_device() {
+    static std::mutex mu;
+    static std::unordered_map<int, void*> pages;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = pages.find(dev);
+    if (it != pages.end()) return (const bf16_t*)it->second;
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    (void)hipDeviceSynchronize();
+    pages[dev] = p;
+    return (const bf16_t*)p;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int grid = tiles_m * tiles_n;
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
+    const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
+    const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
+                                                : (double)p.M * p.K * 2.0;
+    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
+                        a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
+#define GYRE_GEMM8_GO(MODE_, UNI_)                                                                                  \
+    do {                                                                                                            \
+        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_>;                                                           \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n);                              \
+    } while (0)
+    if (p.mode == GEMM_LINEAR) {
+        GYRE_GEMM8_GO(GEMM_LINEAR, true);
+    } else {
+        const bool uni = (p.Cin % BK == 0) && (p.C1 % BK == 0);
+        if (uni) GYRE_GEMM8_GO(GEMM_CONV3, true); else GYRE_GEMM8_GO(GEMM_CONV3, false);
+    }
+#undef GYRE_GEMM8_GO
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
+// 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256.
+static int pick_cfg(const GemmParams& p) {
+    const bool trans = p.out_mode == OUT_BF16_T;
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    // wave-quantisation efficiency on 256 CUs with `slots` resident workgroups per CU
+    auto eff = [&](long t, int slots) { long cap = 256L * slots; long waves = (t + cap - 1) / cap; return (double)t / (double)(waves * cap); };
+    // padding efficiency along N
+    auto neff = [&](int bn) { long nt = (p.N + bn - 1) / bn; return (double)p.N / (double)(nt * bn); };
+    double best = -1; int cfg = 3;
+    auto consider = [&](int id, double speed, int bm, int bn, int slots) {
+        double s = speed * eff(tiles(bm, bn), slots) * neff(bn);
+        if (s > best) { best = s; cfg = id; }
+    };
+    // relative speeds measured with tools/opbench.py on MI355X (TFLOP/s at full occupancy / 1000)
+    consider(3, 0.30, 64, 64, 4);
+    consider(1, 0.55, 128, 128, 2);
+    consider(2, 0.50, 256, 64, 2);
+    if (!trans) {
+        // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the
+        // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
+        auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
+        if (!p.geglu && p.N % 320 == 0) { big(4, 0.92, 256, 320); big(5, 0.88, 128, 320); }
+        if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
+    }
+    return cfg;
+}
+
+static thread_local int g_force_cfg = 0;
+extern "C" int gyre_debug_force_gemm_cfg(int cfg) { int old = g_force_cfg; g_force_cfg = cfg; return old; }
+
 int launch_gemm(hipStream_t st, const GemmParams& p0) {
     GemmParams p = p0;
+    if (!p.force_cfg) p.force_cfg = g_force_cfg;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) GYRE_FAIL(-1, "gemm: empty problem");
     if (p.K % 8) GYRE_FAIL(-1, "gemm: K must be a multiple of 8");
     if (!p.A2) { p.C1 = p.mode == GEMM_LINEAR ? p.K : p.Cin; p.A2 = p.A; p.lda2 = p.lda; }
@@ -329,10 +558,21 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.geglu && (p.N % 32)) GYRE_FAIL(-1, "gemm: GEGLU needs N % 32 == 0");
     if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
-    // tile choice: 128x128 when N divides, 256x64 for the N % 128 != 0 widths (320, 960, ...),
-    // 64x64 when the big tiles would leave most of the 256 CUs idle.
-    const long big_tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (big_tiles < 192 || p.N < 64) return launch_cfg<64, 64, 2, 2>(st, p);
-    if (p.N % 128 == 0) return launch_cfg<128, 128, 2, 2>(st, p);
-    return launch_cfg<256, 64, 4, 1>(st, p);
+    int cfg = p.force_cfg ? p.force_cfg : pick_cfg(p);
+    if (cfg >= 4) {
+        if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
+        if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
+        p.zero_page = zero_page_for_current_device();
+        if (!p.zero_page) GYRE_FAIL(-5, "gemm: cannot allocate the zero page");
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<128, 128, 2, 2>(st, p);
+        case 2: return launch_cfg<256, 64, 4, 1>(st, p);
+        case 3: return launch_cfg<64, 64, 2, 2>(st, p);
+        case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320);
+        case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320);
+        case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256);
+        case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256);
+        default: GYRE_FAIL(-1, "gemm: unknown tile config");
+    }
 }

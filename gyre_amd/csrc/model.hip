@@ -57,6 +57,8 @@ static const char* kclass_name(int k) {
     static const char* n[KC_COUNT] = {
         "k_gemm<128, 128, 2, 2, 1", "k_gemm<256, 64, 4, 1, 1", "k_gemm<64, 64, 2, 2, 1",
         "k_gemm<128, 128, 2, 2, 0", "k_gemm<256, 64, 4, 1, 0", "k_gemm<64, 64, 2, 2, 0",
+        "k_gemm8<256, 320, 4, 2, 1", "k_gemm8<128, 320, 2, 4, 1", "k_gemm8<256, 256, 4, 2, 1", "k_gemm8<128, 256, 2, 4, 1",
+        "k_gemm8<256, 320, 4, 2, 0", "k_gemm8<128, 320, 2, 4, 0", "k_gemm8<256, 256, 4, 2, 0", "k_gemm8<128, 256, 2, 4, 0",
         "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other"};
     return (k >= 0 && k < KC_COUNT) ? n[k] : "?";
 }

@@ -148,6 +148,11 @@ int gyre_prof_num_classes(void);
 const char* gyre_prof_class_name(int kclass);
 int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes);
 
+/* Tests / tuning only: force the GEMM tile configuration of this thread's following launches
+ * (0 = automatic; 1 = 4-wave 128x128, 2 = 4-wave 256x64, 3 = 4-wave 64x64, 4 = 8-wave 256x320,
+ * 5 = 8-wave 128x320, 6 = 8-wave 256x256, 7 = 8-wave 128x256).  Returns the previous value. */
+int gyre_debug_force_gemm_cfg(int cfg);
+
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */
 int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,

@@ -249,3 +249,70 @@ def test_error_paths():
     assert rc == -6
     with pytest.raises(NotImplementedError):
         _lib.check(rc)
+
+
+# ---- every GEMM tile configuration, forced, on shapes with M / N / K tails -------------------------
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("M,K,N,bias,res", [(1000, 320, 640, True, True), (4096 + 37, 200, 1280, True, False),
+                                            (513, 1280, 320 * 4, False, True)])
+def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
+    L = _lib.lib()
+    x = bf16_round(randn(M, K, seed=40))
+    w = bf16_round(randn(N, K, seed=41) / math.sqrt(K))
+    b = randn(N, seed=42) if bias else None
+    r = bf16_round(randn(M, N, seed=43)) if res else None
+    ref = F.linear(x, w, b)
+    if res:
+        ref = ref + r
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w)), N,
+                                    vp(b.to(DEV)) if bias else None, vp(to_dev_bf16(r)) if res else None, 0, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"linear cfg{cfg} M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
+def test_geglu_forced_tile_config(cfg):
+    L = _lib.lib()
+    M, K, F_ = 700, 320, 1280
+    x = bf16_round(randn(M, K, seed=44))
+    w = bf16_round(randn(2 * F_, K, seed=45) / math.sqrt(K))
+    b = randn(2 * F_, seed=46) * 0.5
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w, geglu=True)), F_,
+                                    vp(repack_bias(b, geglu=True)), None, 1, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"geglu cfg{cfg}", y.float().cpu(), ref, TOL)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,asym,res", [
+    (2, 24, 20, 320, 640, 1, 0, 0, True), (1, 16, 16, 72, 1280, 1, 1, 0, False), (2, 18, 18, 128, 1280, 2, 0, 1, False),
+])
+def test_conv_forced_tile_config(cfg, B, H, W, Cin, Cout, stride, ups, asym, res):
+    L = _lib.lib()
+    x = bf16_round(randn(B, Cin, H, W, seed=47))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=48) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=49)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w, b, stride=stride, padding=0) if asym else F.conv2d(xi, w, b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = bf16_round(randn(B, Cout, Ho, Wo, seed=50)) if res else None
+    if res:
+        ref = ref + r
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+                                     vp(to_dev_bf16(nhwc(r))) if res else None, stride, ups, asym, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"conv cfg{cfg} {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
