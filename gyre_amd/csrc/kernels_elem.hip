@@ -185,28 +185,39 @@ __global__ __launch_bounds__(256) void k_gn_partial(GnParams p, int TX, int PY, 
 }
 
 __global__ __launch_bounds__(256) void k_gn_finalize(GnParams p) {
+    // 256 threads per sample: thread (g, part) sums every PARTS-th chunk of group g, then a fixed-order
+    // LDS tree over the parts (deterministic; latency ~ nchunks/PARTS dependent loads instead of nchunks)
+    __shared__ float red_s[256], red_q[256];
     __shared__ float mean_s[256], rstd_s[256];
     const int n = blockIdx.x;
     const int cpg = p.C / p.G;
     const float cnt = (float)p.HW * (float)cpg;
-    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
-        float a = 0.f, b = 0.f;
-        for (int ch = 0; ch < p.nchunks; ++ch) {
+    int parts = 256 / p.G;
+    if (parts < 1) parts = 1;
+    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+    float a = 0.f, b = 0.f;
+    if (part < parts)
+        for (int ch = part; ch < p.nchunks; ch += parts) {
             const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
             a += src[0]; b += src[1];
         }
-        float mean = a / cnt;
-        float var = fmaxf(b / cnt - mean * mean, 0.f);
+    red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < p.G) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < parts; ++q) { sa += red_s[q * p.G + g]; sb += red_q[q * p.G + g]; }
+        float mean = sa / cnt;
+        float var = fmaxf(sb / cnt - mean * mean, 0.f);
         mean_s[g] = mean;
         rstd_s[g] = rsqrtf(var + p.eps);
     }
     __syncthreads();
     float* sc = p.scale_shift + (size_t)n * 2 * p.C;
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        int g = c / cpg;
-        float a = rstd_s[g] * p.gamma[c];
-        sc[c] = a;
-        sc[p.C + c] = p.beta[c] - mean_s[g] * a;
+        int gg = c / cpg;
+        float aa = rstd_s[gg] * p.gamma[c];
+        sc[c] = aa;
+        sc[p.C + c] = p.beta[c] - mean_s[gg] * aa;
     }
 }
 

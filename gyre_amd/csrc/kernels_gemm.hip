@@ -116,7 +116,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
-__global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int AR = BM / 64, BR = BN / 64;  // 8-row groups per wave per K step (A, B)
@@ -124,7 +124,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     static_assert(WM * WN == 8 && BM % 64 == 0 && BN % 64 == 0, "8 waves, 64-row staging granules");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-    const int bid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
+    // split-K: the K range is cut into `splits` contiguous slices; slice s of a tile is block s*ntiles + tile
+    const int ntiles = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntiles;
+    const int bid = xcd_tile_id(blockIdx.x - split * ntiles, ntiles);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x;
@@ -205,13 +208,16 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int nk_per = (nk_all + splits - 1) / splits;
+    const int kc0 = split * nk_per;
+    const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
-    issue_stage(0, 0);
+    issue_stage(kc0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1;
+    for (int kc = kc0; kc < nk; ++kc) {
+        const int cur = (kc - kc0) & 1;
         if (kc + 1 < nk) issue_stage(kc + 1, cur ^ 1);
         const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
         const uint4* b = a + BM * 8;
@@ -235,7 +241,45 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (splits > 1) {
+        // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
+        float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * TM + i * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * TN + j * 16 + 4 * fq;
+                if (n < p.N) *(float4*)(slab + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+}
+
+// out = bf16( sum_s slab[s] + bias + rowbias + residual ), fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 consecutive columns
+    const int nq = p.N / 4;
+    if (q >= (size_t)p.M * nq) return;
+    const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+    float4 a = make_float4(0, 0, 0, 0);
+    for (int s = 0; s < splits; ++s) {
+        float4 v = *(const float4*)(p.splitk_ws + ((size_t)s * p.M + m) * p.N + n);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (p.bias) { float4 b = *(const float4*)(p.bias + n); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (p.rowbias) {
+        float4 b = *(const float4*)(p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (p.residual) {
+        uint2 rv = *(const uint2*)(p.residual + (size_t)m * p.ldr + n);
+        a.x += bf16lo(rv.x); a.y += bf16hi(rv.x); a.z += bf16lo(rv.y); a.w += bf16hi(rv.y);
+    }
+    *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool TRANS>
@@ -481,9 +525,9 @@ static const bf16_t* zero_page_for_current_device() {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base) {
+static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int grid = tiles_m * tiles_n;
+    const int grid = tiles_m * tiles_n * splits;
     const size_t lds = (size_t)2 * (BM + BN) * 128;
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
@@ -499,7 +543,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base) {
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
             attr_set = true;                                                                                        \
         }                                                                                                           \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n);                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
     if (p.mode == GEMM_LINEAR) {
         GYRE_GEMM8_GO(GEMM_LINEAR, true);
@@ -509,12 +553,18 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base) {
     }
 #undef GYRE_GEMM8_GO
     GYRE_LAUNCH_CHECK();
+    if (splits > 1) {
+        const size_t nthreads = (size_t)p.M * (p.N / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
+        GYRE_LAUNCH_CHECK();
+    }
     return 0;
 }
 
 // Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
 // 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256.
-static int pick_cfg(const GemmParams& p) {
+static int pick_cfg(const GemmParams& p, int* splits_out) {
+    *splits_out = 1;
     const bool trans = p.out_mode == OUT_BF16_T;
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     // wave-quantisation efficiency on 256 CUs with `slots` resident workgroups per CU
@@ -536,12 +586,46 @@ static int pick_cfg(const GemmParams& p) {
         auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
         if (!p.geglu && p.N % 320 == 0) { big(4, 0.92, 256, 320); big(5, 0.88, 128, 320); }
         if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
+        // few output tiles but a long reduction (the 8x8 / 16x16 UNet levels: K = 9*Cin up to 23040): cut K into
+        // slices so that tiles x slices covers the chip; fp32 slabs are reduced by k_splitk_reduce
+        const int nk = (p.K + BK - 1) / BK;
+        if (p.out_mode == OUT_BF16 && !p.geglu && p.K >= 2048 && p.N % 4 == 0) {
+            auto tryk = [&](int id, double speed, int bm, int bn) {
+                long t = tiles(bm, bn);
+                if (t >= 160 || t < 1) return;
+                int sp = (int)(256 / t);
+                while (sp > 1 && nk / sp < 16) --sp;
+                if (sp < 2) return;
+                // slab traffic (write + read, fp32) against the operand traffic of the GEMM itself
+                double sc = speed * eff(t * sp, 1) * neff(bn) * 0.85;
+                if (sc > best) { best = sc; cfg = id; *splits_out = sp; }
+            };
+            if (p.N % 320 == 0) tryk(5, 0.88, 128, 320);
+            if (p.N % 256 == 0) tryk(7, 0.62, 128, 256);
+        }
     }
     return cfg;
 }
 
 static thread_local int g_force_cfg = 0;
+static thread_local float* g_dbg_ws = nullptr;
+static thread_local size_t g_dbg_ws_bytes = 0;
 extern "C" int gyre_debug_force_gemm_cfg(int cfg) { int old = g_force_cfg; g_force_cfg = cfg; return old; }
+extern "C" int gyre_debug_set_splitk_workspace(void* ws, size_t bytes) { g_dbg_ws = (float*)ws; g_dbg_ws_bytes = bytes; return 0; }
+
+static int pick_cfg_nosplit(const GemmParams& p) {
+    GemmParams q = p; q.K = q.K < 2048 ? q.K : 2040;  // same tile scoring, split path disabled
+    int sp; return pick_cfg(q, &sp);
+}
+
+GemmPlan gemm_plan(const GemmParams& p0) {
+    GemmParams p = p0;
+    GemmPlan pl{3, 1, 0};
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return pl;
+    pl.cfg = pick_cfg(p, &pl.splits);
+    if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * p.M * p.N * sizeof(float);
+    return pl;
+}
 
 int launch_gemm(hipStream_t st, const GemmParams& p0) {
     GemmParams p = p0;
@@ -558,7 +642,16 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.geglu && (p.N % 32)) GYRE_FAIL(-1, "gemm: GEGLU needs N % 32 == 0");
     if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
-    int cfg = p.force_cfg ? p.force_cfg : pick_cfg(p);
+    int splits = 1;
+    int cfg = pick_cfg(p, &splits);
+    if (p.force_cfg) { cfg = p.force_cfg; splits = 1; }
+    if (splits > 1) {
+        if (!p.splitk_ws) { p.splitk_ws = g_dbg_ws; p.splitk_ws_bytes = g_dbg_ws_bytes; }
+        if (!p.splitk_ws || p.splitk_ws_bytes < (size_t)splits * p.M * p.N * sizeof(float)) {
+            splits = 1;   // no slab space: best single-split configuration instead
+            cfg = pick_cfg_nosplit(p);
+        }
+    }
     if (cfg >= 4) {
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
@@ -569,10 +662,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 1: return launch_cfg<128, 128, 2, 2>(st, p);
         case 2: return launch_cfg<256, 64, 4, 1>(st, p);
         case 3: return launch_cfg<64, 64, 2, 2>(st, p);
-        case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320);
-        case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320);
-        case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256);
-        case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256);
+        case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320, 1);
+        case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
+        case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, 1);
+        case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }

@@ -294,13 +294,24 @@ struct Exec {
         free(ws);
         return 0;
     }
+    // runs one GEMM launch, giving it split-K slab space from the arena when the planner wants it
+    int run_gemm(GemmParams& p) {
+        GemmPlan pl = gemm_plan(p);
+        Tn ws;
+        if (pl.ws_bytes) {
+            TRY(alloc_raw(ws, pl.ws_bytes));
+            p.splitk_ws = (float*)ws.p; p.splitk_ws_bytes = pl.ws_bytes;
+        }
+        int rc = dry() ? 0 : launch_gemm(st, p);
+        free(ws);
+        return rc;
+    }
     // 3x3 conv; x2 = second channel source (skip concat), rowbias = per-sample channel bias (temb)
     int conv3(const Tn& x, const ConvW& w, int stride, int pad, int ups, const float* rowbias, int ld_rowbias,
               const Tn* residual, Tn& y) {
         int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
         int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
         TRY(alloc(y, x.B, Ho, Wo, pad8(w.cout)));
-        if (dry()) return 0;
         GemmParams p;
         p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
         p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad; p.ups = ups;
@@ -308,7 +319,7 @@ struct Exec {
         p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
         if (residual) { p.residual = residual->p; p.ldr = residual->C; }
         p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
-        return launch_gemm(st, p);
+        return run_gemm(p);
     }
     // final 3x3 conv straight to the caller's NCHW buffer
     int conv3_nchw(const Tn& x, const ConvW& w, void* out, int out_dtype) {
@@ -324,12 +335,11 @@ struct Exec {
     // y[M][N] = x[M][K] (|| x2) @ w^T + bias (+ residual); geglu halves N
     int linear(const bf16_t* x, int lda, const bf16_t* x2, int lda2, int C1, int M, int K, const bf16_t* w, int N,
                const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc) {
-        if (dry()) return 0;
         GemmParams p;
         p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
         p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
         p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
-        return launch_gemm(st, p);
+        return run_gemm(p);
     }
     int linear_t(const bf16_t* x, int lda, int M, int K, const bf16_t* w, int N, const float* bias, int tokens, int ldt,
                  bf16_t* y) {

@@ -152,6 +152,9 @@ int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* byte
  * (0 = automatic; 1 = 4-wave 128x128, 2 = 4-wave 256x64, 3 = 4-wave 64x64, 4 = 8-wave 256x320,
  * 5 = 8-wave 128x320, 6 = 8-wave 256x256, 7 = 8-wave 128x256).  Returns the previous value. */
 int gyre_debug_force_gemm_cfg(int cfg);
+/* Tests / tuning only: split-K slab space for this thread's gyre_op_* calls (the model handles carve theirs from
+ * the caller's workspace).  Without it the single operators run the best single-split configuration. */
+int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
 
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */

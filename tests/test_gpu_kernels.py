@@ -316,3 +316,30 @@ def test_conv_forced_tile_config(cfg, B, H, W, Cin, Cout, stride, ups, asym, res
     finally:
         L.gyre_debug_force_gemm_cfg(old)
     report(f"conv cfg{cfg} {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res", [(16, 8, 8, 1280, 1280, True), (4, 16, 16, 640, 1280, False),
+                                                (16, 8, 8, 2560, 1280, True), (2, 8, 8, 512, 512, False)])
+def test_conv_split_k(B, H, W, Cin, Cout, res):
+    """Few output tiles + long K: the planner cuts K into slices (fp32 slabs + deterministic reduce)."""
+    L = _lib.lib()
+    x = bf16_round(randn(B, Cin, H, W, seed=51))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=52) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=53)
+    ref = F.conv2d(x, w, b, padding=1)
+    r = bf16_round(randn(B, Cout, H, W, seed=54)) if res else None
+    if res:
+        ref = ref + r
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
+    try:
+        args = (st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+                vp(to_dev_bf16(nhwc(r))) if res else None, 1, 0, 0, vp(y))
+        _lib.check(L.gyre_op_conv3x3(*args))
+        y1 = y.clone()
+        _lib.check(L.gyre_op_conv3x3(*args))
+        assert torch.equal(y, y1)  # deterministic reduction order
+    finally:
+        L.gyre_debug_set_splitk_workspace(None, 0)
+    report(f"conv split-K {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)

@@ -40,6 +40,8 @@ def rnd(*shape):
 
 
 B = 16
+_ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+L.gyre_debug_set_splitk_workspace(vp(_ws), _ws.numel())
 if which in ("linear", "all"):
     print("== linear (M, K, N) ==")
     shapes = [(65536, 320, 320), (65536, 320, 640), (65536, 320, 2560), (65536, 1280, 320),
