@@ -21,6 +21,7 @@
 //   * head dims 40/80/160 are zero-padded in LDS only (QK^T contraction to a multiple of 32, PV
 //     output to a multiple of 16); global traffic is the unpadded Q/K/V/O.
 #include "kernels.h"
+#include <type_traits>
 
 template <int D, int QI>
 __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
@@ -199,6 +200,272 @@ __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 (head dims <= 160): K / V^T tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round
+// trip) into a 2-deep ring, the loads of tile t+1 are in flight while tile t is computed (counted
+// s_waitcnt vmcnt + raw s_barrier so the DMA survives the barrier).  The LDS image of a DMA is
+// lane-linear, so every layout decision is made on the per-lane SOURCE address:
+//   * K rows are stored densely ([64][D] bf16, no padding) in the permuted key order the S^T/P register
+//     layout needs (see krow in v1); the zero padding of the contraction (D -> multiple of 32) lives in
+//     the Q fragments only: a K fragment read past a row end sees the next row's (finite) data times 0.
+//   * V^T rows are 128 B ([d][64 keys]) with the 16-byte slots XOR-swizzled by (d & 7) -> conflict-free
+//     ds_read_b128 of the MFMA A operand.
+//   * key / dim tails fetch from a zero page.
+// Softmax: p = exp2(fma(s, scale*log2e, -m*scale*log2e)) - one FMA + one v_exp per score.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_a;
+typedef __attribute__((address_space(1))) const void gbl_void_a;
+
+template <int D, int QI, int PD>
+__global__ __launch_bounds__(256) void k_attn2(AttnParams p, const bf16_t* zero) {
+    constexpr int NS = PD + 2;               // ring depth: PD tiles in flight + the one being computed + one spare,
+                                             // so a refill never targets a stage a slower wave may still be reading
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = DP / 32;
+    constexpr int DO = (D + 15) / 16;
+    constexpr int KVEC = D / 8;              // 16-byte granules per K row
+    constexpr int VR = DO * 16;              // V^T rows staged (rows >= D come from the zero page)
+    constexpr int KBYTES = 64 * D * 2;
+    constexpr int RAW = KBYTES + VR * 128;
+    constexpr int STAGE = (RAW + 4095) / 4096 * 4096;   // whole number of 4-wave DMA rounds
+    constexpr int NW = STAGE / 4096;         // DMA instructions per wave per tile
+    constexpr int KG = 64 * KVEC, VG = VR * 8;
+    static_assert(KG % 64 == 0, "K granules fill whole wave instructions");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * (64 * QI) + wave * (16 * QI);
+    const bf16_t* qb = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* kb = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* vb = p.vt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldvt;
+
+    // ---- per-lane DMA descriptors: element offset at tile 0, key index used for the tail check ----------
+    int off[NW], kq[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int g = (i * 4 + wave) * 64 + lane;
+        if (g < KG) {
+            const int rho = g / KVEC, vec = g - rho * KVEC;
+            // LDS row rho of fragment ki = rho>>4 holds key 32*(ki>>1) + 8*(i>>2) + 4*(ki&1) + (i&3), i = rho&15
+            const int ki = rho >> 4, ii = rho & 15;
+            const int key = 32 * (ki >> 1) + 8 * (ii >> 2) + 4 * (ki & 1) + (ii & 3);
+            off[i] = key * p.ldk + vec * 8;
+            kq[i] = key;
+        } else if (g - KG < VG) {
+            const int gv = g - KG, d = gv >> 3, sl = gv & 7;
+            const int kg = sl ^ (d & 7);
+            off[i] = d * p.ldvt + kg * 8;
+            kq[i] = d < D ? kg * 8 : (1 << 28);
+        } else {
+            off[i] = 0; kq[i] = 1 << 28;
+        }
+    }
+    auto issue = [&](int kv0, int st) {
+        char* sbase = smem + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
+            const bf16_t* src = zero;
+            if (kv0 + kq[i] < p.Nk) src = isk ? kb + (size_t)kv0 * p.ldk + off[i] : vb + kv0 + off[i];
+            __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(sbase + i * 4096), 16, 0, 0);
+        }
+    };
+
+    // ---- Q fragments ---------------------------------------------------------------------------------------
+    bf16x8_t qf[QI][KS];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        const int q = q0 + qi * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + fq * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.Nq && d < D) v = *(const uint4*)(qb + (size_t)q * p.ldq + d);
+            qf[qi][ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    f32x4_t o[QI][DO];
+    float m_run[QI], l_run[QI];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        m_run[qi] = -1e30f; l_run[qi] = 0.f;
+#pragma unroll
+        for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+
+    auto tile = [&](int t, int kv0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const char* k_lds = smem + (t % NS) * STAGE;
+        const char* v_lds = k_lds + KBYTES;
+
+        f32x4_t s[QI][4];
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8_t kf = __builtin_bit_cast(
+                    bf16x8_t, *(const uint4*)(k_lds + (ki * 16 + fr) * (D * 2) + (ks * 4 + fq) * 16));
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (TAIL) {
+                        const int kvl = 32 * (ki >> 1) + 8 * fq + 4 * (ki & 1) + r;
+                        if (kv0 + kvl >= p.Nk) s[qi][ki][r] = -1e30f;
+                    }
+                    mx = fmaxf(mx, s[qi][ki][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qi], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * sc);
+            const float nm = -m_new * sc;
+            m_run[qi] = m_new;
+            float ls = 0.f;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(s[qi][ki][r], sc, nm));
+                    s[qi][ki][r] = pv;
+                    ls += pv;
+                }
+            l_run[qi] = l_run[qi] * alpha + ls;
+#pragma unroll
+            for (int di = 0; di < DO; ++di) {
+                o[qi][di][0] *= alpha; o[qi][di][1] *= alpha; o[qi][di][2] *= alpha; o[qi][di][3] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            bf16x8_t pf[QI];
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) {
+                uint4 w;
+                w.x = pack_bf16x2(s[qi][2 * ks2][0], s[qi][2 * ks2][1]);
+                w.y = pack_bf16x2(s[qi][2 * ks2][2], s[qi][2 * ks2][3]);
+                w.z = pack_bf16x2(s[qi][2 * ks2 + 1][0], s[qi][2 * ks2 + 1][1]);
+                w.w = pack_bf16x2(s[qi][2 * ks2 + 1][2], s[qi][2 * ks2 + 1][3]);
+                pf[qi] = __builtin_bit_cast(bf16x8_t, w);
+            }
+#pragma unroll
+            for (int di = 0; di < DO; ++di) {
+                const int d = di * 16 + fr;
+                uint4 vraw = *(const uint4*)(v_lds + d * 128 + (((ks2 * 4 + fq) ^ (d & 7)) * 16));
+                if (TAIL) {  // keys >= Nk inside a partially valid granule: whatever the V^T pad columns hold, use 0
+                    const int nvalid = p.Nk - (kv0 + ks2 * 32 + fq * 8);
+                    uint32_t w[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (2 * e >= nvalid) w[e] = 0;
+                        else if (2 * e + 1 >= nvalid) w[e] &= 0xffffu;
+                    }
+                    vraw = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vraw);
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    o[qi][di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi], o[qi][di], 0, 0, 0);
+            }
+        }
+    };
+    const int nt = (p.Nk + 63) / 64;
+#pragma unroll
+    for (int t0 = 0; t0 < PD; ++t0)
+        if (t0 < nt) issue(t0 * 64, t0);
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * 64;
+        if (t + PD < nt) issue(kv0 + PD * 64, (t + PD) % NS);
+        // wait until tile t has landed; the (up to PD) younger tiles stay in flight (counted vmcnt)
+        const int ahead = min(PD, nt - 1 - t);
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NW) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS (the only barrier per tile)
+        if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}); else tile(t, kv0, std::false_type{});
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        float l = l_run[qi];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + qi * 16 + fr;
+        if (q >= p.Nq) continue;
+        bf16_t* orow = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#pragma unroll
+        for (int di = 0; di < DO; ++di) {
+            const int d = di * 16 + 4 * fq;
+            if (d < D) {
+                uint2 pk = make_uint2(pack_bf16x2(o[qi][di][0] * inv, o[qi][di][1] * inv),
+                                      pack_bf16x2(o[qi][di][2] * inv, o[qi][di][3] * inv));
+                *(uint2*)(orow + d) = pk;
+            }
+        }
+    }
+}
+
+#include <mutex>
+#include <unordered_map>
+static const bf16_t* attn_zero_page() {
+    static std::mutex mu;
+    static std::unordered_map<int, void*> pages;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = pages.find(dev);
+    if (it != pages.end()) return (const bf16_t*)it->second;
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    (void)hipDeviceSynchronize();
+    pages[dev] = p;
+    return (const bf16_t*)p;
+}
+
+static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1 (register staged), 2 = v2 QI=2, 4 = v2 QI=4
+extern "C" int gyre_debug_force_attn_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
+
+template <int D, int QI>
+static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
+    constexpr int DO = (D + 15) / 16;
+    constexpr int RAW = 64 * D * 2 + DO * 16 * 128;
+    constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
+    constexpr int PD = D <= 80 ? 2 : 1;      // tiles in flight ahead of the one being computed
+    const size_t lds = (size_t)(PD + 2) * STAGE;
+    const bf16_t* zero = attn_zero_page();
+    if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
+    auto kern = k_attn2<D, QI, PD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.Nq + 64 * QI - 1) / (64 * QI), p.B * p.H);
+    GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
+                        2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int D, int QI>
 static int launch_attn_t(hipStream_t st, const AttnParams& p) {
     constexpr int DP = (D + 31) / 32 * 32;
@@ -223,6 +490,20 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) GYRE_FAIL(-1, "attention: strides must be multiples of 8");
     if (p.ldvt < (p.Nk + 7) / 8 * 8) GYRE_FAIL(-1, "attention: ldvt must cover Nk rounded up to 8");
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
+    const int var = g_attn_variant;
+    if (var != 1) {
+        const bool q4 = var == 4 || (var == 0 && p.D >= 64 && p.Nq >= 1024 && p.Nk >= 256);
+        switch (p.D) {
+            case 16: return q4 ? launch_attn2_t<16, 4>(st, p) : launch_attn2_t<16, 2>(st, p);
+            case 32: return q4 ? launch_attn2_t<32, 4>(st, p) : launch_attn2_t<32, 2>(st, p);
+            case 40: return q4 ? launch_attn2_t<40, 4>(st, p) : launch_attn2_t<40, 2>(st, p);
+            case 64: return q4 ? launch_attn2_t<64, 4>(st, p) : launch_attn2_t<64, 2>(st, p);
+            case 80: return q4 ? launch_attn2_t<80, 4>(st, p) : launch_attn2_t<80, 2>(st, p);
+            case 128: return launch_attn2_t<128, 2>(st, p);
+            case 160: return launch_attn2_t<160, 2>(st, p);
+            default: break;
+        }
+    }
     switch (p.D) {
         case 8: return launch_attn_t<8, 2>(st, p);
         case 16: return launch_attn_t<16, 2>(st, p);

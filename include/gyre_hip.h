@@ -155,6 +155,9 @@ int gyre_debug_force_gemm_cfg(int cfg);
 /* Tests / tuning only: split-K slab space for this thread's gyre_op_* calls (the model handles carve theirs from
  * the caller's workspace).  Without it the single operators run the best single-split configuration. */
 int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
+/* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
+ * query rows per wave.  Returns the previous value. */
+int gyre_debug_force_attn_variant(int v);
 
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */

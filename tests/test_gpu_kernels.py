@@ -343,3 +343,28 @@ def test_conv_split_k(B, H, W, Cin, Cout, res):
     finally:
         L.gyre_debug_set_splitk_workspace(None, 0)
     report(f"conv split-K {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("B,heads,Nq,Nk,D", [(1, 2, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
+                                              (2, 8, 1024, 77, 40), (1, 8, 256, 231, 160), (2, 4, 96, 77, 32),
+                                              (2, 2, 100, 50, 16), (1, 10, 1024, 1000, 64), (1, 2, 1000, 333, 128)])
+def test_attention_variants(variant, B, heads, Nq, Nk, D):
+    """register-staged (1) and LDS-DMA double-buffered (2: 32 q rows / wave, 4: 64) kernels, incl. key tails."""
+    L = _lib.lib()
+    C_ = heads * D
+    q = bf16_round(randn(B, Nq, C_, seed=60))
+    k = bf16_round(randn(B, Nk, C_, seed=61))
+    v = bf16_round(randn(B, Nk, C_, seed=62))
+    ref = attn_ref(q, k, v, heads)
+    ldvt = (Nk + 7) // 8 * 8
+    vt = torch.zeros((B, C_, ldvt), dtype=torch.bfloat16, device=DEV)  # pad columns must be finite (zero) for v2
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
+    o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_attn_variant(variant)
+    try:
+        _lib.check(L.gyre_op_attention(st(), vp(to_dev_bf16(q)), C_, vp(to_dev_bf16(k)), C_, vp(vt), ldvt, B, heads, Nq, Nk,
+                                       D, vp(o), C_))
+    finally:
+        L.gyre_debug_force_attn_variant(old)
+    report(f"attention v{variant} B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, TOL_ATTN)

@@ -86,9 +86,14 @@ if which in ("attn", "all"):
         ldvt = (Nk + 7) // 8 * 8
         vt = rnd(Bc, Cc, ldvt)
         o = torch.empty(Bc, Nq, Cc, dtype=torch.bfloat16, device=DEV)
-        us = timeit(lambda: L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(vt), ldvt, Bc, h, Nq, Nk, D, vp(o), Cc))
         fl = 4.0 * Bc * h * Nq * Nk * D
-        print(f"attn B{Bc} h{h} Nq{Nq} Nk{Nk} D{D}: {us:9.1f} us  {fl/us/1e6:7.1f} TF/s")
+        res = []
+        for var in (1, 2, 4):
+            L.gyre_debug_force_attn_variant(var)
+            us = timeit(lambda: L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(vt), ldvt, Bc, h, Nq, Nk, D, vp(o), Cc))
+            res.append(f"v{var}: {us:8.1f} us {fl/us/1e6:6.1f} TF/s")
+        L.gyre_debug_force_attn_variant(0)
+        print(f"attn B{Bc} h{h} Nq{Nq} Nk{Nk} D{D}: " + " | ".join(res))
 
 if which in ("gn", "all"):
     print("== groupnorm+silu / layernorm ==")
