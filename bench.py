@@ -170,7 +170,7 @@ def main():
             tj = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tj):
                 tinfo = json.load(open(tj))
-                if tinfo.get("kernel", "").startswith(dom_name.split(",")[0]) and dom_name[:24] in tinfo.get("kernel", "") + ",":
+                if tinfo.get("kernel", "").startswith(dom_name):
                     traffic = tinfo.get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": dom_name + ", ...>",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

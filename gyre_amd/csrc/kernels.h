@@ -57,6 +57,7 @@ struct GemmParams {
     int tokens_per_batch = 0; int ldt = 0;  // OUT_BF16_T: out[(b*N + col)*ldt + tok]
     const bf16_t* zero_page = nullptr;      // >= 16 zero bytes in global memory (filled in by launch_gemm)
     int force_cfg = 0;                      // tests/tuning: 0 auto, else tile-config id (see launch_gemm)
+    int debug = 0;                          // tuning ablations: bit0 = no operand loads in the K loop, bit1 = no MFMAs
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;  // fp32 partial slabs [splits][M][N] (see gemm_plan)
 };
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.

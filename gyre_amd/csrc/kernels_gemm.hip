@@ -25,6 +25,7 @@
 // torch.nn.Conv2d inside the third-party UNet/VAE the reference calls at
 // gyre/pipeline/unet/core.py:274 and gyre/pipeline/unified_pipeline.py:309,1531.
 #include "kernels.h"
+#include <utility>
 
 #define BK 64
 
@@ -173,9 +174,11 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         } else {
             int tap, c;
             if (UNIFORM_TAP) {
-                const int kb = kc * BK;
-                tap = kb / p.Cin;
-                c = kb - tap * p.Cin + kvs * 8;
+                // K order = channel chunk outer, tap inner: the nine taps of one 64-channel chunk run back to
+                // back, so the (shifted) input rows they share are re-read from L1/L2 instead of the fabric
+                const int chunk = kc / 9;
+                tap = kc - chunk * 9;
+                c = chunk * BK + kvs * 8;
             } else {
                 tap = k / p.Cin;
                 c = k - tap * p.Cin;
@@ -194,10 +197,15 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 8192), 16, 0, 0);
             }
         }
+        int kw = k;  // position of this lane's 8 weights inside a [taps][Cin] weight row
+        if (MODE == GEMM_CONV3 && UNIFORM_TAP) {
+            const int chunk = kc / 9, tap = kc - chunk * 9;
+            kw = tap * p.Cin + chunk * BK + kvs * 8;
+        }
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int n = n0 + r0 + 64 * i;
-            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + k : zero;
+            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
         }
     };
@@ -218,11 +226,14 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     __syncthreads();
     for (int kc = kc0; kc < nk; ++kc) {
         const int cur = (kc - kc0) & 1;
-        if (kc + 1 < nk) issue_stage(kc + 1, cur ^ 1);
+        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
         const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
         const uint4* b = a + BM * 8;
+        if (!(p.debug & 2))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            // (explicit 2-deep fragment prefetch pinned with sched_group_barrier was measured 3-6 % slower: with two
+            // waves per SIMD the partner wave already covers the ds_read latency)
             bf16x8_t af[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -610,6 +621,8 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
 static thread_local int g_force_cfg = 0;
 static thread_local float* g_dbg_ws = nullptr;
 static thread_local size_t g_dbg_ws_bytes = 0;
+static thread_local int g_gemm_debug = 0;
+extern "C" int gyre_debug_gemm_ablation(int bits) { int old = g_gemm_debug; g_gemm_debug = bits; return old; }
 extern "C" int gyre_debug_force_gemm_cfg(int cfg) { int old = g_force_cfg; g_force_cfg = cfg; return old; }
 extern "C" int gyre_debug_set_splitk_workspace(void* ws, size_t bytes) { g_dbg_ws = (float*)ws; g_dbg_ws_bytes = bytes; return 0; }
 
@@ -630,6 +643,7 @@ GemmPlan gemm_plan(const GemmParams& p0) {
 int launch_gemm(hipStream_t st, const GemmParams& p0) {
     GemmParams p = p0;
     if (!p.force_cfg) p.force_cfg = g_force_cfg;
+    p.debug = g_gemm_debug;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) GYRE_FAIL(-1, "gemm: empty problem");
     if (p.K % 8) GYRE_FAIL(-1, "gemm: K must be a multiple of 8");
     if (!p.A2) { p.C1 = p.mode == GEMM_LINEAR ? p.K : p.Cin; p.A2 = p.A; p.lda2 = p.lda; }

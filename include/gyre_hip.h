@@ -158,6 +158,8 @@ int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave.  Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
+/* Tuning only: bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs (results are garbage). */
+int gyre_debug_gemm_ablation(int bits);
 
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */

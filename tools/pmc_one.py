@@ -1,0 +1,30 @@
+"""Run one conv / linear shape a few times (for rocprofv3 --pmc passes)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gyre_amd import _lib
+L = _lib.lib(); DEV = "cuda:0"
+vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+rnd = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
+kind = sys.argv[1]
+if kind == "conv":
+    B, H, W, Ci, Co = map(int, sys.argv[2:7])
+    x, w, b = rnd(B, H, W, Ci), rnd(Co, 9 * Ci), torch.zeros(Co, device=DEV)
+    y = torch.empty(B, H, W, Co, dtype=torch.bfloat16, device=DEV)
+    for _ in range(5):
+        L.gyre_op_conv3x3(st(), vp(x), B, H, W, Ci, vp(w), Co, vp(b), None, 1, 0, 0, vp(y))
+elif kind == "linear":
+    M, K, N = map(int, sys.argv[2:5])
+    x, w, b = rnd(M, K), rnd(N, K), torch.zeros(N, device=DEV)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    for _ in range(5):
+        L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), None, 0, vp(y))
+elif kind == "attn":
+    B, h, Nq, Nk, D = map(int, sys.argv[2:7])
+    Cc = h * D
+    q, k, vt = rnd(B, Nq, Cc), rnd(B, Nk, Cc), rnd(B, Cc, Nk)
+    o = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=DEV)
+    for _ in range(5):
+        L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(vt), Nk, B, h, Nq, Nk, D, vp(o), Cc)
+torch.cuda.synchronize()
