@@ -103,6 +103,70 @@ __device__ __forceinline__ int xcd_tile_id(int bid, int ntiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// LDS-staged epilogue of the 8-wave kernel (bf16 row-major output).  The register layout after the swapped
+// MFMAs gives every lane 4 consecutive channels of 16 different rows, i.e. 8-byte accesses in 32-byte runs;
+// measured, that epilogue cost ~20 us per 42 MB output.  Here each wave parks one 16-row slab of its tile in
+// LDS as fp32 (bias / time-embedding bias / GEGLU already applied), reads it back as whole rows and issues
+// 16-byte coalesced residual loads and stores.  One rounding, after the residual add - same as the direct path.
+template <int MI, int NI, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
+                                                     int fr, int fq, int lane, float* my) {
+    constexpr int TNO_FULL = TN;                 // staged columns per wave without GEGLU
+    const bool gg = p.geglu != 0;
+    const int tno = gg ? TNO_FULL / 2 : TNO_FULL;        // output columns this wave produces
+    const int rowf = TNO_FULL + 4;                         // floats per staged row (+16 B pad: conflict-free b128 writes)
+    const int n_out_base = gg ? n_base / 2 : n_base;
+    const int n_out = gg ? p.N / 2 : p.N;
+    const int vec_per_row = tno / 8;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m_base + i * 16 + fr;
+        const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        if (gg) {
+#pragma unroll
+            for (int j = 0; j + 1 < NI; j += 2) {
+                const int nin = n_base + j * 16 + 4 * fq;
+                float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0);
+                if (p.bias && nin < p.N) { bv = *(const float4*)(p.bias + nin); bg = *(const float4*)(p.bias + nin + 16); }
+                float4 o;
+                o.x = (acc[i][j][0] + bv.x) * gelu_erf_f(acc[i][j + 1][0] + bg.x);
+                o.y = (acc[i][j][1] + bv.y) * gelu_erf_f(acc[i][j + 1][1] + bg.y);
+                o.z = (acc[i][j][2] + bv.z) * gelu_erf_f(acc[i][j + 1][2] + bg.z);
+                o.w = (acc[i][j][3] + bv.w) * gelu_erf_f(acc[i][j + 1][3] + bg.w);
+                *(float4*)(my + fr * rowf + (j / 2) * 16 + 4 * fq) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n_base + j * 16 + 4 * fq;
+                float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                if (n < p.N) {
+                    if (p.bias) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                    if (rbias) { float4 tv = *(const float4*)(rbias + n); o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w; }
+                }
+                *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
+            }
+        }
+        // read the slab back row-wise: 8 consecutive channels (32 B fp32) per lane -> one 16-byte store
+        for (int v = lane; v < 16 * vec_per_row; v += 64) {
+            const int row = v / vec_per_row, c8 = v - row * vec_per_row;
+            const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
+            const float4 lo = *(const float4*)(my + row * rowf + c8 * 8);
+            const float4 hi = *(const float4*)(my + row * rowf + c8 * 8 + 4);
+            if (mm < p.M && nn < n_out) {
+                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.residual) {
+                    float r[8];
+                    unpack8(*(const uint4*)(p.residual + (size_t)mm * p.ldr + nn), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += r[e];
+                }
+                *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pack8(f);
+            }
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -265,6 +329,23 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                 if (n < p.N) *(float4*)(slab + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
         }
+        return;
+    }
+    if (p.debug & 4) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sum == 12345.678f) ((float*)p.out)[0] = sum;
+        return;
+    }
+    // coalesced LDS-staged epilogue when every 8-channel group is 16-byte addressable, else the direct one
+    const int n_out = p.geglu ? p.N / 2 : p.N;
+    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
+        float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
+        gemm_epilogue_staged<MI, NI, TN>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
         return;
     }
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
