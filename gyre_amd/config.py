@@ -29,6 +29,10 @@ class UNetConfig:
     sample_size: int = 64
     flip_sin_to_cos: bool = True
     freq_shift: float = 0.0
+    # SDXL "text_time" added conditioning (None for SD1.x/2.x)
+    addition_embed_type: str | None = None
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
     _diffusers_version: str = "0.16.0"
 
     @property
@@ -70,6 +74,21 @@ def tiny_unet(in_channels: int = 4) -> UNetConfig:
     and head dims multiples of 8 (vector loads)."""
     return UNetConfig(in_channels=in_channels, block_out_channels=(32, 64, 128, 128),
                       num_heads=(2, 2, 4, 4), cross_attention_dim=64, sample_size=16)
+
+
+def sdxl_unet() -> UNetConfig:
+    """SDXL-base UNet (BASELINE config 4; not in the reference - an extension on the same kernel set): 3 levels,
+    transformer depth 0/2/10, head dim 64, context 2048, linear projections, text_time added conditioning."""
+    return UNetConfig(block_out_channels=(320, 640, 1280), attn_levels=(False, True, True), num_heads=(5, 10, 20),
+                      transformer_depth=(1, 2, 10), cross_attention_dim=2048, use_linear_projection=True,
+                      sample_size=128, addition_embed_type="text_time")
+
+
+def tiny_sdxl_unet() -> UNetConfig:
+    return UNetConfig(block_out_channels=(32, 64, 128), attn_levels=(False, True, True), num_heads=(2, 2, 4),
+                      transformer_depth=(1, 2, 3), cross_attention_dim=64, use_linear_projection=True, sample_size=16,
+                      addition_embed_type="text_time", addition_time_embed_dim=8,
+                      projection_class_embeddings_input_dim=32 + 6 * 8)
 
 
 def tiny_vae() -> VAEConfig:

@@ -69,6 +69,16 @@ int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, 
     return 0;
 }
 
+__global__ void k_add_f32(float* __restrict__ y, const float* __restrict__ x, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n) {
+    hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------
 // out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]   (f = SiLU when act_in_silu)
 // One wave per output column n, rows in groups of 8.  Weight-read bound (B <= 32).

@@ -599,7 +599,7 @@ struct gyre_unet {
     }
 
     int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
-            int W, int S, void* ws, size_t ws_bytes, void* out, int odt) {
+            int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr) {
         const gyre_unet_cfg& c = cfg;
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
@@ -622,6 +622,8 @@ struct gyre_unet {
             TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
             TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
             TRY(launch_rowvec_linear(st, (float*)t1.p, B, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
+            // SDXL-style added conditioning (text_time): emb = time_embedding(t) + aug_emb, aug_emb from the host
+            if (temb_add) TRY(launch_add_f32(st, (float*)t2.p, temb_add, (size_t)B * temb_dim));
             // every resnet's Linear(SiLU(temb)) in one launch
             TRY(launch_rowvec_linear(st, (float*)t2.p, B, temb_dim, tproj_w, tproj_b, temb_cols, 1, (float*)tp.p, temb_cols));
         }
@@ -896,13 +898,17 @@ size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0)) return 0;
     return h->ex.arena.peak;
 }
-int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
-                      int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {
+int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
+                         int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add) {
     if (!h || !x || !t || !ctx || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     if (xdt < 0 || xdt > 2 || cdt < 0 || cdt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
-    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt);
+    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add);
+}
+int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
+                      int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {
+    return gyre_unet_forward_ex(h, st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, nullptr);
 }
 
 int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out) {

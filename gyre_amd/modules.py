@@ -109,7 +109,12 @@ class _NativeModule(nn.Module):
             if self._dirty:
                 st = _lib.stream_ptr(device)
                 setw = getattr(L, f"gyre_{self._kind}_set_weight")
+                nkeys = getattr(L, f"gyre_{self._kind}_num_params")(C.c_void_p(self._handle))
+                native = {getattr(L, f"gyre_{self._kind}_param_key")(C.c_void_p(self._handle), i).decode()
+                          for i in range(nkeys)}
                 for key, p in self.state_dict().items():
+                    if key not in native:
+                        continue  # host-side parameters (e.g. SDXL add_embedding) stay in PyTorch
                     t = p.detach()
                     if t.device != device:
                         t = t.to(device)
@@ -207,10 +212,28 @@ class GyreHipUNet(_NativeModule):
         cfg.freq_shift = c.freq_shift
         return cfg
 
+    def _aug_embedding(self, added_cond_kwargs, B: int, dev) -> Optional[torch.Tensor]:
+        """SDXL text_time conditioning: tiny MLP on the host (PyTorch-ROCm), result handed to the native call."""
+        if self.config.addition_embed_type != "text_time":
+            return None
+        if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+            raise ValueError("this UNet needs added_cond_kwargs={'text_embeds': [B,D], 'time_ids': [B,6]}")
+        c = self.config
+        te, ids = added_cond_kwargs["text_embeds"].to(dev, torch.float32), added_cond_kwargs["time_ids"].to(dev)
+        half = c.addition_time_embed_dim // 2
+        freq = torch.exp(-torch.log(torch.tensor(10000.0, device=dev)) * torch.arange(half, device=dev) / (half - c.freq_shift))
+        ang = ids.flatten()[:, None].float() * freq[None]
+        emb = torch.cat([torch.cos(ang), torch.sin(ang)] if c.flip_sin_to_cos else [torch.sin(ang), torch.cos(ang)], dim=-1)
+        a = torch.cat([te, emb.reshape(B, -1)], dim=-1)
+        ae = self.add_embedding
+        a = torch.nn.functional.linear(a, ae.linear_1.weight.float(), ae.linear_1.bias.float())
+        a = torch.nn.functional.linear(torch.nn.functional.silu(a), ae.linear_2.weight.float(), ae.linear_2.bias.float())
+        return a.contiguous()
+
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, adapter_states=None,
-                return_dict: bool = True, **_ignored):
+                added_cond_kwargs=None, return_dict: bool = True, **_ignored):
         if encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states is required")
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None \
@@ -244,10 +267,12 @@ class GyreHipUNet(_NativeModule):
             ws = self._workspace(need, dev)
             wp = (ws.data_ptr() + 255) & ~255
             out = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
-            _lib.check(L.gyre_unet_forward(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
-                                           _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
-                                           _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
-                                           C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
+            aug = self._aug_embedding(added_cond_kwargs, B, dev)
+            _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                              _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                                              _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
+                                              C.c_void_p(out.data_ptr()), _lib.dtype_code(out),
+                                              C.c_void_p(aug.data_ptr()) if aug is not None else None))
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
 

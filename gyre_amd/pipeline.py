@@ -5,7 +5,9 @@ Host orchestration restating the reference's ``UnifiedPipeline.__call__``
 
   Txt2imgMode                 unified_pipeline.py:155-237
   Img2imgMode                 unified_pipeline.py:240-337
-  EnhancedRunwayInpaintMode   unified_pipeline.py:398-696 (strength < 1: no shaped-noise fill)
+  EnhancedInpaintMode         unified_pipeline.py:398-645 (per-step blend of original vs predicted latents)
+  EnhancedRunwayInpaintMode   unified_pipeline.py:648-696 (9-channel UNet input assembly)
+  (strength >= 1 "shaped noise" fill, unified_pipeline.py:466-601, is not implemented)
 
 Call stack per SURVEY.md 3.2/3.3: embeddings -> UNetWithEmbeddings -> (UnetWithExtraChannels)
 -> CFGUNet_Parallel -> KDiffusionUNetWrapper -> sampler loop -> vae.decode(latents / 0.18215)
@@ -159,9 +161,10 @@ class GyrePipeline:
         lat_ch = 4
         lat_h, lat_w = height // self.vae_scale_factor, width // self.vae_scale_factor
 
-        sched = S.KDiffusionScheduler(sampler, generators, dev, torch.float32)
+        sched = S.make_scheduler(sampler, generators, dev, torch.float32)
         extra = None
         init_latents = None
+        blend_orig = blend_mask = None
         if image is not None:
             if not 0 <= strength <= 1:
                 raise NotImplementedError("strength outside [0,1] (shaped-noise fill) is not on the native path yet")
@@ -178,8 +181,9 @@ class GyrePipeline:
                     extra = torch.cat([inpaint_mask, orig], dim=1)
                 init_latents = self.image_to_latents(img, generators)
                 if not runway:
-                    raise NotImplementedError("mask_image without the 9-channel inpaint UNet (EnhancedInpaintMode "
-                                              "blending) is not on the native path yet")
+                    # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
+                    # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
+                    blend_orig, blend_mask = orig, latent_mask
             else:
                 init_latents = self.image_to_latents(img, generators)
 
@@ -207,7 +211,16 @@ class GyrePipeline:
             noise = S.batched_randn(init_latents.shape, generators, dev, torch.float32)
             latents = sched.add_noise(init_latents, noise)
 
-        latents = sched.loop(latents, callback=callback)
+        wrap = {}
+        if blend_orig is not None:
+            def _blend(u, orig, nxt):
+                it = blend_mask.gt(u).to(nxt.dtype)
+                return orig * it + nxt * (1 - it)
+            if isinstance(sched, S.KDiffusionScheduler):
+                wrap["k_wrap"] = lambda px0, u: _blend(u, blend_orig.to(px0.dtype), px0)
+            else:
+                wrap["d_wrap"] = lambda xt, t, u: _blend(u, sched.add_noise_at(blend_orig, noise, t).to(xt.dtype), xt)
+        latents = sched.loop(latents, callback=callback, **wrap)
         self.last_unet_evals = sched.unet.evals
         if output_type == "latent":
             return latents

@@ -154,7 +154,7 @@ def _f(v) -> float:
 
 @torch.no_grad()
 def sample_dpmpp_2m(model, x: Tensor, sigmas: Tensor, callback=None, warmup_lms: bool = False,
-                    ddim_cutoff: float = 0.0, **_):
+                    ddim_cutoff: float = 0.0, step_cb=None, **_):
     """DPM-Solver++(2M) with the reference's LMS warm-up (an extra model eval at the first step) and
     first-order cutoff: gyre/pipeline/schedulers/sample_dpmpp_2m.py:6-50."""
     sigmas = sigmas.to("cpu", torch.float32)
@@ -162,6 +162,8 @@ def sample_dpmpp_2m(model, x: Tensor, sigmas: Tensor, callback=None, warmup_lms:
     t_fn = lambda sigma: sigma.log().neg()
     old_denoised = None
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
@@ -192,9 +194,11 @@ def get_ancestral_step(sigma_from: Tensor, sigma_to: Tensor, eta: float = 1.0):
 
 
 @torch.no_grad()
-def sample_euler(model, x: Tensor, sigmas: Tensor, callback=None, **_):
+def sample_euler(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
@@ -205,9 +209,11 @@ def sample_euler(model, x: Tensor, sigmas: Tensor, callback=None, **_):
 
 @torch.no_grad()
 def sample_euler_ancestral(model, x: Tensor, sigmas: Tensor, noise_sampler=None, callback=None, eta: float = 1.0,
-                           s_noise: float = 1.0, **_):
+                           s_noise: float = 1.0, step_cb=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
         if callback is not None:
@@ -220,9 +226,11 @@ def sample_euler_ancestral(model, x: Tensor, sigmas: Tensor, noise_sampler=None,
 
 
 @torch.no_grad()
-def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, **_):
+def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
@@ -239,9 +247,11 @@ def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, **_):
 
 
 @torch.no_grad()
-def sample_dpm_2(model, x: Tensor, sigmas: Tensor, callback=None, **_):
+def sample_dpm_2(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
@@ -259,11 +269,13 @@ def sample_dpm_2(model, x: Tensor, sigmas: Tensor, callback=None, **_):
 
 @torch.no_grad()
 def sample_dpmpp_2s_ancestral(model, x: Tensor, sigmas: Tensor, noise_sampler=None, callback=None, eta: float = 1.0,
-                              s_noise: float = 1.0, **_):
+                              s_noise: float = 1.0, step_cb=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     sigma_fn = lambda t: t.neg().exp()
     t_fn = lambda sigma: sigma.log().neg()
     for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
         denoised = model(x, sigmas[i])
         sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
         if callback is not None:
@@ -373,10 +385,218 @@ class KDiffusionScheduler:
         sigma = s.t_to_sigma(s.sigma_to_t(self.start_sigma))
         return latents + noise * float(sigma)
 
-    def loop(self, latents: Tensor, callback=None) -> Tensor:
+    def loop(self, latents: Tensor, callback=None, k_wrap=None) -> Tensor:
+        """k_wrap(px0, u) -> px0 lets a mode post-process the denoised prediction with the progress value u in
+        [0, 0.999] (reference KDiffusionPositionTracker, common_scheduler.py:358-389, and Mode.wrap_k_unet)."""
         sigmas = self.sigmas[self.start_offset:]
         kwargs = dict(self.sampler_kwargs)
         if self.eta is not None:
             kwargs["eta"] = self.eta
         kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
-        return self.sampler_fn(self.unet, latents, sigmas, callback=callback, **kwargs)
+        model = self.unet
+        if k_wrap is not None:
+            u_off = self.start_offset / len(self.sigmas)
+            state = {"i": 0, "i_max": len(sigmas) - 1}
+
+            def tracked(x, sigma):
+                u = u_off + (1 - u_off) * state["i"] / state["i_max"]
+                return k_wrap(self.unet(x, sigma), max(min(u, 0.999), 0))
+
+            model = tracked
+            kwargs["step_cb"] = lambda i: state.__setitem__("i", i)
+        return self.sampler_fn(model, latents, sigmas, callback=callback, **kwargs)
+
+
+# ------------------------------------------------------------------------------
+# more k-diffusion samplers [3P k_diffusion.sampling], selected at reference samplers.py:48-57
+# ------------------------------------------------------------------------------
+@torch.no_grad()
+def sample_dpm_2_ancestral(model, x: Tensor, sigmas: Tensor, noise_sampler=None, callback=None, eta: float = 1.0,
+                           s_noise: float = 1.0, step_cb=None, **_):
+    sigmas = sigmas.to("cpu", torch.float32)
+    for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
+        denoised = model(x, sigmas[i])
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        d = (x - denoised) / _f(sigmas[i])
+        if sigma_down == 0:
+            x = x + d * _f(sigma_down - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
+            x_2 = x + d * _f(sigma_mid - sigmas[i])
+            denoised_2 = model(x_2, sigma_mid)
+            d_2 = (x_2 - denoised_2) / _f(sigma_mid)
+            x = x + d_2 * _f(sigma_down - sigmas[i])
+            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * (s_noise * _f(sigma_up))
+    return x
+
+
+def linear_multistep_coeff(order: int, t, i: int, j: int) -> float:
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def fn(tau):
+        prod = 1.0
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, x: Tensor, sigmas: Tensor, callback=None, order: int = 4, step_cb=None, **_):
+    sigmas = sigmas.to("cpu", torch.float32)
+    sig = sigmas.double().numpy()
+    ds = []
+    for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
+        denoised = model(x, sigmas[i])
+        d = (x - denoised) / _f(sigmas[i])
+        ds.append(d)
+        if len(ds) > order:
+            ds.pop(0)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        cur_order = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur_order, sig, i, j) for j in range(cur_order)]
+        x = x + sum(c * dd for c, dd in zip(coeffs, reversed(ds)))
+    return x
+
+
+SAMPLERS.update({
+    "dpm_2_a": (sample_dpm_2_ancestral, {}),
+    "lms": (sample_lms, {}),
+})
+
+
+# ------------------------------------------------------------------------------
+# diffusers-scheduler loop (reference common_scheduler.py:179-314: DDIM, PLMS = PNDM(skip_prk_steps=True)).
+# The step arithmetic is diffusers' [3P, ~=0.16.0, not vendored]; restated from the published algorithms with the
+# SD1.x scheduler_config.json values (scaled_linear betas, steps_offset=1, set_alpha_to_one=False, no clipping).
+# Coefficients are host fp32/64 scalars applied to the device latents (no per-step sync).
+# ------------------------------------------------------------------------------
+class DiffusersLikeScheduler:
+    init_noise_sigma = 1.0
+
+    def __init__(self, kind: str, num_train_timesteps: int = 1000, steps_offset: int = 1):
+        if kind not in ("ddim", "plms"):
+            raise NotImplementedError(kind)
+        self.kind, self.T, self.steps_offset = kind, num_train_timesteps, steps_offset
+        self.alphas_cumprod = DiscreteSchedule(num_train_timesteps).alphas_cumprod.double()
+        self.final_alpha_cumprod = self.alphas_cumprod[0]  # set_alpha_to_one = False
+
+    def set_timesteps(self, n: int):
+        import numpy as np
+        self.n = n
+        ratio = self.T // n
+        base = (np.arange(0, n) * ratio).round().astype(np.int64) + self.steps_offset
+        if self.kind == "ddim":
+            self.timesteps = base[::-1].copy()
+        else:  # PNDM with skip_prk_steps: the second timestep is visited twice
+            self.timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        self.ets, self.counter, self.cur_sample = [], 0, None
+
+    def _ac(self, t: int) -> float:
+        return float(self.alphas_cumprod[t]) if t >= 0 else float(self.final_alpha_cumprod)
+
+    def step(self, eps: Tensor, t: int, sample: Tensor) -> Tensor:
+        ratio = self.T // self.n
+        if self.kind == "ddim":
+            prev_t = t - ratio
+            a_t, a_prev = self._ac(t), self._ac(prev_t)
+            x0 = (sample - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+            return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps  # eta = 0
+        prev_t = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+        else:
+            prev_t = t
+            t = t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            eps = (eps + self.ets[-1]) / 2
+            sample, self.cur_sample = self.cur_sample, None
+        elif len(self.ets) == 2:
+            eps = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            eps = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            eps = (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4]) / 24
+        self.counter += 1
+        a_t, a_prev = self._ac(t), self._ac(prev_t)
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        sample_coeff = (a_prev / a_t) ** 0.5
+        denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        return sample_coeff * sample - (a_prev - a_t) / denom * eps
+
+
+class DiffusersScheduler:
+    """Loop driver with the KDiffusionScheduler surface (set_eps_unet / set_timesteps / prepare_initial_latents /
+    add_noise / loop) for the samplers k-diffusion has no twin for."""
+
+    def __init__(self, kind: str, generators, device, dtype=torch.float32):
+        self.sched = DiffusersLikeScheduler(kind)
+        self.generators, self.device, self.dtype = generators, device, dtype
+        self.eps_unet, self.unet = None, None
+        self.start_offset = 0
+
+    def set_eps_unet(self, eps_unet):
+        self.eps_unet = eps_unet
+
+    def set_timesteps(self, num_inference_steps: int, start_offset=None, strength=None, config=None):
+        if self.eps_unet is None:
+            raise ValueError("Epsilon unet needs to be set before timesteps")
+        self.sched.set_timesteps(num_inference_steps)
+        if strength is not None:
+            init = min(int(num_inference_steps * strength), num_inference_steps)
+            self.start_offset = max(num_inference_steps - init, 0)
+        else:
+            self.start_offset = start_offset or 0
+        self.unet = type("EvalCounter", (), {"evals": 0})()
+
+    def prepare_initial_latents(self, latents: Tensor) -> Tensor:
+        return latents * self.sched.init_noise_sigma
+
+    def add_noise(self, latents: Tensor, noise: Tensor) -> Tensor:
+        a = float(self.sched.alphas_cumprod[int(self.sched.timesteps[self.start_offset])])
+        return a ** 0.5 * latents + (1 - a) ** 0.5 * noise
+
+    def add_noise_at(self, latents: Tensor, noise: Tensor, t: int) -> Tensor:
+        a = float(self.sched.alphas_cumprod[t])
+        return a ** 0.5 * latents + (1 - a) ** 0.5 * noise
+
+    def loop(self, latents: Tensor, callback=None, d_wrap=None) -> Tensor:
+        """d_wrap(xt, t, u) -> xt post-processes each new sample (reference Mode.wrap_d_unet)."""
+        x = latents
+        ts = self.sched.timesteps[self.start_offset:]
+        u_off = self.start_offset / max(len(self.sched.timesteps), 1)
+        for i, t in enumerate(ts):
+            eps = self.eps_unet(x, int(t))
+            self.unet.evals += 1
+            x = self.sched.step(eps, int(t), x)
+            if d_wrap is not None:
+                u = u_off + (1 - u_off) * i / max(len(ts), 1)
+                x = d_wrap(x, int(t), max(min(u, 0.999), 0))
+            if callback is not None:
+                callback({"x": x, "i": i, "t": int(t)})
+        return x
+
+
+DIFFUSERS_SAMPLERS = ("ddim", "plms")
+
+
+def make_scheduler(sampler, generators, device, dtype=torch.float32):
+    """sampler name -> loop driver, the split the reference makes in build_sampler_set (samplers.py:110-130)."""
+    if isinstance(sampler, str) and sampler in DIFFUSERS_SAMPLERS:
+        return DiffusersScheduler(sampler, generators, device, dtype)
+    return KDiffusionScheduler(sampler, generators, device, dtype)

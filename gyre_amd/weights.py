@@ -74,6 +74,11 @@ def unet_param_shapes(cfg: UNetConfig) -> Shapes:
     s["time_embedding.linear_1.bias"] = (td,)
     s["time_embedding.linear_2.weight"] = (td, td)
     s["time_embedding.linear_2.bias"] = (td,)
+    if getattr(cfg, "addition_embed_type", None) == "text_time":
+        s["add_embedding.linear_1.weight"] = (td, cfg.projection_class_embeddings_input_dim)
+        s["add_embedding.linear_1.bias"] = (td,)
+        s["add_embedding.linear_2.weight"] = (td, td)
+        s["add_embedding.linear_2.bias"] = (td,)
     s["conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3)
     s["conv_in.bias"] = (boc[0],)
     n = len(boc)

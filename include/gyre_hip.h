@@ -122,6 +122,14 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
                       void* workspace, size_t workspace_bytes,
                       void* eps_out_nchw, int out_dtype);
 
+/* Same, plus an optional additive term for the time embedding: temb_add[B, 4*block_out_channels[0]] (f32, dev) is
+ * added to time_embedding(t) before it feeds the ResNet blocks.  This is how SDXL's `text_time` added conditioning
+ * (add_embedding MLP over pooled text + size/crop ids, a few MFLOP) enters: the MLP stays host PyTorch. */
+int gyre_unet_forward_ex(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
+                         const void* ctx, int ctx_dtype, int B, int H, int W, int S,
+                         void* workspace, size_t workspace_bytes, void* eps_out_nchw, int out_dtype,
+                         const float* temb_add_dev);
+
 /* ---- VAE ---------------------------------------------------------------- */
 int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out);
 void gyre_vae_destroy(gyre_vae* h);

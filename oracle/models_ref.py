@@ -164,8 +164,18 @@ def transformer_2d(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int, groups: i
 # --------------------------------------------------------------------------
 # UNet2DConditionModel forward
 # --------------------------------------------------------------------------
+def added_cond_embedding(sd: SD, cfg, text_embeds: Tensor, time_ids: Tensor) -> Tensor:
+    """SDXL `text_time` conditioning [3P diffusers UNet2DConditionModel.get_aug_embed]: sinusoid(time_ids) ++ pooled
+    text -> add_embedding MLP.  Not part of the reference (SDXL is an extension)."""
+    te = timestep_embedding(time_ids.flatten(), cfg.addition_time_embed_dim, cfg.flip_sin_to_cos, cfg.freq_shift)
+    te = te.reshape(text_embeds.shape[0], -1)
+    a = torch.cat([text_embeds, te.to(text_embeds.dtype)], dim=-1)
+    a = _lin(a, sd, "add_embedding.linear_1")
+    return _lin(F.silu(a), sd, "add_embedding.linear_2")
+
+
 def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder_hidden_states: Tensor,
-                 taps: Optional[dict] = None) -> Tensor:
+                 taps: Optional[dict] = None, added_cond: Optional[dict] = None) -> Tensor:
     """eps = unet(latents[NCHW], t[int64 N], ctx[N,S,D]).  ``taps`` (optional dict)
     receives named intermediate activations for block-level parity tests."""
     g, eps = cfg.norm_num_groups, 1e-5
@@ -175,6 +185,8 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
     temb = timestep_embedding(t, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift).to(latents.dtype)
     temb = _lin(temb, sd, "time_embedding.linear_1")
     temb = _lin(F.silu(temb), sd, "time_embedding.linear_2")
+    if added_cond is not None:
+        temb = temb + added_cond_embedding(sd, cfg, added_cond["text_embeds"], added_cond["time_ids"])
     if taps is not None:
         taps["temb"] = temb
 

@@ -125,3 +125,19 @@ def test_sd15_vae_decode_full_size():
     got = net.decode(z.to(DEV)).sample
     assert got.shape == (1, 3, 512, 512)
     report("SD1.5 vae decode 1x4x64x64", got.cpu(), ref, 3e-2)
+
+
+def test_tiny_sdxl_topology_parity():
+    """SDXL-style UNet (3 levels, depth 0/2/3, linear projections, text_time added conditioning) - an extension
+    beyond the reference (BASELINE config 4); parity against the build's own oracle."""
+    cfg = gcfg.tiny_sdxl_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 16, 16, seed=11)
+    t = torch.tensor([981, 17])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=12)
+    ac = {"text_embeds": randn(2, 32, seed=13), "time_ids": torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * 2)}
+    ref = M.unet_forward(sd, cfg, x, t, ctx, added_cond=ac)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=ac).sample
+    report("tiny sdxl-topology unet", got.cpu(), ref, 3e-2)
+    with pytest.raises(ValueError):
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))

@@ -84,3 +84,21 @@ def test_sd15_txt2img_psnr_vs_cpu_oracle():
     p = PR.psnr(img, ref)
     print(f"[parity] SD1.5 512x512 4-step euler_a: PSNR {p:.1f} dB")
     assert img.shape == (1, 3, 512, 512) and p >= 30.0
+
+
+def test_tiny_inpaint_modes_and_diffusers_samplers_on_gpu(tiny):
+    """EnhancedInpaintMode blend + DDIM/PLMS drivers run on the native models and agree with the same host code on
+    the oracle models (PSNR on the latents' decoded image)."""
+    from test_host_pipeline import OracleUNet, OracleVAE
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    ref_pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0
+    for sampler, steps in (("euler", 6), ("plms", 6), ("ddim", 6), ("lms", 5)):
+        kw = dict(seeds=[5, 6], height=128, width=128, num_inference_steps=steps, sampler=sampler, strength=0.8)
+        got = pipe(text_embeddings=text[:2], uncond_embeddings=unc[:2], image=image.to(DEV), mask_image=mask.to(DEV), **kw).cpu()
+        ref = ref_pipe(text_embeddings=text[:2], uncond_embeddings=unc[:2], image=image, mask_image=mask, **kw)
+        p = PR.psnr(got, ref)
+        print(f"[parity] tiny inpaint {sampler}: PSNR {p:.1f} dB")
+        assert p >= 30.0

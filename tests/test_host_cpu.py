@@ -65,3 +65,12 @@ def test_product_does_not_import_oracle():
     out = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "gyre_amd")],
                          capture_output=True, text=True).stdout.strip()
     assert out == "", f"product code imports the oracle: {out}"
+
+
+def test_sdxl_param_count_and_keys():
+    shapes = weights.unet_param_shapes(gcfg.sdxl_unet())
+    assert sum(torch.Size(s).numel() for s in shapes.values()) == 2_567_463_684  # SDXL-base UNet
+    assert "down_blocks.2.attentions.1.transformer_blocks.9.attn2.to_k.weight" in shapes
+    assert shapes["down_blocks.1.attentions.0.proj_in.weight"] == (640, 640)        # linear projection
+    assert shapes["add_embedding.linear_1.weight"] == (1280, 2816)
+    assert not any(k.startswith("down_blocks.0.attentions") for k in shapes)

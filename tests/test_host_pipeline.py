@@ -207,4 +207,82 @@ def test_pipeline_errors(tiny):
     with pytest.raises(ValueError):
         pipe(seeds=[], text_embeddings=text, uncond_embeddings=unc)
     with pytest.raises(NotImplementedError):
-        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, sampler="plms")
+        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, sampler="dpm_adaptive")
+
+
+def test_more_samplers_on_linear_toy_problem():
+    """lms / dpm_2_a / heun / dpmpp_2s_a: on the analytic denoiser x/(1+sigma^2) (data ~ N(0,1)) every consistent
+    sampler must bring x_T = sigma_max * n to (about) unit scale; eval counts follow the k-diffusion definitions."""
+    sch = S.DiscreteScheduleRef()
+    sigmas = sch.get_sigmas(15)
+    x0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1)) * sigmas[0]
+    for name, evals in (("lms", 15), ("dpm_2_a", 29), ("heun", 29), ("dpmpp_2s_a", 29), ("dpm_2", 29), ("euler", 15)):
+        fn, kw = PS.SAMPLERS[name]
+        calls = []
+
+        def toy(x, s):
+            calls.append(float(s))
+            return x / (1 + float(s) ** 2)
+
+        g = gens([3, 4])
+        out = fn(toy, x0, sigmas, noise_sampler=lambda a, b: PS.batched_randn([2, 4, 8, 8], g, "cpu", torch.float32), **kw)
+        assert len(calls) == evals, (name, len(calls))
+        assert torch.isfinite(out).all() and 0.2 < float(out.std()) < 3.0, (name, float(out.std()))
+
+
+def test_lms_matches_euler_at_order_one():
+    sch = S.DiscreteScheduleRef()
+    sigmas = sch.get_sigmas(10)
+    toy = lambda x, s: x / (1 + float(s) ** 2)
+    x0 = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2)) * sigmas[0]
+    a = PS.sample_lms(toy, x0, sigmas, order=1)
+    b = PS.sample_euler(toy, x0, sigmas)
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
+
+
+def test_ddim_and_plms_drivers():
+    """DDIM with the exact eps of a point-mass data distribution at 0 (eps = x / sqrt(1-abar)) lands on x0 = 0;
+    PLMS visits n+1 timesteps (the second one twice)."""
+    for kind, evals in (("ddim", 12), ("plms", 13)):
+        sched = PS.make_scheduler(kind, gens([1]), "cpu")
+        ac = sched.sched.alphas_cumprod
+
+        def eps_model(x, t):
+            return x / float((1 - ac[t]) ** 0.5)
+
+        sched.set_eps_unet(eps_model)
+        sched.set_timesteps(12)
+        assert len(sched.sched.timesteps) == evals
+        assert sched.sched.timesteps[0] == 917 + 0 or sched.sched.timesteps[0] > 900  # leading spacing + steps_offset
+        x = sched.prepare_initial_latents(torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(3)))
+        out = sched.loop(x)
+        assert sched.unet.evals == evals
+        assert float(out.abs().max()) < 0.2 * float(x.abs().max()), kind
+
+
+def test_pipeline_runs_with_diffusers_style_sampler(tiny):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    out = pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128,
+               num_inference_steps=4, sampler="plms", output_type="latent")
+    assert out.shape == (1, 4, 16, 16) and pipe.last_unet_evals == 5 and torch.isfinite(out).all()
+
+
+def test_enhanced_inpaint_blend_pins_protected_area(tiny):
+    """4-channel UNet + mask: with a hard mask the protected latents of the final x0 equal the masked original's."""
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0  # repaint the centre, keep the border
+    for sampler in ("euler", "ddim"):
+        out = pipe(seeds=[5], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128,
+                   num_inference_steps=6, sampler=sampler, image=image, mask_image=mask, strength=0.9, output_type="latent")
+        keep = torch.ones(1, 1, 128, 128) - mask
+        orig = pipe.image_to_latents(pipe.preprocess_image(image), [torch.Generator().manual_seed(5)],
+                                     (keep > 0.001).float())
+        lm = (torch.nn.functional.max_pool2d(mask, 8) == 0).expand(1, 4, 16, 16)  # latent cells fully protected
+        if sampler == "euler":  # x0-space blend: the last denoised prediction is pinned exactly
+            assert torch.allclose(out[lm], orig[lm], atol=1e-5)
+        assert torch.isfinite(out).all()
+        assert not torch.allclose(out[~lm], orig[~lm], atol=1e-2)
