@@ -108,16 +108,16 @@ __device__ __forceinline__ int xcd_tile_id(int bid, int ntiles) {
 // measured, that epilogue cost ~20 us per 42 MB output.  Here each wave parks one 16-row slab of its tile in
 // LDS as fp32 (bias / time-embedding bias / GEGLU already applied), reads it back as whole rows and issues
 // 16-byte coalesced residual loads and stores.  One rounding, after the residual add - same as the direct path.
-template <int MI, int NI, int TN>
+template <int MI, int NI, int TN, bool GG>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
                                                      int fr, int fq, int lane, float* my) {
     constexpr int TNO_FULL = TN;                 // staged columns per wave without GEGLU
-    const bool gg = p.geglu != 0;
-    const int tno = gg ? TNO_FULL / 2 : TNO_FULL;        // output columns this wave produces
-    const int rowf = TNO_FULL + 4;                         // floats per staged row (+16 B pad: conflict-free b128 writes)
+    constexpr bool gg = GG;
+    constexpr int tno = gg ? TNO_FULL / 2 : TNO_FULL;    // output columns this wave produces
+    constexpr int rowf = TNO_FULL + 4;                     // floats per staged row (+16 B pad: conflict-free b128 writes)
     const int n_out_base = gg ? n_base / 2 : n_base;
     const int n_out = gg ? p.N / 2 : p.N;
-    const int vec_per_row = tno / 8;
+    constexpr int vec_per_row = tno / 8;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 16 + fr;
@@ -148,6 +148,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
             }
         }
         // read the slab back row-wise: 8 consecutive channels (32 B fp32) per lane -> one 16-byte store
+#pragma unroll
         for (int v = lane; v < 16 * vec_per_row; v += 64) {
             const int row = v / vec_per_row, c8 = v - row * vec_per_row;
             const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
@@ -172,6 +173,9 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ------------------------------------------------------------------------------------------------
 // 8-wave, LDS-DMA staged variant for the big problems (tiles BM x BN with BN = 320 or 256).
+// (A persistent variant that issued the next tile's first K step before the epilogue was built and measured: no
+// gain - vmcnt retires in order on CDNA, so a wave's pending epilogue stores gate its next load wait, and with one
+// workgroup per CU nothing else can run under the store drain.)
 // The 4-wave 128x128 kernel above tops out near 750 TFLOP/s because its operand traffic
 // (64 FLOP per byte fetched into LDS) saturates the L2->LDS path (~11-12 TB/s measured); every SD
 // UNet width is a multiple of 320, so a 256x320 tile (142 FLOP/B) reads each activation row once per
@@ -345,7 +349,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
         (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
         float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
-        gemm_epilogue_staged<MI, NI, TN>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+        if constexpr (NI % 2 == 0) {
+            if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my); return; }
+        }
+        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
         return;
     }
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);

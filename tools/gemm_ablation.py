@@ -24,12 +24,13 @@ for (B,H,W,Ci,Co) in [(16,64,64,320,320),(16,32,32,1280,640)]:
         L.gyre_debug_gemm_ablation(bits); r.append(timeit(f))
     L.gyre_debug_gemm_ablation(0)
     print(f"conv {B}x{H}x{W} {Ci}->{Co}: full {r[0]:.1f} us | no-loads {r[1]:.1f} | no-mfma {r[2]:.1f} | neither {r[3]:.1f} | neither+no-epilogue {r[4]:.1f} | full-no-epilogue {r[5]:.1f}")
-for (M,K,N) in [(8192,8192,8192),(65536,1280,320)]:
+for (M,K,N,gg) in [(8192,8192,8192,0),(65536,1280,320,0),(65536,320,2560,1),(65536,320,640,0),(16384,640,5120,1),(16384,640,1280,0)]:
     x, w, b = rnd(M, K), rnd(N, K), torch.zeros(N, device=DEV)
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    f=lambda: L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), None, 0, vp(y))
+    no = N // 2 if gg else N
+    y = torch.empty(M, no, dtype=torch.bfloat16, device=DEV)
+    f=lambda: L.gyre_op_linear(st(), vp(x), M, K, vp(w), no, vp(b), None, gg, vp(y))
     r=[]
     for bits in (0,1,2,3,7,4):
         L.gyre_debug_gemm_ablation(bits); r.append(timeit(f))
     L.gyre_debug_gemm_ablation(0)
-    print(f"linear {M}x{K}x{N}: full {r[0]:.1f} us | no-loads {r[1]:.1f} | no-mfma {r[2]:.1f} | neither {r[3]:.1f} | neither+no-epilogue {r[4]:.1f} | full-no-epilogue {r[5]:.1f}")
+    print(f"linear {M}x{K}x{N} geglu={gg}: full {r[0]:.1f} us | no-loads {r[1]:.1f} | no-mfma {r[2]:.1f} | neither {r[3]:.1f} | neither+no-epilogue {r[4]:.1f} | full-no-epilogue {r[5]:.1f}")
