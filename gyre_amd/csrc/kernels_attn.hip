@@ -492,7 +492,7 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
     const int var = g_attn_variant;
     if (var != 1) {
-        const bool q4 = var == 4 || (var == 0 && p.D >= 64 && p.Nq >= 1024 && p.Nk >= 256);
+        const bool q4 = var == 4;  // 64 query rows per wave: measured slower than 32 at every SD shape (register pressure)
         switch (p.D) {
             case 16: return q4 ? launch_attn2_t<16, 4>(st, p) : launch_attn2_t<16, 2>(st, p);
             case 32: return q4 ? launch_attn2_t<32, 4>(st, p) : launch_attn2_t<32, 2>(st, p);
