@@ -184,7 +184,7 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // 128 B), so the XOR swizzle is applied to the per-lane SOURCE address and mirrored on the ds_read
 // (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, int NST = 2>
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -289,12 +289,26 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int kc0 = split * nk_per;
     const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
+    constexpr int LPW = AR + BR;   // DMA instructions per wave per K step
     issue_stage(kc0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NST == 3 && kc0 + 1 < nk) issue_stage(kc0 + 1, 1);
+    if (NST == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     for (int kc = kc0; kc < nk; ++kc) {
-        const int cur = (kc - kc0) & 1;
-        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
+        const int cur = NST == 3 ? (kc - kc0) % 3 : (kc - kc0) & 1;
+        if (NST == 3) {
+            // 3-deep ring, two K steps in flight: the refill target was read in step kc-1 (barrier B below protects it)
+            if (kc + 2 < nk && !(p.debug & 1)) issue_stage(kc + 2, (kc + 2 - kc0) % 3);
+            const int ahead = min(2, nk - 1 - kc);
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // barrier A: stage `cur` complete for every wave
+        } else {
+            if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
+        }
         const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
         const uint4* b = a + BM * 8;
         if (!(p.debug & 2))
@@ -317,9 +331,15 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (NST == 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // barrier B: every wave finished reading stage `cur`
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
+    if (NST == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     if (splits > 1) {
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
@@ -623,11 +643,11 @@ static const bf16_t* zero_page_for_current_device() {
     return (const bf16_t*)p;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST = 2>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    const size_t lds = (size_t)NST * (BM + BN) * 128;
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
@@ -636,7 +656,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
                         a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
 #define GYRE_GEMM8_GO(MODE_, UNI_)                                                                                  \
     do {                                                                                                            \
-        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_>;                                                           \
+        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_, NST>;                                                        \
         static bool attr_set = false;                                                                               \
         if (!attr_set) {                                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
@@ -768,6 +788,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, 1);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
+        case 8: return launch_cfg8<128, 256, 2, 4, 3>(st, p, KC_G8_CONV_128x256, splits);  // experiment: 3-deep ring
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }

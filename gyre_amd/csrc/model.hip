@@ -252,11 +252,15 @@ struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; }
 // ------------------------------------------------------------------------------------------
 // execution context: arena + stream + dry-run switch; every op allocates its output
 // ------------------------------------------------------------------------------------------
+struct CtxKV { bf16_t* k; bf16_t* vt; };
 struct Exec {
     Arena arena;
     hipStream_t st = nullptr;
     int groups = 32;
     std::string fail;
+    // cross-attention K / V^T of the current text context, projected once per request (gyre_unet_set_context)
+    const std::vector<CtxKV>* ctx_cache = nullptr;
+    size_t ctx_layer = 0;
 
     bool dry() const { return arena.dry; }
     int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
@@ -359,28 +363,35 @@ struct Exec {
             const Tn& residual, Tn& out) {
         const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
         Tn q, k, vt, ao;
-        const bf16_t *qp, *kp; int ldq, ldk, Nk, ldvt;
+        const bf16_t *qp, *kp, *vtp = nullptr; int ldq, ldk, Nk, ldvt;
         if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, 2 * C));
             TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
             TRY(alloc(vt, B, C, 1, ldvt));
             TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
-            qp = q.p; kp = dry() ? nullptr : q.p + C; ldq = ldk = 2 * C;
+            qp = q.p; kp = dry() ? nullptr : q.p + C; vtp = vt.p; ldq = ldk = 2 * C;
         } else {
             Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, C));
             TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wq, C, w.bq, nullptr, 0, 0, q.p, C));
-            TRY(alloc(k, B, Nk, 1, C));
-            TRY(linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wk, C, w.bk, nullptr, 0, 0, k.p, C));
-            TRY(alloc(vt, B, C, 1, ldvt));
-            TRY(linear_t(kvsrc, kv_dim, B * Nk, kv_dim, w.wv, C, w.bv, Nk, ldvt, vt.p));
-            qp = q.p; kp = k.p; ldq = ldk = C;
+            if (ctx_cache) {  // K / V^T of this layer were projected when the context was set
+                if (ctx_layer >= ctx_cache->size()) GYRE_FAIL(GYRE_ERR_INVALID, "internal: context cache layer overflow");
+                kp = (*ctx_cache)[ctx_layer].k; vtp = (*ctx_cache)[ctx_layer].vt;
+                ++ctx_layer;
+            } else {
+                TRY(alloc(k, B, Nk, 1, C));
+                TRY(linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wk, C, w.bk, nullptr, 0, 0, k.p, C));
+                TRY(alloc(vt, B, C, 1, ldvt));
+                TRY(linear_t(kvsrc, kv_dim, B * Nk, kv_dim, w.wv, C, w.bv, Nk, ldvt, vt.p));
+                kp = k.p; vtp = vt.p;
+            }
+            qp = q.p; ldq = ldk = C;
         }
         TRY(alloc(ao, B, xq.H, xq.W, C));
         if (!dry()) {
             AttnParams a;
-            a.q = qp; a.ldq = ldq; a.k = kp; a.ldk = ldk; a.vt = vt.p; a.ldvt = ldvt; a.o = ao.p; a.ldo = C;
+            a.q = qp; a.ldq = ldq; a.k = kp; a.ldk = ldk; a.vt = vtp; a.ldvt = ldvt; a.o = ao.p; a.ldo = C;
             a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
             TRY(launch_attention(st, a));
         }
@@ -509,6 +520,56 @@ struct gyre_unet {
     struct Level { std::vector<ResW> res; std::vector<TransW> attn; ConvW resample; bool has_resample = false; };
     std::vector<Level> down, up;
     ResW mid0, mid1; TransW mid_attn;
+    // text-context cache (cross-attention K / V^T per layer, and the bf16 copy of the context)
+    std::vector<CtxKV> kv_cache;
+    void* kv_buf = nullptr; size_t kv_bytes = 0;
+    int cache_B = 0, cache_S = 0; bool cache_valid = false;
+    ~gyre_unet() { if (kv_buf) (void)hipFree(kv_buf); }
+
+    template <typename F> void for_each_cross_attn(F f) {
+        for (auto& lv : down) for (auto& t : lv.attn) for (auto& b : t.blocks) f(b.a2);
+        for (auto& b : mid_attn.blocks) f(b.a2);
+        for (auto& lv : up) for (auto& t : lv.attn) for (auto& b : t.blocks) f(b.a2);
+    }
+    // Project the text context through every cross-attention to_k / to_v once; the denoising loop then calls
+    // forward with ctx == NULL (the context is constant over the 50+ UNet evaluations of a request).
+    int set_context(hipStream_t st, const void* ctx, int cdt, int B, int S) {
+        if (B < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty context");
+        const int D = cfg.cross_attention_dim, Spad = (S + 7) / 8 * 8;
+        size_t need = align_up((size_t)B * S * D * 2, 256);
+        for_each_cross_attn([&](AttnW& a) { need += align_up((size_t)B * S * a.c * 2, 256) + align_up((size_t)B * a.c * Spad * 2, 256); });
+        cache_valid = false;
+        if (need > kv_bytes) {
+            if (kv_buf) { GYRE_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(kv_buf); kv_buf = nullptr; kv_bytes = 0; }
+            GYRE_HIP_CHECK(hipMalloc(&kv_buf, need));
+            kv_bytes = need;
+        }
+        GYRE_HIP_CHECK(hipMemsetAsync(kv_buf, 0, need, st));   // V^T pad columns must be finite
+        char* ptr = (char*)kv_buf;
+        bf16_t* cx = (bf16_t*)ptr; ptr += align_up((size_t)B * S * D * 2, 256);
+        TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx));
+        kv_cache.clear();
+        int rc = 0;
+        for_each_cross_attn([&](AttnW& a) {
+            if (rc) return;
+            CtxKV e;
+            e.k = (bf16_t*)ptr; ptr += align_up((size_t)B * S * a.c * 2, 256);
+            e.vt = (bf16_t*)ptr; ptr += align_up((size_t)B * a.c * Spad * 2, 256);
+            GemmParams p;
+            p.A = cx; p.lda = D; p.mode = GEMM_LINEAR; p.W = a.wk; p.K = D; p.N = a.c; p.M = B * S; p.bias = a.bk;
+            p.out = e.k; p.ldc = a.c; p.out_mode = OUT_BF16;
+            rc = launch_gemm(st, p);
+            if (rc) return;
+            GemmParams q;
+            q.A = cx; q.lda = D; q.mode = GEMM_LINEAR; q.W = a.wv; q.K = D; q.N = a.c; q.M = B * S; q.bias = a.bv;
+            q.out = e.vt; q.out_mode = OUT_BF16_T; q.tokens_per_batch = S; q.ldt = Spad;
+            rc = launch_gemm(st, q);
+            kv_cache.push_back(e);
+        });
+        if (rc) return rc;
+        cache_B = B; cache_S = S; cache_valid = true;
+        return 0;
+    }
 
     int build() {
         const gyre_unet_cfg& c = cfg;
@@ -599,7 +660,8 @@ struct gyre_unet {
     }
 
     int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
-            int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr) {
+            int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr,
+            bool use_ctx_cache = false) {
         const gyre_unet_cfg& c = cfg;
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
@@ -609,16 +671,21 @@ struct gyre_unet {
         ex.st = st;
         Exec& e = ex;
         const int D = c.cross_attention_dim;
+        const bool cached = use_ctx_cache;
+        if (cached && (!cache_valid || cache_B != B || cache_S != S))
+            GYRE_FAIL(GYRE_ERR_INVALID, "unet: ctx == NULL needs a gyre_unet_set_context call with the same B and S");
+        e.ctx_cache = cached ? &kv_cache : nullptr;
+        e.ctx_layer = 0;
         Tn xin, cx, emb, t1, t2, tp;
         TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
-        TRY(e.alloc(cx, B, S, 1, D));
+        if (!cached) TRY(e.alloc(cx, B, S, 1, D));
         TRY(e.alloc(emb, B, 1, 1, c.block_out_channels[0], 4));
         TRY(e.alloc(t1, B, 1, 1, temb_dim, 4));
         TRY(e.alloc(t2, B, 1, 1, temb_dim, 4));
         TRY(e.alloc(tp, B, 1, 1, temb_cols, 4));
         if (!dry) {
             TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
-            TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
+            if (!cached) TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
             TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
             TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
             TRY(launch_rowvec_linear(st, (float*)t1.p, B, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
@@ -885,6 +952,7 @@ const char* gyre_unet_param_key(const gyre_unet* h, int i) {
 int gyre_unet_set_weight(gyre_unet* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* st) {
     if (!h || !key || !p || !shape) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     h->finalized = false;
+    h->cache_valid = false;
     return h->store.set_weight(key, p, dtype, shape, ndim, (hipStream_t)st);
 }
 int gyre_unet_finalize(gyre_unet* h, void* st) {
@@ -896,15 +964,26 @@ int gyre_unet_finalize(gyre_unet* h, void* st) {
 size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     if (!h) return 0;
     if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0)) return 0;
-    return h->ex.arena.peak;
+    size_t peak = h->ex.arena.peak;
+    if (h->cache_valid && h->cache_B == B && h->cache_S == S) {   // cached-context path allocates a subset; take the max
+        if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0, nullptr, true)) return 0;
+        peak = std::max(peak, h->ex.arena.peak);
+    }
+    return peak;
+}
+int gyre_unet_set_context(gyre_unet* h, void* st, const void* ctx, int cdt, int B, int S) {
+    if (!h || !ctx) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    if (cdt < 0 || cdt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    return h->set_context((hipStream_t)st, ctx, cdt, B, S);
 }
 int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                          int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add) {
-    if (!h || !x || !t || !ctx || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!h || !x || !t || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     if (xdt < 0 || xdt > 2 || cdt < 0 || cdt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
-    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add);
+    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr);
 }
 int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                       int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {

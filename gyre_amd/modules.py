@@ -59,15 +59,18 @@ class _NativeModule(nn.Module):
         self._handle_device: Optional[torch.device] = None
         self._dirty = True
         self._ws: Optional[torch.Tensor] = None
+        self._ctx_src, self._ctx_ver, self._ctx_handle = None, -1, None
         self.register_load_state_dict_post_hook(lambda m, ik: m._invalidate())
 
     # -- lifecycle ---------------------------------------------------------------------------
     def _invalidate(self):
         self._dirty = True
+        self._ctx_src = None
 
     def _apply(self, fn, *a, **k):  # .to() / .half() / .cuda(): the native copy is stale afterwards
         r = super()._apply(fn, *a, **k)
         self._dirty = True
+        self._ctx_src = None
         return r
 
     def _destroy(self):
@@ -174,6 +177,7 @@ class GyreHipUNet(_NativeModule):
     def __init__(self, config: Optional[UNetConfig] = None):
         super().__init__()
         self.config = config or sd15_unet()
+        self._ctx_src, self._ctx_ver, self._ctx_handle = None, -1, None
         _build_tree(self, unet_param_shapes(self.config))
 
     def _shapes(self):
@@ -261,6 +265,14 @@ class GyreHipUNet(_NativeModule):
         S = ctx.shape[1]
         L = _lib.lib()
         with torch.cuda.device(dev):
+            # context cache: the denoising loop passes the SAME embeddings tensor on every call (the reference binds
+            # it once per request, unet/core.py:242-259); project it through the cross-attention K/V weights once.
+            # Identity + version of a tensor we keep referenced => the storage cannot have been recycled.
+            src = encoder_hidden_states
+            if not (self._ctx_src is src and self._ctx_ver == src._version and self._ctx_handle == h):
+                _lib.check(L.gyre_unet_set_context(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)),
+                                                   C.c_void_p(ctx.data_ptr()), _lib.dtype_code(ctx), B, S))
+                self._ctx_src, self._ctx_ver, self._ctx_handle = src, src._version, h
             need = L.gyre_unet_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
                 _lib.check(-1 if "unet:" in L.gyre_last_error().decode() else -4)
@@ -269,7 +281,7 @@ class GyreHipUNet(_NativeModule):
             out = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
             aug = self._aug_embedding(added_cond_kwargs, B, dev)
             _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
-                                              _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                                              _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None,
                                               _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
                                               C.c_void_p(out.data_ptr()), _lib.dtype_code(out),
                                               C.c_void_p(aug.data_ptr()) if aug is not None else None))

@@ -122,6 +122,13 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
                       void* workspace, size_t workspace_bytes,
                       void* eps_out_nchw, int out_dtype);
 
+/* Text-context cache.  The context is constant over the 50+ UNet evaluations of a request, so its cross-attention
+ * K / V projections (32 small GEMMs per call for SD1.x) can be done once: set_context projects ctx[B,S,cross_dim]
+ * through every attn2.to_k / to_v into handle-owned buffers (may (re)allocate: not for the per-step path); afterwards
+ * gyre_unet_forward / _ex accept ctx == NULL with the same B and S and reuse them.  Any set_weight invalidates it.
+ * In the reference the same tensor is re-projected on every call (unet/core.py:253-259 binds it per wrapper). */
+int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_dtype, int B, int S);
+
 /* Same, plus an optional additive term for the time embedding: temb_add[B, 4*block_out_channels[0]] (f32, dev) is
  * added to time_embedding(t) before it feeds the ResNet blocks.  This is how SDXL's `text_time` added conditioning
  * (add_embedding MLP over pooled text + size/crop ids, a few MFLOP) enters: the MLP stays host PyTorch. */

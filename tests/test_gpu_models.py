@@ -141,3 +141,34 @@ def test_tiny_sdxl_topology_parity():
     report("tiny sdxl-topology unet", got.cpu(), ref, 3e-2)
     with pytest.raises(ValueError):
         net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))
+
+
+def test_context_cache_matches_uncached_and_tracks_changes():
+    """The shell projects the text context once (gyre_unet_set_context) and reuses it while the SAME tensor is passed;
+    a new tensor, or an in-place edit of the old one, must be picked up."""
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 16, 16, seed=21).to(DEV)
+    t = torch.tensor([700, 30], device=DEV)
+    c1 = randn(2, 77, cfg.cross_attention_dim, seed=22).to(DEV)
+    c2 = randn(2, 77, cfg.cross_attention_dim, seed=23).to(DEV)
+    a1 = net(x, t, encoder_hidden_states=c1).sample
+    a1b = net(x, t, encoder_hidden_states=c1).sample          # cached path
+    assert torch.equal(a1, a1b)
+    a2 = net(x, t, encoder_hidden_states=c2).sample            # different tensor -> re-projected
+    assert not torch.equal(a1, a2)
+    ref2 = M.unet_forward(sd, cfg, x.cpu(), t.cpu(), c2.cpu())
+    report("ctx cache second context", a2.cpu(), ref2, 3e-2)
+    c2.copy_(c1)                                               # in-place edit bumps the version counter
+    a3 = net(x, t, encoder_hidden_states=c2).sample
+    assert torch.equal(a3, a1)
+    # raw C ABI: ctx == NULL without a matching set_context is an error, not a crash
+    import ctypes as C
+    from gyre_amd import _lib
+    L = _lib.lib()
+    h = net._handle
+    ws = torch.empty(L.gyre_unet_workspace_bytes(C.c_void_p(h), 3, 16, 16, 77) + 256, dtype=torch.uint8, device=DEV)
+    x3 = randn(3, 4, 16, 16).to(DEV); t3 = torch.zeros(3, dtype=torch.int64, device=DEV); o3 = torch.empty_like(x3)
+    rc = L.gyre_unet_forward(C.c_void_p(h), None, C.c_void_p(x3.data_ptr()), 0, C.c_void_p(t3.data_ptr()), None, 0, 3, 16, 16, 77,
+                             C.c_void_p((ws.data_ptr() + 255) & ~255), ws.numel() - 256, C.c_void_p(o3.data_ptr()), 0)
+    assert rc == -1 and b"set_context" in L.gyre_last_error()
