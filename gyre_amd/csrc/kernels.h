@@ -27,6 +27,8 @@ size_t gn_workspace_bytes(int B, int HW, int C, int G);
 int gn_pick_chunks(int B, int HW, int C);
 int launch_groupnorm_stats(hipStream_t st, const GnParams& p);   // partial sums + finalize -> scale_shift
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+b)
+bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch path for small feature maps
+int launch_groupnorm_small(hipStream_t st, const GnParams& p);
 int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
                      bf16_t* y);
 

@@ -292,8 +292,12 @@ struct Exec {
             p.partial = (float*)ws.p;
             p.scale_shift = (float*)((char*)ws.p + align_up((size_t)x.B * p.nchunks * groups * 2 * sizeof(float), 256));
             p.y = y.p;
-            TRY(launch_groupnorm_stats(st, p));
-            TRY(launch_groupnorm_apply(st, p));
+            if (gn_use_small(HW, C, x.C, groups)) {
+                TRY(launch_groupnorm_small(st, p));
+            } else {
+                TRY(launch_groupnorm_stats(st, p));
+                TRY(launch_groupnorm_apply(st, p));
+            }
         }
         free(ws);
         return 0;
@@ -1068,6 +1072,7 @@ int gyre_op_groupnorm(void* st, const void* x, const void* x2, int C1, int B, in
     p.partial = (float*)ws;
     p.scale_shift = (float*)((char*)ws + align_up((size_t)B * p.nchunks * groups * 2 * sizeof(float), 256));
     p.y = (bf16_t*)y;
+    if (gn_use_small(HW, C, p.C1, groups)) return launch_groupnorm_small((hipStream_t)st, p);
     TRY(launch_groupnorm_stats((hipStream_t)st, p));
     return launch_groupnorm_apply((hipStream_t)st, p);
 }

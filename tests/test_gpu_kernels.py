@@ -43,6 +43,8 @@ def test_nchw_to_nhwc_pad():
     (2, 64, 64, 320, 0, 1, 1e-5), (2, 32, 32, 640, 0, 0, 1e-6), (2, 16, 16, 1280, 0, 1, 1e-5),
     (2, 8, 8, 2560, 1280, 1, 1e-5), (2, 32, 32, 960, 640, 1, 1e-5), (1, 128, 128, 128, 0, 1, 1e-6),
     (3, 24, 40, 64, 0, 1, 1e-5), (1, 8, 8, 1920, 1280, 1, 1e-5),
+    (2, 16, 16, 1280, 0, 0, 1e-6), (2, 16, 16, 2560, 1280, 1, 1e-5), (2, 16, 16, 1920, 1280, 1, 1e-5),
+    (2, 32, 32, 640, 0, 1, 1e-5), (4, 8, 8, 1280, 0, 1, 1e-5), (2, 8, 8, 64, 0, 1, 1e-5),
 ])
 def test_groupnorm(B, H, W, C, C1, silu, eps):
     L = _lib.lib()
