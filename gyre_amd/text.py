@@ -55,3 +55,190 @@ class ClipTextEncoder:
     def __call__(self, input_ids: torch.Tensor) -> torch.Tensor:
         out = self.model(input_ids=input_ids.to(self.device), return_dict=True)
         return out.last_hidden_state.float()
+
+
+# ------------------------------------------------------------------------------------------------
+# Long-prompt weighting (host logic of reference text_embedding/lpw_text_embedding.py:35-405):
+# "(text)" x1.1, "(text:w)" x w, "[text]" /1.1, backslash escapes; tokens are padded to 75k+2, encoded in
+# 77-token chunks, multiplied by their weights and rescaled to keep the embedding mean.
+# Pinned by tests/golden (parser outputs, padding, weighting produced by the reference functions).
+# ------------------------------------------------------------------------------------------------
+def parse_prompt_attention(text: str):
+    """-> [[fragment, weight], ...] with adjacent equal-weight fragments merged."""
+    up, down = 1.1, 1.0 / 1.1
+    res, rounds, squares = [], [], []
+
+    def scale_from(start, m):
+        for item in res[start:]:
+            item[1] *= m
+
+    i, n, buf = 0, len(text), ""
+
+    def flush():
+        nonlocal buf
+        if buf:
+            res.append([buf, 1.0])
+            buf = ""
+
+    while i < n:
+        ch = text[i]
+        if ch == "\\" and i + 1 < n and text[i + 1] in "()[]\\":
+            flush()
+            res.append([text[i + 1], 1.0])
+            i += 2
+            continue
+        if ch == "\\":  # a lone backslash is dropped (the reference grammar consumes it as an escape lead-in)
+            flush()
+            res.append(["", 1.0])
+            i += 1
+            continue
+        if ch == "(":
+            flush(); rounds.append(len(res)); i += 1; continue
+        if ch == "[":
+            flush(); squares.append(len(res)); i += 1; continue
+        if ch == ":":
+            # ":<number>)" closes a round bracket with an explicit weight
+            j = i + 1
+            while j < n and text[j] == " ":
+                j += 1
+            k = j
+            if k < n and text[k] in "+-":
+                k += 1
+            d0 = k
+            while k < n and (text[k].isdigit() or text[k] == "."):
+                k += 1
+            e = k
+            while e < n and text[e] == " ":
+                e += 1
+            if k > d0 and e < n and text[e] == ")":
+                try:
+                    w = float(text[j:k])
+                    if rounds:
+                        flush(); scale_from(rounds.pop(), w)
+                    else:
+                        buf += text[i:e + 1]; flush()
+                    i = e + 1
+                    continue
+                except ValueError:
+                    pass
+            buf += ch; i += 1; continue
+        if ch == ")":
+            flush()
+            if rounds:
+                scale_from(rounds.pop(), up)
+            else:
+                res.append([")", 1.0])
+            i += 1; continue
+        if ch == "]":
+            flush()
+            if squares:
+                scale_from(squares.pop(), down)
+            else:
+                res.append(["]", 1.0])
+            i += 1; continue
+        buf += ch
+        i += 1
+    flush()
+    for pos in rounds:
+        scale_from(pos, up)
+    for pos in squares:
+        scale_from(pos, down)
+    if not res:
+        res = [["", 1.0]]
+    merged = [res[0]]
+    for frag, w in res[1:]:
+        if merged[-1][1] == w:
+            merged[-1][0] += frag
+        else:
+            merged.append([frag, w])
+    return merged
+
+
+def pad_tokens_and_weights(tokens, weights, max_length: int, bos: int, eos: int, no_boseos_middle: bool = True,
+                           chunk_length: int = MAX_LEN):
+    """BOS + tokens + EOS padding to max_length; weights padded with 1.0 (per chunk when BOS/EOS are kept)."""
+    mult = (max_length - 2) // (chunk_length - 2)
+    out_t, out_w = [], []
+    for tk, wt in zip(tokens, weights):
+        out_t.append([bos] + list(tk) + [eos] * (max_length - 1 - len(tk)))
+        if no_boseos_middle:
+            out_w.append([1.0] + list(wt) + [1.0] * (max_length - 1 - len(wt)))
+        else:
+            total = mult * chunk_length
+            if not wt:
+                w = [1.0] * total
+            else:
+                w = []
+                body = chunk_length - 2
+                for j in range(mult):
+                    w.append(1.0)
+                    w += list(wt[j * body:min(len(wt), (j + 1) * body)])
+                    w.append(1.0)
+                w += [1.0] * (total - len(w))
+            out_w.append(w)
+    return out_t, out_w
+
+
+def chunked_encode(encoder, input_ids: torch.Tensor, chunk_length: int = MAX_LEN, no_boseos_middle: bool = True):
+    """Encode [B, 75k+2] ids in k chunks of 77 (BOS/EOS re-attached per chunk), concatenated along the token axis."""
+    mult = (input_ids.shape[1] - 2) // (chunk_length - 2)
+    if mult <= 1:
+        return encoder(input_ids)
+    body = chunk_length - 2
+    parts = []
+    for i in range(mult):
+        chunk = input_ids[:, i * body:(i + 1) * body + 2].clone()
+        chunk[:, 0] = input_ids[0, 0]
+        chunk[:, -1] = input_ids[0, -1]
+        e = encoder(chunk)
+        if no_boseos_middle:
+            e = e[:, :-1] if i == 0 else (e[:, 1:] if i == mult - 1 else e[:, 1:-1])
+        parts.append(e)
+    return torch.cat(parts, dim=1)
+
+
+def apply_token_weights(emb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """emb * w, then rescaled so that the per-prompt mean of the embedding is unchanged."""
+    prev = emb.mean(dim=(-2, -1))
+    out = emb * weights.unsqueeze(-1)
+    return out * (prev / out.mean(dim=(-2, -1))).unsqueeze(-1).unsqueeze(-1)
+
+
+class LPWTextEmbedder:
+    """get_embeddings(prompts, negative_prompts) -> (cond [B,75k+2... ,D], uncond).  `tokenize(fragment) -> [ids]`
+    is supplied by the caller (a CLIP tokenizer's ids without BOS/EOS); no vocabulary ships offline."""
+
+    def __init__(self, encoder, tokenize, max_embeddings_multiples: int = 3, bos: int = BOS, eos: int = EOS):
+        self.encoder, self.tokenize, self.mult, self.bos, self.eos = encoder, tokenize, max_embeddings_multiples, bos, eos
+
+    def _tokens(self, prompts, max_len):
+        toks, wts = [], []
+        for ptxt in prompts:
+            t, w = [], []
+            for frag, weight in (parse_prompt_attention(ptxt) if isinstance(ptxt, str) else ptxt):
+                ids = list(self.tokenize(frag))
+                t += ids
+                w += [weight] * len(ids)
+                if len(t) > max_len:
+                    break
+            toks.append(t[:max_len]); wts.append(w[:max_len])
+        return toks, wts
+
+    def get_embeddings(self, prompts, uncond_prompts=None):
+        body = MAX_LEN - 2
+        lim = body * self.mult
+        pt, pw = self._tokens(prompts, lim)
+        ut, uw = self._tokens(uncond_prompts, lim) if uncond_prompts is not None else ([], [])
+        longest = max([len(t) for t in pt + ut] + [1])
+        mult = max(1, min(self.mult, (longest - 1) // body + 1))
+        max_length = body * mult + 2
+        dev = getattr(self.encoder, "device", "cpu")
+
+        def run(tok, wt):
+            tok, wt = pad_tokens_and_weights(tok, wt, max_length, self.bos, self.eos, True, MAX_LEN)
+            ids = torch.tensor(tok, dtype=torch.long, device=dev)
+            emb = chunked_encode(self.encoder, ids, MAX_LEN, True)
+            return apply_token_weights(emb, torch.tensor(wt, dtype=emb.dtype, device=emb.device))
+
+        cond = run(pt, pw)
+        return cond, (run(ut, uw) if uncond_prompts is not None else None)

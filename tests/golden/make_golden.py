@@ -265,6 +265,31 @@ def main():
     out["vae_approx_in"] = l4.numpy()
     out["vae_approx_out"] = va(l4).numpy()
 
+    # (9) prompt attention parser + token/weight padding (long-prompt weighting) ------------------------
+    import json
+    from gyre.pipeline.text_embedding import lpw_text_embedding as lpw
+    prompts = ["normal text", "an (important) word", "(unbalanced", "\\(literal\\]", "(unnecessary)(parens)",
+               "a (((house:1.3)) [on] a (hill:0.5), sun, (((sky))).", "", "[[deep]] (a:2) b) c] \\\\ d",
+               "(x:1.5)(y:0.25) [z", "no (nested [mix (of:3) all] kinds) here"]
+    out["lpw_prompts"] = np.array(json.dumps(prompts))
+    out["lpw_parsed"] = np.array(json.dumps([lpw.parse_prompt_attention(t) for t in prompts]))
+    toks = [[5, 6, 7], [], list(range(100, 180))]
+    wts = [[1.1, 1.0, 0.5], [], [1.0 + 0.01 * i for i in range(80)]]
+    import copy
+    for nbm in (True, False):
+        t2, w2 = lpw.pad_tokens_and_weights(copy.deepcopy(toks), copy.deepcopy(wts), 152, 49406, 49407,
+                                            no_boseos_middle=nbm, chunk_length=77)
+        out[f"lpw_pad_tokens_nbm{int(nbm)}"] = np.array(t2, dtype=np.int64)
+        out[f"lpw_pad_weights_nbm{int(nbm)}"] = np.array(w2, dtype=np.float64)
+    # mean-preserving weighting as applied at lpw_text_embedding.py:366-375
+    g = torch.Generator().manual_seed(21)
+    emb = torch.randn(2, 77, 16, generator=g) + 0.3
+    w = torch.rand(2, 77, generator=g) * 1.5
+    prev = emb.mean(axis=[-2, -1])
+    e2 = emb * w.unsqueeze(-1)
+    e2 = e2 * (prev / e2.mean(axis=[-2, -1])).unsqueeze(-1).unsqueeze(-1)
+    out["lpw_weighting_in"] = emb.numpy(); out["lpw_weighting_w"] = w.numpy(); out["lpw_weighting_out"] = e2.numpy()
+
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", len(out), "arrays:", sorted(out))
 

@@ -1,0 +1,45 @@
+"""Prompt-weighting host code vs vectors produced by the reference's own functions (tests/golden)."""
+import json
+
+import numpy as np
+import torch
+
+from gyre_amd import text as T
+
+
+def test_parse_prompt_attention_matches_reference(golden):
+    prompts = json.loads(str(golden["lpw_prompts"]))
+    want = json.loads(str(golden["lpw_parsed"]))
+    for ptxt, w in zip(prompts, want):
+        got = T.parse_prompt_attention(ptxt)
+        assert [g[0] for g in got] == [x[0] for x in w], (ptxt, got, w)
+        assert np.allclose([g[1] for g in got], [x[1] for x in w], rtol=1e-12), (ptxt, got, w)
+
+
+def test_pad_tokens_and_weights_matches_reference(golden):
+    toks = [[5, 6, 7], [], list(range(100, 180))]
+    wts = [[1.1, 1.0, 0.5], [], [1.0 + 0.01 * i for i in range(80)]]
+    for nbm in (True, False):
+        t2, w2 = T.pad_tokens_and_weights(toks, wts, 152, 49406, 49407, no_boseos_middle=nbm, chunk_length=77)
+        assert np.array_equal(np.array(t2), golden[f"lpw_pad_tokens_nbm{int(nbm)}"])
+        assert np.allclose(np.array(w2), golden[f"lpw_pad_weights_nbm{int(nbm)}"], rtol=0, atol=0)
+
+
+def test_token_weighting_matches_reference(golden):
+    out = T.apply_token_weights(torch.from_numpy(golden["lpw_weighting_in"]), torch.from_numpy(golden["lpw_weighting_w"]))
+    assert np.allclose(out.numpy(), golden["lpw_weighting_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_lpw_embedder_long_prompt_chunks():
+    calls = []
+
+    def enc(ids):
+        calls.append(tuple(ids.shape))
+        return torch.nn.functional.one_hot(ids % 8, 8).float() + 0.1
+
+    emb = T.LPWTextEmbedder(enc, lambda frag: [ord(c) for c in frag if c != " "], max_embeddings_multiples=3)
+    cond, unc = emb.get_embeddings(["a (b:2) " + "c" * 90], [""])
+    assert cond.shape == (1, 152, 8) and unc.shape == (1, 152, 8)   # 2 chunks of 75 + BOS/EOS
+    assert calls == [(1, 77), (1, 77), (1, 77), (1, 77)]
+    short, _ = emb.get_embeddings(["(x:1.5) y"])
+    assert short.shape == (1, 77, 8)
