@@ -680,6 +680,212 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 4-wave LDS-DMA variant, K step 32, sized so that TWO independent workgroups share a CU (57 KB LDS, 256 VGPRs).
+// Same tile math as k_gemm8 (wave tile 64 x 160 for the 128x320 tile), but the two co-resident workgroups are not
+// tied by a common barrier: they drift apart, so one's DMA-issue / barrier / epilogue phases run under the
+// other's MFMA phase (with one 8-wave workgroup per CU all waves hit those phases together and the matrix pipe
+// idles; its epilogue store drain cannot overlap anything - see the persistent-kernel note above).
+// LDS rows are 64 B (32 bf16): one DMA wave-instruction fills 16 rows; 16-byte slots are XOR-swizzled with
+// (row >> 2) & 3 on the source address and on the ds_read_b128 (conflict-free: 16 rows x same k-slot hit 16 slots).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
+__global__ __launch_bounds__(256, 2) void k_gemm4d(GemmParams p, int tiles_m, int tiles_n, int splits) {
+    constexpr int BKS = 32;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int AR = BM / 64, BR = BN / 64;      // DMA instructions per wave per K step (16 rows each, 4 waves)
+    constexpr int STAGE_BYTES = (BM + BN) * 64;
+    static_assert(WM * WN == 4 && BM % 64 == 0 && BN % 64 == 0, "4 waves, 64-row staging granules");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int ntiles = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntiles;
+    const int bid = xcd_tile_id(blockIdx.x - split * ntiles, ntiles);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int rl = lane >> 2;                       // row inside a 16-row DMA granule
+    const int kvs = (lane & 3) ^ ((lane >> 4) & 3); // global k-granule fetched into LDS slot (lane & 3): swizzle (row>>2)&3
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // rows staged by this lane: A rows 16*(wave + 4*i) + rl (i < AR), B rows 16*(wave + 4*i) + rl (i < BR)
+    int a_base[AR], a_y0[AR], a_x0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int row = m0 + 16 * (wave + 4 * i) + rl;
+        bool ok = row < p.M;
+        if (MODE == GEMM_LINEAR) {
+            a_base[i] = ok ? row : -1;
+            a_y0[i] = 0; a_x0[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int n = row / hw, rem = row - n * hw;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = ok ? n * p.Hi * p.Wi : -1;
+            a_y0[i] = oy * p.stride - p.pad;
+            a_x0[i] = ox * p.stride - p.pad;
+        }
+    }
+    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+    const bf16_t* zero = p.zero_page;
+
+    auto issue_stage = [&](int kc, int s) {
+        char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
+        const int k = kc * BKS + kvs * 8;
+        const bool kok = k < p.K;
+        if (MODE == GEMM_LINEAR) {
+            const bool first = k < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bf16_t* src = zero;
+                if (kok && a_base[i] >= 0)
+                    src = first ? p.A + (size_t)a_base[i] * p.lda + k : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 4096), 16, 0, 0);
+            }
+        } else {
+            int tap, c;
+            if (UNIFORM_TAP) {  // channel chunk (32 wide) outer, tap inner
+                const int chunk = kc / 9;
+                tap = kc - chunk * 9;
+                c = chunk * BKS + kvs * 8;
+            } else {
+                tap = k / p.Cin;
+                c = k - tap * p.Cin;
+            }
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool first = c < p.C1;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bf16_t* src = zero;
+                int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
+                    src = first ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
+                }
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 4096), 16, 0, 0);
+            }
+        }
+        int kw = k;
+        if (MODE == GEMM_CONV3 && UNIFORM_TAP) {
+            const int chunk = kc / 9, tap = kc - chunk * 9;
+            kw = tap * p.Cin + chunk * BKS + kvs * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int n = n0 + 16 * (wave + 4 * i) + rl;
+            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 64 + i * 4096), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_all = (p.K + BKS - 1) / BKS;
+    const int nk_per = (nk_all + splits - 1) / splits;
+    const int kc0 = split * nk_per;
+    const int nk = min(nk_all, kc0 + nk_per);
+    issue_stage(kc0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kc = kc0; kc < nk; ++kc) {
+        const int cur = (kc - kc0) & 1;
+        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
+        const char* a = smem_raw + cur * STAGE_BYTES;
+        const char* b = a + BM * 64;
+        if (!(p.debug & 2)) {
+            bf16x8_t af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                int r = wm * TM + i * 16 + fr;
+                af[i] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(a + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                int r = wn * TN + j * 16 + fr;
+                bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(b + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (splits > 1) {
+        float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * TM + i * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * TN + j * 16 + 4 * fq;
+                if (n < p.N) *(float4*)(slab + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
+    const int n_out = p.geglu ? p.N / 2 : p.N;
+    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
+        float* my = (float*)smem_raw + wave * (16 * (TN + 4));
+        if constexpr (NI % 2 == 0) {
+            if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my); return; }
+        }
+        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+        return;
+    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg4d(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int grid = tiles_m * tiles_n * splits;
+    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int ESIZE = 4 * 16 * (BN / WN + 4) * 4;
+    const int lds = 2 * STAGE > ESIZE ? 2 * STAGE : ESIZE;
+    const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
+    const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
+    const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
+                                                : (double)p.M * p.K * 2.0;
+    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
+                        a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
+#define GYRE_GEMM4D_GO(MODE_, UNI_)                                                                                 \
+    do {                                                                                                            \
+        auto kern = k_gemm4d<BM, BN, WM, WN, MODE_, UNI_>;                                                          \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n, splits);                      \
+    } while (0)
+    if (p.mode == GEMM_LINEAR) {
+        GYRE_GEMM4D_GO(GEMM_LINEAR, true);
+    } else {
+        const bool uni = (p.Cin % 32 == 0) && (p.C1 % 32 == 0);
+        if (uni) GYRE_GEMM4D_GO(GEMM_CONV3, true); else GYRE_GEMM4D_GO(GEMM_CONV3, false);
+    }
+#undef GYRE_GEMM4D_GO
+    GYRE_LAUNCH_CHECK();
+    if (splits > 1) {
+        const size_t nthreads = (size_t)p.M * (p.N / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
+        GYRE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
 // 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256.
 static int pick_cfg(const GemmParams& p, int* splits_out) {
@@ -775,6 +981,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         }
     }
     if (cfg >= 4) {
+        if (p.geglu && cfg == 9) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         p.zero_page = zero_page_for_current_device();
@@ -789,6 +996,8 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, 1);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         case 8: return launch_cfg8<128, 256, 2, 4, 3>(st, p, KC_G8_CONV_128x256, splits);  // experiment: 3-deep ring
+        case 9: return launch_cfg4d<128, 320, 2, 2>(st, p, KC_G8_CONV_128x320, splits);     // 2 workgroups / CU
+        case 10: return launch_cfg4d<128, 256, 2, 2>(st, p, KC_G8_CONV_128x256, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }
