@@ -8,7 +8,9 @@ reference's batched_seeds (generate.py:977-990: even split, remainder spread ove
 ranks) - runs the whole denoising loop on its slice with its own per-image generators, and
 the only collective is one all_gather of the finished latents (32 KB / image at 512^2).
 Weights are replicated.  Because every random draw is per image (randtools.py:39-64) and no
-kernel's arithmetic depends on batch position, the result is bit-identical for any split.
+kernel's arithmetic depends on batch position, an image's result does not depend on which rank or
+batch slot it lands in (bit-identical for equal shard sizes; across different shard sizes the GEMM
+planner may pick another split-K factor, which changes results only at bf16-rounding level).
 """
 from __future__ import annotations
 
