@@ -169,9 +169,10 @@ def main():
             traffic = None
             tj = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tj):
-                tinfo = json.load(open(tj))
-                if tinfo.get("kernel", "").startswith(dom_name):
-                    traffic = tinfo.get("hbm_bytes_per_launch")
+                hits = [v for k, v in json.load(open(tj)).get("kernels", {}).items() if k.startswith(dom_name)]
+                n = sum(h["launches_in_pmc_run"] for h in hits)
+                if n:
+                    traffic = round(sum(h["hbm_bytes_per_launch"] * h["launches_in_pmc_run"] for h in hits) / n)
             roof = {"bound": "mfma", "kernel": dom_name + ", ...>",
                     "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

@@ -70,6 +70,8 @@ _SIGS = {
     "gyre_debug_set_splitk_workspace": (_i, [_vp, _sz]),
     "gyre_debug_force_attn_variant": (_i, [_i]),
     "gyre_debug_gemm_ablation": (_i, [_i]),
+    "gyre_set_batch_invariant": (_i, [_i]),
+    "gyre_get_batch_invariant": (_i, []),
     "gyre_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
     "gyre_op_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
     "gyre_op_layernorm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp]),

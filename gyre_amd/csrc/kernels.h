@@ -25,6 +25,9 @@ struct GnParams {
 };
 size_t gn_workspace_bytes(int B, int HW, int C, int G);
 int gn_pick_chunks(int B, int HW, int C);
+// 0 = off; n > 0: plan every split-K factor as if the batch held n samples (results then do not depend on B)
+int gemm_set_batch_invariant(int canonical_samples);
+int gemm_get_batch_invariant();
 int launch_groupnorm_stats(hipStream_t st, const GnParams& p);   // partial sums + finalize -> scale_shift
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+b)
 bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch path for small feature maps
@@ -61,6 +64,7 @@ struct GemmParams {
     const bf16_t* zero_page = nullptr;      // >= 16 zero bytes in global memory (filled in by launch_gemm)
     int force_cfg = 0;                      // tests/tuning: 0 auto, else tile-config id (see launch_gemm)
     int debug = 0;                          // tuning ablations: bit0 = no operand loads in the K loop, bit1 = no MFMAs
+    int samples = 0;              // batch entries folded into M (0 = unknown); used by the batch-invariant planner
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;  // fp32 partial slabs [splits][M][N] (see gemm_plan)
 };
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.

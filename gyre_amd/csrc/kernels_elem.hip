@@ -256,10 +256,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p, size_t total_vec) 
 }
 
 int gn_pick_chunks(int B, int HW, int C) {
-    // aim for >= ~1024 blocks, chunks of >= 16 pixels
-    int want = (1024 + B - 1) / B;
-    int maxc = (HW + 15) / 16;
-    int n = want < maxc ? want : maxc;
+    // The chunking fixes the order the per-sample statistics are summed in, so it must not depend on B (batch
+    // independence): 16-pixel chunks up to 4096 pixels, then 256 chunks per sample with at most 256 pixels each,
+    // beyond that 256-pixel chunks (VAE resolutions).  Even B = 1 at 64x64 gets 256 blocks.
+    (void)B; (void)C;
+    int ppc = HW / 256;
+    ppc = ppc < 16 ? 16 : (ppc > 256 ? 256 : ppc);
+    int n = (HW + ppc - 1) / ppc;
     return n < 1 ? 1 : n;
 }
 size_t gn_workspace_bytes(int B, int HW, int C, int G) {

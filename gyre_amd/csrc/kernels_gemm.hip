@@ -25,6 +25,7 @@
 // torch.nn.Conv2d inside the third-party UNet/VAE the reference calls at
 // gyre/pipeline/unet/core.py:274 and gyre/pipeline/unified_pipeline.py:309,1531.
 #include "kernels.h"
+#include <atomic>
 #include <utility>
 
 #define BK 64
@@ -463,9 +464,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
         } else {
             int tap, c;
             if (UNIFORM_TAP) {
-                const int kb = kc * BK;
-                tap = kb / p.Cin;           // scalar: same tap for the whole K step
-                c = kb - tap * p.Cin + kv * 8;
+                // same K order as k_gemm8 (64-channel chunk outer, tap inner): every tile config then sums in the
+                // same order and gives bit-identical results, so the planner is free to choose by problem size
+                const int chunk = kc / 9;
+                tap = kc - chunk * 9;       // scalar: same tap for the whole K step
+                c = chunk * BK + kv * 8;
             } else {
                 tap = k / p.Cin;
                 c = k - tap * p.Cin;
@@ -488,11 +491,16 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
         }
         {
             const bool kok = k < p.K;
+            int kw = k;  // position of this lane's 8 weights inside a [taps][Cin] weight row
+            if (MODE == GEMM_CONV3 && UNIFORM_TAP) {
+                const int chunk = kc / 9, tap = kc - chunk * 9;
+                kw = tap * p.Cin + chunk * BK + kv * 8;
+            }
 #pragma unroll
             for (int i = 0; i < BR; ++i) {
                 int n = n0 + r0 + 32 * i;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (kok && n < p.N) v = *(const uint4*)(p.W + (size_t)n * p.K + k);
+                if (kok && n < p.N) v = *(const uint4*)(p.W + (size_t)n * p.K + kw);
                 rb[i] = v;
             }
         }
@@ -945,11 +953,32 @@ static int pick_cfg_nosplit(const GemmParams& p) {
     int sp; return pick_cfg(q, &sp);
 }
 
+// Batch-invariant planning.  Every tile config sums K in the same order, so the only way the batch size can change
+// a result bit is through the split-K factor (it is chosen from the tile count, i.e. from M = batch x rows).  With
+// the mode on, the factor is planned for M' = rows-per-sample x canonical batch whatever the real batch is: any
+// split of a request over GPUs / sub-batches then gives bit-identical images (reference property
+// tests/batch_independance.py:15-27 made exact) at the price of a worse-filled chip when batch << canonical.
+static std::atomic<int> g_invariant_batch{0};
+int gemm_set_batch_invariant(int n) { return g_invariant_batch.exchange(n < 0 ? 0 : n); }
+int gemm_get_batch_invariant() { return g_invariant_batch.load(); }
+
+static int plan_cfg(const GemmParams& p, int* splits) {
+    const int inv = g_invariant_batch.load();
+    if (inv > 0 && p.samples > 0 && p.M % p.samples == 0) {
+        GemmParams q = p;
+        q.M = p.M / p.samples * inv;
+        int c = pick_cfg(q, splits);
+        if (*splits > 1) return c;            // split path: 128-row tiles, fine for any M
+        return pick_cfg_nosplit(p);           // no split at the canonical size -> none here either
+    }
+    return pick_cfg(p, splits);
+}
+
 GemmPlan gemm_plan(const GemmParams& p0) {
     GemmParams p = p0;
     GemmPlan pl{3, 1, 0};
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return pl;
-    pl.cfg = pick_cfg(p, &pl.splits);
+    pl.cfg = plan_cfg(p, &pl.splits);
     if (pl.splits > 1) pl.ws_bytes = (size_t)pl.splits * p.M * p.N * sizeof(float);
     return pl;
 }
@@ -971,7 +1000,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
     int splits = 1;
-    int cfg = pick_cfg(p, &splits);
+    int cfg = plan_cfg(p, &splits);
     if (p.force_cfg) { cfg = p.force_cfg; splits = 1; }
     if (splits > 1) {
         if (!p.splitk_ws) { p.splitk_ws = g_dbg_ws; p.splitk_ws_bytes = g_dbg_ws_bytes; }

@@ -261,6 +261,7 @@ struct Exec {
     // cross-attention K / V^T of the current text context, projected once per request (gyre_unet_set_context)
     const std::vector<CtxKV>* ctx_cache = nullptr;
     size_t ctx_layer = 0;
+    int batch = 0;   // samples in the current call (planner hint, see gemm_set_batch_invariant)
 
     bool dry() const { return arena.dry; }
     int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
@@ -304,6 +305,7 @@ struct Exec {
     }
     // runs one GEMM launch, giving it split-K slab space from the arena when the planner wants it
     int run_gemm(GemmParams& p) {
+        if (!p.samples) p.samples = batch;
         GemmPlan pl = gemm_plan(p);
         Tn ws;
         if (pl.ws_bytes) {
@@ -560,12 +562,12 @@ struct gyre_unet {
             e.k = (bf16_t*)ptr; ptr += align_up((size_t)B * S * a.c * 2, 256);
             e.vt = (bf16_t*)ptr; ptr += align_up((size_t)B * a.c * Spad * 2, 256);
             GemmParams p;
-            p.A = cx; p.lda = D; p.mode = GEMM_LINEAR; p.W = a.wk; p.K = D; p.N = a.c; p.M = B * S; p.bias = a.bk;
+            p.A = cx; p.lda = D; p.mode = GEMM_LINEAR; p.W = a.wk; p.K = D; p.N = a.c; p.M = B * S; p.bias = a.bk; p.samples = B;
             p.out = e.k; p.ldc = a.c; p.out_mode = OUT_BF16;
             rc = launch_gemm(st, p);
             if (rc) return;
             GemmParams q;
-            q.A = cx; q.lda = D; q.mode = GEMM_LINEAR; q.W = a.wv; q.K = D; q.N = a.c; q.M = B * S; q.bias = a.bv;
+            q.A = cx; q.lda = D; q.mode = GEMM_LINEAR; q.W = a.wv; q.K = D; q.N = a.c; q.M = B * S; q.bias = a.bv; q.samples = B;
             q.out = e.vt; q.out_mode = OUT_BF16_T; q.tokens_per_batch = S; q.ldt = Spad;
             rc = launch_gemm(st, q);
             kv_cache.push_back(e);
@@ -672,7 +674,7 @@ struct gyre_unet {
         if ((H % (1 << (n - 1))) || (W % (1 << (n - 1))))
             GYRE_FAIL(GYRE_ERR_INVALID, "unet: latent H, W must be multiples of 2^(n_levels-1)");
         ex.arena.reset((char*)ws, ws_bytes, dry);
-        ex.st = st;
+        ex.st = st; ex.batch = B;
         Exec& e = ex;
         const int D = c.cross_attention_dim;
         const bool cached = use_ctx_cache;
@@ -875,7 +877,7 @@ struct gyre_vae {
         const int n = cfg.n_levels;
         if (B < 1 || H < 1 || W < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: empty input");
         if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: H, W must be multiples of 8");
-        ex.arena.reset((char*)ws, wsb, dry); ex.st = st;
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
         Exec& e = ex;
         Tn x, h;
         TRY(e.alloc(x, B, H, W, pad8(cfg.in_channels)));
@@ -907,7 +909,7 @@ struct gyre_vae {
                    void* out, int odt) {
         const int n = cfg.n_levels;
         if (B < 1 || h_ < 1 || w_ < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.decode: empty input");
-        ex.arena.reset((char*)ws, wsb, dry); ex.st = st;
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
         Exec& e = ex;
         Tn x, q, h;
         const int zc = pad8(cfg.latent_channels);
@@ -1059,6 +1061,9 @@ int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* byte
     return 0;
 }
 
+int gyre_set_batch_invariant(int n) { return gemm_set_batch_invariant(n); }
+int gyre_get_batch_invariant(void) { return gemm_get_batch_invariant(); }
+
 // ---- single operators -----------------------------------------------------------------------
 size_t gyre_op_groupnorm_workspace(int B, int HW, int C, int groups) { return gn_workspace_bytes(B, HW, C, groups); }
 int gyre_op_groupnorm(void* st, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
@@ -1105,7 +1110,7 @@ int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, con
     int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
     GemmParams p;
     p.A = (const bf16_t*)x; p.lda = Cin; p.mode = GEMM_CONV3; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
-    p.stride = stride; p.pad = pad; p.ups = ups; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * Ho * Wo;
+    p.stride = stride; p.pad = pad; p.ups = ups; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * Ho * Wo; p.samples = B;
     p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = Cout; p.rows_per_sample = Ho * Wo;
     p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
     return launch_gemm((hipStream_t)st, p);

@@ -288,6 +288,13 @@ class GyreHipUNet(_NativeModule):
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
 
+def set_batch_invariant(canonical_samples: int = 16) -> int:
+    """Plan every split-K factor for ``canonical_samples`` batch entries whatever the real batch is (0 = off, the
+    default): any split of a request over GPUs / sub-batches is then bit-identical (include/gyre_hip.h
+    gyre_set_batch_invariant; reference property tests/batch_independance.py:15-27).  Returns the previous value."""
+    return int(_lib.lib().gyre_set_batch_invariant(int(canonical_samples)))
+
+
 class DiagonalGaussian:
     """diffusers DiagonalGaussianDistribution [3P] as used at unified_pipeline.py:309-313."""
 

@@ -45,8 +45,13 @@ def gather_batches(local: torch.Tensor, sizes: Sequence[int], group=None) -> tor
 
 
 def generate_sharded(pipe, *, seeds: Sequence[int], text_embeddings: torch.Tensor,
-                     uncond_embeddings: Optional[torch.Tensor] = None, group=None, gather: bool = True, **kw):
+                     uncond_embeddings: Optional[torch.Tensor] = None, group=None, gather: bool = True,
+                     bit_exact: bool = False, **kw):
     """Run pipe(...) on this rank's slice of the batch and gather the finished latents.
+
+    bit_exact=True switches the native library to batch-invariant planning (modules.set_batch_invariant) for the
+    call, so the gathered result is bit-identical to a single-GPU run of the whole batch for ANY world size, also
+    when the shards differ in size; off, that only holds between equal-sized shards.
 
     Returns (latents_full [B,4,h,w] on every rank, (start, end) of the local slice).
     Ranks with an empty slice (more GPUs than images) only take part in the collective."""
@@ -60,7 +65,15 @@ def generate_sharded(pipe, *, seeds: Sequence[int], text_embeddings: torch.Tenso
         ue = uncond_embeddings
         if ue is not None and ue.shape[0] != 1:
             ue = ue[s:e]
-        local = pipe(seeds=list(seeds[s:e]), text_embeddings=te, uncond_embeddings=ue, **kw)
+        prev = None
+        if bit_exact:
+            from .modules import set_batch_invariant
+            prev = set_batch_invariant(16)
+        try:
+            local = pipe(seeds=list(seeds[s:e]), text_embeddings=te, uncond_embeddings=ue, **kw)
+        finally:
+            if prev is not None:
+                set_batch_invariant(prev)
     else:
         h, w = kw.get("height", 512) // 8, kw.get("width", 512) // 8
         local = torch.zeros((0, 4, h, w), dtype=torch.float32, device=pipe.device)

@@ -176,6 +176,18 @@ int gyre_debug_force_attn_variant(int v);
 /* Tuning only: bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs (results are garbage). */
 int gyre_debug_gemm_ablation(int bits);
 
+/* ---- batch-invariant mode ------------------------------------------------
+ * The reference asserts that an image does not depend on what shares its batch (tests/batch_independance.py:15-27)
+ * and splits a request into sub-batches by available memory (services/generate.py:977-990,1049-1091).  All kernels
+ * here are batch-position independent and every GEMM tile configuration sums in the same order, but the split-K
+ * factor of the deep (16x16 / 8x8) UNet levels is chosen from the tile count and therefore from the batch size.
+ * canonical_samples > 0 plans that factor as if every call held canonical_samples batch entries (16 = the
+ * 8-images-with-CFG call of the headline configuration): results become bit-identical for ANY split of a batch
+ * over GPUs or sub-batches, while calls much smaller than the canonical size fill the chip less well.
+ * 0 (default) = plan for the actual batch.  Process-wide; returns the previous value. */
+int gyre_set_batch_invariant(int canonical_samples);
+int gyre_get_batch_invariant(void);
+
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
 /* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */
 int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,

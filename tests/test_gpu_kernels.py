@@ -370,3 +370,61 @@ def test_attention_variants(variant, B, heads, Nq, Nk, D):
     finally:
         L.gyre_debug_force_attn_variant(old)
     report(f"attention v{variant} B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, TOL_ATTN)
+
+
+def test_all_tile_configs_sum_in_the_same_order():
+    """Every production tile config (4-wave 128x128 / 256x64 / 64x64, 8-wave 256x320 / 128x320 / 256x256 / 128x256)
+    gives BIT-identical output for the same problem: the planner may pick by problem size without changing results.
+    (Configs 9/10, the BK=32 experiment, sum in 32-channel chunks and are excluded.)"""
+    L = _lib.lib()
+    # 3x3 conv, uniform taps, dual-source-free; Cout multiple of 320 and 256 so that all configs are legal
+    B, H, W, Cin, Cout = 2, 20, 24, 192, 1280
+    x = to_dev_bf16(nhwc(bf16_round(randn(B, Cin, H, W, seed=60))))
+    w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
+    b = randn(Cout, seed=62).to(DEV)
+    outs = {}
+    for cfg in (1, 2, 3, 4, 5, 6, 7):
+        y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        old = L.gyre_debug_force_gemm_cfg(cfg)
+        try:
+            _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, W, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
+        finally:
+            L.gyre_debug_force_gemm_cfg(old)
+        outs[cfg] = y
+    for cfg, y in outs.items():
+        assert torch.equal(y, outs[1]), f"conv: config {cfg} differs bitwise from config 1"
+    # linear
+    M, K, N = 777, 640, 1280
+    xl = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
+    wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
+    outs = {}
+    for cfg in (1, 2, 3, 4, 5, 6, 7):
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        old = L.gyre_debug_force_gemm_cfg(cfg)
+        try:
+            _lib.check(L.gyre_op_linear(st(), vp(xl), M, K, vp(wl), N, None, None, 0, vp(y)))
+        finally:
+            L.gyre_debug_force_gemm_cfg(old)
+        outs[cfg] = y
+    for cfg, y in outs.items():
+        assert torch.equal(y, outs[1]), f"linear: config {cfg} differs bitwise from config 1"
+
+
+def test_groupnorm_statistics_do_not_depend_on_batch_size():
+    """The per-sample chunking of the two-pass statistics is a function of HW only."""
+    L = _lib.lib()
+    for HW, Cc in ((4096, 320), (1024, 640), (9216, 320), (65536, 128)):
+        B = 5
+        x = (torch.randn(B, HW, Cc, device=DEV) * 2 + 0.5).to(torch.bfloat16)
+        gam, bet = torch.randn(Cc, device=DEV), torch.randn(Cc, device=DEV)
+
+        def run(xs):
+            n = xs.shape[0]
+            y = torch.empty_like(xs)
+            wsb = L.gyre_op_groupnorm_workspace(n, HW, Cc, 32)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+            _lib.check(L.gyre_op_groupnorm(st(), vp(xs), None, 0, n, HW, Cc, 32, vp(gam), vp(bet), 1e-5, 1, vp(ws), wsb, vp(y)))
+            return y
+        full = run(x)
+        assert torch.equal(run(x[3:4].contiguous()), full[3:4])
+        assert torch.equal(run(x[1:4].contiguous()), full[1:4])

@@ -131,3 +131,32 @@ def test_vae_roundtrip_shapes_and_finiteness_768():
     assert torch.equal(swapped.flip(0), out1)
     one = vae.decode(z[1:2].contiguous()).sample          # different batch size: same up to summation order
     assert float((one - out1[1:2]).norm() / out1[1:2].norm()) < 1.5e-2
+
+
+def test_batch_invariant_mode_makes_any_split_bit_exact_full_size():
+    """gyre_set_batch_invariant(16): split-K factors are planned for the canonical batch, so the config-2 UNet call
+    (batch 16) and the VAE decode give bit-identical results for ANY split of the batch (SURVEY 8(d) sharding gate,
+    reference property tests/batch_independance.py:15-27 made exact)."""
+    from gyre_amd.modules import set_batch_invariant
+    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
+    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).to(DEV), 1)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
+    ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
+    t = torch.full((16,), 801, device=DEV)
+    z = torch.randn(4, 4, 64, 64, device=DEV, generator=g)
+    prev = set_batch_invariant(16)
+    try:
+        assert _lib.lib().gyre_get_batch_invariant() == 16
+        full = net(x, t, encoder_hidden_states=ctx).sample
+        for lo, hi in ((0, 8), (8, 16), (3, 5), (15, 16), (0, 1), (4, 8)):
+            part = net(x[lo:hi].contiguous(), t[lo:hi], encoder_hidden_states=ctx[lo:hi].contiguous()).sample
+            assert torch.equal(part, full[lo:hi]), (lo, hi)
+        img = vae.decode(z).sample
+        for lo, hi in ((0, 1), (1, 4), (2, 3)):
+            assert torch.equal(vae.decode(z[lo:hi].contiguous()).sample, img[lo:hi]), (lo, hi)
+        mom = vae.encode(img[:, :, :256, :256].contiguous()).latent_dist.parameters
+        assert torch.equal(vae.encode(img[2:3, :, :256, :256].contiguous()).latent_dist.parameters, mom[2:3])
+    finally:
+        set_batch_invariant(prev)
+    assert _lib.lib().gyre_get_batch_invariant() == prev

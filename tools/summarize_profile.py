@@ -2,7 +2,7 @@
 summaries under profiles/:
   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py --steps 1 --warmup 1`
   <tag>_pmc_summary.csv    per kernel: launches, mean FETCH_SIZE / WRITE_SIZE (KB as reported) from the two --pmc passes
-  traffic.json             HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes
+  traffic.json             HBM bytes per launch of every GEMM / attention kernel, corrected as MI355X_MICROARCH.md prescribes
                            (gfx950 FETCH_SIZE counts 128-B read requests as 64 B -> x2; WRITE_SIZE taken as reported)
 """
 import csv
@@ -60,12 +60,13 @@ with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
                 "mean_FETCH_SIZE_KB_raw", "mean_WRITE_SIZE_KB_raw", "hbm_bytes_per_launch_corrected(2*FETCH+WRITE)"])
     for r in rows:
         w.writerow([r[0], r[1], f"{r[2]:.2f}", f"{r[3]:.2f}", r[4], f"{r[5]:.1f}", f"{r[6]:.1f}", f"{r[7]:.0f}"])
-dom = next((r for r in rows if r[0].startswith("k_gemm") or r[0].startswith("k_attn")), None)
-if dom:
-    json.dump({"kernel": dom[0], "hbm_bytes_per_launch": dom[7], "mean_FETCH_SIZE_KB_raw": dom[5],
-               "mean_WRITE_SIZE_KB_raw": dom[6], "avg_launch_us": dom[2], "pct_of_gpu_time": dom[3],
-               "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests as 64 B), WRITE_SIZE as reported, x1024",
-               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), tools/profile_bench.sh {tag}"},
-              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+# traffic.json: every MFMA kernel instantiation, keyed by its rocprof name, so bench.py can look up whichever kernel
+# class is dominant in its own run (weighted over the instantiations that share the class prefix)
+kern = {r[0]: {"hbm_bytes_per_launch": r[7], "mean_FETCH_SIZE_KB_raw": r[5], "mean_WRITE_SIZE_KB_raw": r[6],
+               "launches_in_pmc_run": r[4], "avg_launch_us": r[2], "pct_of_gpu_time": r[3]}
+        for r in rows if r[0].startswith("k_gemm") or r[0].startswith("k_attn")}
+json.dump({"correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests as 64 B), WRITE_SIZE as reported, x1024",
+           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs), tools/profile_bench.sh {tag}",
+           "kernels": kern}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 for r in rows[:14]:
     print(f"{r[0][:60]:60s} calls={r[1]:6d} avg={r[2]:9.1f}us {r[3]:5.2f}%  fetchKB={r[5]:10.1f} writeKB={r[6]:10.1f} hbmMB/launch={r[7]/1e6:8.2f}")
