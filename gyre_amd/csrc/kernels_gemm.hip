@@ -1001,7 +1001,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
-    if (p.force_cfg) { cfg = p.force_cfg; splits = 1; }
+    if (p.force_cfg) { cfg = p.force_cfg & 0xff; splits = (p.force_cfg >> 8) & 0xff; if (splits < 1) splits = 1; }
     if (splits > 1) {
         if (!p.splitk_ws) { p.splitk_ws = g_dbg_ws; p.splitk_ws_bytes = g_dbg_ws_bytes; }
         if (!p.splitk_ws || p.splitk_ws_bytes < (size_t)splits * p.M * p.N * sizeof(float)) {
@@ -1020,9 +1020,9 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 1: return launch_cfg<128, 128, 2, 2>(st, p);
         case 2: return launch_cfg<256, 64, 4, 1>(st, p);
         case 3: return launch_cfg<64, 64, 2, 2>(st, p);
-        case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320, 1);
+        case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320, splits);
         case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
-        case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, 1);
+        case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         case 8: return launch_cfg8<128, 256, 2, 4, 3>(st, p, KC_G8_CONV_128x256, splits);  // experiment: 3-deep ring
         case 9: return launch_cfg4d<128, 320, 2, 2>(st, p, KC_G8_CONV_128x320, splits);     // 2 workgroups / CU

@@ -8,6 +8,7 @@ Host orchestration restating the reference's ``UnifiedPipeline.__call__``
   EnhancedInpaintMode         unified_pipeline.py:398-645 (per-step blend of original vs predicted latents)
   EnhancedRunwayInpaintMode   unified_pipeline.py:648-696 (9-channel UNet input assembly)
   (strength >= 1 "shaped noise" fill, unified_pipeline.py:466-601, is not implemented)
+  Hires fix (mode tree of a natural-size and a full-size leaf)   unified_pipeline.py:1064-1200, 2100-2181
 
 Call stack per SURVEY.md 3.2/3.3: embeddings -> UNetWithEmbeddings -> (UnetWithExtraChannels)
 -> CFGUNet_Parallel -> KDiffusionUNetWrapper -> sampler loop -> vae.decode(latents / 0.18215)
@@ -19,10 +20,13 @@ does not depend on which other images share its batch or GPU.
 """
 from __future__ import annotations
 
+import math
+from types import SimpleNamespace
 from typing import Callable, List, Optional, Sequence
 
 import torch
 
+from . import hires as H
 from . import schedulers as S
 
 Tensor = torch.Tensor
@@ -80,6 +84,11 @@ class GyrePipeline:
 
     vae_scale_factor = 8
     latent_scale = 0.18215
+    # hires-fix engine defaults (reference unified_pipeline.py:1368-1373)
+    hires_fix = True
+    hires_threshold_fraction = 0.0333
+    hires_oos_fraction = 0.6
+    hires_image_oos_fraction = 1.0
 
     def __init__(self, unet, vae, text_encoder: Optional[Callable] = None, device="cuda:0"):
         self.unet, self.vae, self.text_encoder = unet, vae, text_encoder
@@ -118,6 +127,60 @@ class GyrePipeline:
         t = t[:, [0]]
         return 1 - t if inputIs0K1D else t
 
+    # -- one mode-tree leaf ---------------------------------------------------------------------------
+    def _build_leaf(self, *, height, width, image, mask_image, generators, text_embeddings, uncond_embeddings,
+                    guidance_scale, cfg_execution, B):
+        """Everything one resolution needs: the CFG-wrapped epsilon UNet with its conditioning bound, the clean
+        init latents (img2img / inpaint) and the inpaint blend data.  reference: a ModeTreeLeaf
+        (unified_pipeline.py:1173-1200) + the mode built for it (Txt2img/Img2img/EnhancedInpaint/RunwayInpaint)."""
+        dev = self.device
+        runway = self.unet.config.in_channels == 9
+        leaf = SimpleNamespace(height=height, width=width, lat_h=height // self.vae_scale_factor,
+                               lat_w=width // self.vae_scale_factor, extra=None, init_latents=None,
+                               blend_orig=None, blend_mask=None, noise=None)
+        if image is not None:
+            img = self.preprocess_image(image.to(torch.float32))
+            if img.shape[-2:] != (height, width):
+                raise ValueError(f"image is {tuple(img.shape[-2:])}, expected {(height, width)}")
+            if mask_image is not None:
+                mask = self.preprocess_mask(mask_image.to(torch.float32)).to(dev)      # 1 keep / 0 replace
+                high_mask = round_mask(mask, 0.001)
+                orig = self.image_to_latents(img, generators, high_mask)
+                latent_mask = torch.cat([mask_to_latent_mask(mask)] * B)
+                if runway:
+                    inpaint_mask = 1 - round_mask(latent_mask, 0.001)[:, [0]]           # 0 keep / 1 replace
+                    leaf.extra = torch.cat([inpaint_mask, orig], dim=1)
+                leaf.init_latents = self.image_to_latents(img, generators)
+                if not runway:
+                    # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
+                    # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
+                    leaf.blend_orig, leaf.blend_mask = orig, latent_mask
+            else:
+                leaf.init_latents = self.image_to_latents(img, generators)
+
+        # UNet stack: embeddings -> extra channels -> CFG
+        def bind(emb):
+            u = S.UNetWithEmbeddings(self.unet, emb)
+            return S.UnetWithExtraChannels(u, leaf.extra) if leaf.extra is not None else u
+
+        if guidance_scale > 1.0:
+            if cfg_execution == "sequential":
+                leaf.eps_unet = S.CFGUNet_Sequential(bind(text_embeddings), bind(uncond_embeddings), guidance_scale, B)
+            else:
+                leaf.eps_unet = S.CFGUNet_Parallel(bind(torch.cat([uncond_embeddings, text_embeddings])), guidance_scale, B)
+        else:
+            leaf.eps_unet = bind(text_embeddings)
+        return leaf
+
+    def _leaf_initial_latents(self, leaf, sched, generators):
+        dev = self.device
+        if leaf.init_latents is None:
+            sample_size = getattr(self.unet.config, "sample_size", 64)
+            latents = txt2img_latents(generators, 4, leaf.lat_h, leaf.lat_w, sample_size, dev)
+            return sched.prepare_initial_latents(latents)
+        leaf.noise = S.batched_randn(leaf.init_latents.shape, generators, dev, torch.float32)
+        return sched.add_noise(leaf.init_latents, leaf.noise)
+
     # -- the generation call ------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, *, seeds: Sequence[int], text_embeddings: Optional[Tensor] = None,
@@ -126,7 +189,8 @@ class GyrePipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, sampler: str = "dpmpp_2m",
                  image: Optional[Tensor] = None, mask_image: Optional[Tensor] = None, strength: float = 0.8,
                  karras_rho: Optional[float] = None, eta: Optional[float] = None, cfg_execution: str = "parallel",
-                 output_type: str = "image", callback=None, generator_device: str = "cpu"):
+                 output_type: str = "image", callback=None, generator_device: str = "cpu",
+                 hires_fix: Optional[bool] = None, hires_oos_fraction: Optional[float] = None):
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
@@ -154,74 +218,74 @@ class GyrePipeline:
             if uncond_embeddings.shape[0] == 1 and B > 1:
                 uncond_embeddings = uncond_embeddings.expand(B, -1, -1)
 
-        in_ch = self.unet.config.in_channels
-        runway = in_ch == 9
-        if runway and (image is None or mask_image is None):
+        if self.unet.config.in_channels == 9 and (image is None or mask_image is None):
             raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
-        lat_ch = 4
-        lat_h, lat_w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        if image is not None and not 0 <= strength <= 1:
+            raise NotImplementedError("strength outside [0,1] (shaped-noise fill) is not on the native path yet")
 
         sched = S.make_scheduler(sampler, generators, dev, torch.float32)
-        extra = None
-        init_latents = None
-        blend_orig = blend_mask = None
-        if image is not None:
-            if not 0 <= strength <= 1:
-                raise NotImplementedError("strength outside [0,1] (shaped-noise fill) is not on the native path yet")
-            img = self.preprocess_image(image.to(torch.float32))
-            if img.shape[-2:] != (height, width):
-                raise ValueError(f"image is {tuple(img.shape[-2:])}, expected {(height, width)}")
-            if mask_image is not None:
-                mask = self.preprocess_mask(mask_image.to(torch.float32)).to(dev)      # 1 keep / 0 replace
-                high_mask = round_mask(mask, 0.001)
-                orig = self.image_to_latents(img, generators, high_mask)
-                latent_mask = torch.cat([mask_to_latent_mask(mask)] * B)
-                if runway:
-                    inpaint_mask = 1 - round_mask(latent_mask, 0.001)[:, [0]]           # 0 keep / 1 replace
-                    extra = torch.cat([inpaint_mask, orig], dim=1)
-                init_latents = self.image_to_latents(img, generators)
-                if not runway:
-                    # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
-                    # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
-                    blend_orig, blend_mask = orig, latent_mask
-            else:
-                init_latents = self.image_to_latents(img, generators)
+        is_k = isinstance(sched, S.KDiffusionScheduler)
 
-        # ---- UNet stack: embeddings -> extra channels -> CFG -> k-diffusion denoiser -------------------
-        def bind(emb):
-            u = S.UNetWithEmbeddings(self.unet, emb)
-            return S.UnetWithExtraChannels(u, extra) if extra is not None else u
+        # ---- mode tree: one leaf, or natural-size + full-size leaves under the hires fix -----------------
+        # engine defaults: unified_pipeline.py:1368-1373 (on, threshold 3.33 %, oos 0.6, 1.0 with an init image)
+        if hires_fix is None:
+            hires_fix = self.hires_fix
+        if hires_oos_fraction is None:
+            hires_oos_fraction = self.hires_image_oos_fraction if image is not None else self.hires_oos_fraction
+        sample_size = getattr(self.unet.config, "sample_size", 64)
+        natural_px = sample_size * self.vae_scale_factor
+        use_hires = False
+        if hires_fix and not (width < natural_px or height < natural_px):
+            threshold = math.floor(natural_px * (1 + self.hires_threshold_fraction))
+            use_hires = not (width <= threshold and height <= threshold)
+        if use_hires and not is_k:
+            raise ValueError("Can't use Diffuser schedulers with Hires fix. "
+                             "Either use a K-Diffusion scheduler or disable Hires fix.")
+        common = dict(generators=generators, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
+                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B)
+        leaves = []
+        if use_hires:
+            to_nat = lambda t: None if t is None else H.image_to_natural(natural_px, t if t.ndim == 4 else t[None],
+                                                                         hires_oos_fraction)
+            leaves.append(self._build_leaf(height=natural_px, width=natural_px, image=to_nat(image),
+                                           mask_image=to_nat(mask_image), **common))
+        leaves.append(self._build_leaf(height=height, width=width, image=image, mask_image=mask_image, **common))
 
-        if do_cfg:
-            if cfg_execution == "sequential":
-                eps_unet = S.CFGUNet_Sequential(bind(text_embeddings), bind(uncond_embeddings), guidance_scale, B)
-            else:
-                eps_unet = S.CFGUNet_Parallel(bind(torch.cat([uncond_embeddings, text_embeddings])), guidance_scale, B)
-        else:
-            eps_unet = bind(text_embeddings)
-        sched.set_eps_unet(eps_unet)
+        sched.set_eps_unets([l.eps_unet for l in leaves]) if is_k else sched.set_eps_unet(leaves[-1].eps_unet)
         sched.set_timesteps(num_inference_steps, strength=strength if image is not None else None,
                             config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho))
+        for leaf in leaves:
+            leaf.latents = self._leaf_initial_latents(leaf, sched, generators)
 
-        if init_latents is None:
-            sample_size = getattr(self.unet.config, "sample_size", 64)
-            latents = txt2img_latents(generators, lat_ch, lat_h, lat_w, sample_size, dev)
-            latents = sched.prepare_initial_latents(latents)
-        else:
-            noise = S.batched_randn(init_latents.shape, generators, dev, torch.float32)
-            latents = sched.add_noise(init_latents, noise)
+        def _blend(mask, u, orig, nxt):
+            it = mask.gt(u).to(nxt.dtype)
+            return orig * it + nxt * (1 - it)
 
-        wrap = {}
-        if blend_orig is not None:
-            def _blend(u, orig, nxt):
-                it = blend_mask.gt(u).to(nxt.dtype)
-                return orig * it + nxt * (1 - it)
-            if isinstance(sched, S.KDiffusionScheduler):
-                wrap["k_wrap"] = lambda px0, u: _blend(u, blend_orig.to(px0.dtype), px0)
+        if is_k:
+            def k_unet(i, leaf):
+                inner = sched.unets[i]
+                if leaf.blend_orig is None:
+                    return lambda x, sigma, u: inner(x, sigma)
+                return lambda x, sigma, u: _blend(leaf.blend_mask, u, leaf.blend_orig.to(x.dtype), inner(x, sigma))
+            ks = [k_unet(i, leaf) for i, leaf in enumerate(leaves)]
+            if use_hires:
+                model = H.HiresUnetWrapper(ks[0], ks[1], generators, [sample_size, sample_size], hires_oos_fraction)
+                latents = H.HiresUnetWrapper.merge_initial_latents(leaves[0].latents, leaves[1].latents)
             else:
-                wrap["d_wrap"] = lambda xt, t, u: _blend(u, sched.add_noise_at(blend_orig, noise, t).to(xt.dtype), xt)
-        latents = sched.loop(latents, callback=callback, **wrap)
-        self.last_unet_evals = sched.unet.evals
+                model, latents = ks[0], leaves[0].latents
+            plain = not use_hires and leaves[0].blend_orig is None
+            latents = sched.loop(latents, callback=callback, k_model=None if plain else model)
+            if use_hires:
+                latents = H.HiresUnetWrapper.split_result(None, latents)
+            self.last_unet_evals = sum(u.evals for u in sched.unets)
+        else:
+            leaf = leaves[0]
+            wrap = {}
+            if leaf.blend_orig is not None:
+                wrap["d_wrap"] = lambda xt, t, u: _blend(leaf.blend_mask, u,
+                                                         sched.add_noise_at(leaf.blend_orig, leaf.noise, t).to(xt.dtype), xt)
+            latents = sched.loop(leaf.latents, callback=callback, **wrap)
+            self.last_unet_evals = sched.unet.evals
         if output_type == "latent":
             return latents
         return self.vae_decode(latents)

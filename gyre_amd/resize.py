@@ -1,0 +1,68 @@
+"""Lanczos-2 resampling of latents / images by an arbitrary scale factor (host PyTorch).
+
+The reference resamples between the natural-size and the full-size latents of its hires fix with
+``resize_right.resize(x, scale_factors=s, interp_method=lanczos2, pad_mode="replicate", antialiasing=False)``
+(gyre/pipeline/unet/hires_fix.py:46-52).  ResizeRight is an un-vendored git submodule
+(.gitmodules:10-12, ``gyre/src/ResizeRight`` is empty in the reference tree), so this file restates the published
+algorithm (Shocher, "ResizeRight", 2021) - *parity unpinned*:
+
+  out_size            = ceil(in_size * scale)
+  projected grid      p_i = i / scale + (in_size - 1) / 2 - (out_size - 1) / (2 * scale)     (centres aligned)
+  field of view       left_i = ceil(p_i - support / 2 - eps), taps left_i .. left_i + support - 1   (support = 4)
+  weights             w_ij = lanczos2(p_i - j), normalised to sum 1 per output sample
+  boundary            taps outside the input are clamped to the edge sample (replicate padding)
+
+Without antialiasing the kernel is not stretched when downscaling (that is what the reference asks for).
+The separable resize is two small dense matrix products, which keeps it deterministic and batch independent.
+"""
+from __future__ import annotations
+
+import math
+from functools import lru_cache
+
+import torch
+
+_EPS = float(torch.finfo(torch.float32).eps)
+
+
+def lanczos2(x: torch.Tensor) -> torch.Tensor:
+    """sinc(x) sinc(x/2) on |x| < 2, written with the same eps guard as the published code so x = 0 gives 1."""
+    pix = math.pi * x
+    return ((torch.sin(pix) * torch.sin(pix / 2) + _EPS) / ((pix * pix / 2) + _EPS)) * (x.abs() < 2)
+
+
+@lru_cache(maxsize=64)
+def _weight_matrix(in_size: int, scale: float) -> torch.Tensor:
+    """[out_size, in_size] float64 resampling matrix (rows sum to 1)."""
+    out_size = int(math.ceil(in_size * scale))
+    support = 4
+    i = torch.arange(out_size, dtype=torch.float64)
+    proj = i / scale + (in_size - 1) / 2 - (out_size - 1) / (2 * scale)
+    left = torch.ceil(proj - support / 2 - _EPS).to(torch.int64)
+    taps = left[:, None] + torch.arange(support)[None, :]                      # [out, 4] input coordinates
+    w = lanczos2(proj[:, None] - taps.to(torch.float64))
+    s = w.sum(dim=1, keepdim=True)
+    s[s == 0] = 1
+    w = w / s
+    m = torch.zeros(out_size, in_size, dtype=torch.float64)
+    m.scatter_add_(1, taps.clamp(0, in_size - 1), w)                           # replicate padding = clamp
+    return m
+
+
+def resize_lanczos2(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """Resize the last two dims of x by ``scale`` (same factor both ways), lanczos2, replicate pad, no antialias."""
+    if scale <= 0:
+        raise ValueError("scale must be positive")
+    if scale == 1:
+        return x.clone()
+    h, w = x.shape[-2], x.shape[-1]
+    mh = _weight_matrix(h, float(scale)).to(x.device, torch.float32)
+    mw = _weight_matrix(w, float(scale)).to(x.device, torch.float32)
+    y = torch.matmul(mh, x.to(torch.float32))                                  # rows
+    y = torch.matmul(y, mw.t())                                                # columns
+    return y.to(x.dtype)
+
+
+def resize_nearest(x: torch.Tensor, scale: float) -> torch.Tensor:
+    hs, ws = int(x.shape[-2] * scale), int(x.shape[-1] * scale)
+    return torch.nn.functional.interpolate(x, size=(hs, ws), mode="nearest")

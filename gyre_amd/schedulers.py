@@ -335,20 +335,29 @@ class KDiffusionScheduler:
         self.generators, self.device, self.dtype = generators, device, dtype
         self.schedule = DiscreteSchedule()
         self.eps_unet = None
+        self.eps_unets = []
+        self.unets: List[KDiffusionUNetWrapper] = []
         self.unet: Optional[KDiffusionUNetWrapper] = None
         self.sigmas: Optional[Tensor] = None
         self.start_offset = 0
         self.eta = None
 
     def set_eps_unet(self, eps_unet):
-        self.eps_unet = eps_unet
+        self.set_eps_unets([eps_unet])
+
+    def set_eps_unets(self, eps_unets):
+        """One denoiser per mode-tree leaf (reference common_scheduler.py set_eps_unets, unified_pipeline.py:2436):
+        the hires fix runs a natural-size and a full-size leaf through the same schedule."""
+        self.eps_unets = list(eps_unets)
+        self.eps_unet = self.eps_unets[-1] if self.eps_unets else None
 
     def set_timesteps(self, num_inference_steps: int, start_offset: Optional[int] = None,
                       strength: Optional[float] = None, config: SchedulerConfig = SchedulerConfig()):
         if self.eps_unet is None:
             raise ValueError("Epsilon unet needs to be set before timesteps")
         s = self.schedule
-        self.unet = KDiffusionUNetWrapper(self.eps_unet, s)
+        self.unets = [KDiffusionUNetWrapper(e, s) for e in self.eps_unets]
+        self.unet = self.unets[-1]
         sigma_min, sigma_max = config.sigma_min, config.sigma_max
         if sigma_min is not None:
             sigma_min = max(float(s.sigma_min), sigma_min)
@@ -385,22 +394,27 @@ class KDiffusionScheduler:
         sigma = s.t_to_sigma(s.sigma_to_t(self.start_sigma))
         return latents + noise * float(sigma)
 
-    def loop(self, latents: Tensor, callback=None, k_wrap=None) -> Tensor:
+    def loop(self, latents: Tensor, callback=None, k_wrap=None, k_model=None) -> Tensor:
         """k_wrap(px0, u) -> px0 lets a mode post-process the denoised prediction with the progress value u in
-        [0, 0.999] (reference KDiffusionPositionTracker, common_scheduler.py:358-389, and Mode.wrap_k_unet)."""
+        [0, 0.999] (reference KDiffusionPositionTracker, common_scheduler.py:358-389, and Mode.wrap_k_unet).
+        k_model(x, sigma, u) -> px0 replaces the whole denoiser (collapsed mode tree: hires fix / graft over
+        self.unets)."""
         sigmas = self.sigmas[self.start_offset:]
         kwargs = dict(self.sampler_kwargs)
         if self.eta is not None:
             kwargs["eta"] = self.eta
         kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
         model = self.unet
-        if k_wrap is not None:
+        if k_wrap is not None or k_model is not None:
             u_off = self.start_offset / len(self.sigmas)
             state = {"i": 0, "i_max": len(sigmas) - 1}
 
             def tracked(x, sigma):
                 u = u_off + (1 - u_off) * state["i"] / state["i_max"]
-                return k_wrap(self.unet(x, sigma), max(min(u, 0.999), 0))
+                u = max(min(u, 0.999), 0)
+                if k_model is not None:
+                    return k_model(x, sigma, u)
+                return k_wrap(self.unet(x, sigma), u)
 
             model = tracked
             kwargs["step_cb"] = lambda i: state.__setitem__("i", i)

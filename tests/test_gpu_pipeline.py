@@ -102,3 +102,19 @@ def test_tiny_inpaint_modes_and_diffusers_samplers_on_gpu(tiny):
         p = PR.psnr(got, ref)
         print(f"[parity] tiny inpaint {sampler}: PSNR {p:.1f} dB")
         assert p >= 30.0
+
+
+def test_tiny_hires_fix_psnr(tiny):
+    """Hires fix (natural-size + full-size leaves, lanczos exchange): native UNet/VAE vs the same host flow on the
+    fp32 CPU oracle models.  The host flow itself is checked against oracle/hires_ref.py in tests/test_hires_host.py."""
+    from test_host_pipeline import OracleUNet, OracleVAE
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    kw = dict(seeds=[3, 4], text_embeddings=text[:2], uncond_embeddings=unc[:2], height=192, width=256,
+              num_inference_steps=6, sampler="euler_a")
+    img = pipe(**kw).cpu()
+    assert pipe.last_unet_evals == 10          # 6 full-size + 4 natural-size evaluations
+    cpu = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    ref = cpu(**kw)
+    p = PR.psnr(img, ref)
+    print(f"[parity] tiny hires-fix 192x256: PSNR {p:.1f} dB")
+    assert img.shape == (2, 3, 192, 256) and p >= 30.0
