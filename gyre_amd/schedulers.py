@@ -401,16 +401,21 @@ class KDiffusionScheduler:
         self.unets)."""
         sigmas = self.sigmas[self.start_offset:]
         kwargs = dict(self.sampler_kwargs)
+        by_range, wants_n = kwargs.pop("_range", False), kwargs.pop("_n", False)
         if self.eta is not None:
             kwargs["eta"] = self.eta
         kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
         model = self.unet
         if k_wrap is not None or k_model is not None:
             u_off = self.start_offset / len(self.sigmas)
-            state = {"i": 0, "i_max": len(sigmas) - 1}
+            state = {"i": None, "i_max": len(sigmas) - 1}
+            host_sigmas = sigmas.to("cpu", torch.float32)
 
             def tracked(x, sigma):
-                u = u_off + (1 - u_off) * state["i"] / state["i_max"]
+                i = state["i"]
+                if i is None:     # sampler without a fixed step range (dpm_fast / dpm_adaptive): place sigma in the
+                    i = int((host_sigmas >= float(sigma.reshape(-1)[0])).sum())      # schedule (common_scheduler.py:366-377)
+                u = u_off + (1 - u_off) * i / state["i_max"]
                 u = max(min(u, 0.999), 0)
                 if k_model is not None:
                     return k_model(x, sigma, u)
@@ -418,6 +423,11 @@ class KDiffusionScheduler:
 
             model = tracked
             kwargs["step_cb"] = lambda i: state.__setitem__("i", i)
+        if by_range:
+            if wants_n:
+                kwargs["n"] = self.num_inference_steps
+            pos = sigmas[sigmas > 0]
+            return self.sampler_fn(model, latents, pos.min(), sigmas.max(), callback=callback, **kwargs)
         return self.sampler_fn(model, latents, sigmas, callback=callback, **kwargs)
 
 
@@ -485,31 +495,244 @@ def sample_lms(model, x: Tensor, sigmas: Tensor, callback=None, order: int = 4, 
     return x
 
 
+@torch.no_grad()
+def sample_dpmpp_sde(model, x: Tensor, sigmas: Tensor, noise_sampler=None, callback=None, eta: float = 1.0,
+                     s_noise: float = 1.0, r: float = 0.5, step_cb=None, **_):
+    """DPM-Solver++ (stochastic), [3P k_diffusion.sampling.sample_dpmpp_sde] selected at reference samplers.py:56.
+    The reference's default noise source is its per-image batched_randn (common_scheduler.py:608-610); the Brownian
+    tree (torchsde) variant is not available."""
+    sigmas = sigmas.to("cpu", torch.float32)
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    for i in range(len(sigmas) - 1):
+        if step_cb is not None:
+            step_cb(i)
+        denoised = model(x, sigmas[i])
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        if sigmas[i + 1] == 0:
+            d = (x - denoised) / _f(sigmas[i])
+            x = x + d * _f(sigmas[i + 1] - sigmas[i])
+            continue
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        s = t + h * r
+        fac = 1 / (2 * r)
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+        s_ = t_fn(sd)
+        x_2 = _f(sigma_fn(s_) / sigma_fn(t)) * x - _f((t - s_).expm1()) * denoised
+        x_2 = x_2 + noise_sampler(sigma_fn(t), sigma_fn(s)) * (s_noise * _f(su))
+        denoised_2 = model(x_2, sigma_fn(s))
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+        t_next_ = t_fn(sd)
+        denoised_d = (1 - fac) * denoised + fac * denoised_2
+        x = _f(sigma_fn(t_next_) / sigma_fn(t)) * x - _f((t - t_next_).expm1()) * denoised_d
+        x = x + noise_sampler(sigma_fn(t), sigma_fn(t_next)) * (s_noise * _f(su))
+    return x
+
+
+class DPMSolver:
+    """DPM-Solver (Lu et al. 2022) in k-diffusion's sigma parameterisation t = -log sigma, with its single-step
+    orders 1-3, the fixed-budget schedule (dpm_fast) and the PID step-size controller (dpm_adaptive)
+    [3P k_diffusion.sampling.DPMSolver; selected at reference samplers.py:54-55].  t values are host fp32 scalars."""
+
+    def __init__(self, model, info_callback=None):
+        self.model, self.info_callback = model, info_callback
+
+    @staticmethod
+    def t(sigma: Tensor) -> Tensor:
+        return sigma.log().neg()
+
+    @staticmethod
+    def sigma(t: Tensor) -> Tensor:
+        return t.neg().exp()
+
+    def eps(self, cache: dict, key: str, x: Tensor, t: Tensor):
+        if key in cache:
+            return cache[key], cache
+        sig = self.sigma(t)
+        e = (x - self.model(x, sig)) / _f(sig)
+        return e, {key: e, **cache}
+
+    def step1(self, x, t, t_next, cache=None):
+        cache = {} if cache is None else cache
+        h = t_next - t
+        e, cache = self.eps(cache, "eps", x, t)
+        return x - _f(self.sigma(t_next) * h.expm1()) * e, cache
+
+    def step2(self, x, t, t_next, r1=1 / 2, cache=None):
+        cache = {} if cache is None else cache
+        h = t_next - t
+        e, cache = self.eps(cache, "eps", x, t)
+        s1 = t + r1 * h
+        u1 = x - _f(self.sigma(s1) * (r1 * h).expm1()) * e
+        e1, cache = self.eps(cache, "eps_r1", u1, s1)
+        x2 = x - _f(self.sigma(t_next) * h.expm1()) * e - _f(self.sigma(t_next) / (2 * r1) * h.expm1()) * (e1 - e)
+        return x2, cache
+
+    def step3(self, x, t, t_next, r1=1 / 3, r2=2 / 3, cache=None):
+        cache = {} if cache is None else cache
+        h = t_next - t
+        e, cache = self.eps(cache, "eps", x, t)
+        s1, s2 = t + r1 * h, t + r2 * h
+        u1 = x - _f(self.sigma(s1) * (r1 * h).expm1()) * e
+        e1, cache = self.eps(cache, "eps_r1", u1, s1)
+        u2 = x - _f(self.sigma(s2) * (r2 * h).expm1()) * e \
+            - _f(self.sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)) * (e1 - e)
+        e2, cache = self.eps(cache, "eps_r2", u2, s2)
+        x3 = x - _f(self.sigma(t_next) * h.expm1()) * e - _f(self.sigma(t_next) / r2 * (h.expm1() / h - 1)) * (e2 - e)
+        return x3, cache
+
+    def _ancestral(self, t, t_next, t_end, eta):
+        if not eta:
+            return t_next, 0.0
+        sd, _ = get_ancestral_step(self.sigma(t), self.sigma(t_next), eta)
+        t_ = torch.minimum(t_end, self.t(sd))
+        su = (self.sigma(t_next) ** 2 - self.sigma(t_) ** 2) ** 0.5
+        return t_, _f(su)
+
+    def fast(self, x, t_start, t_end, nfe: int, eta=0.0, s_noise=1.0, noise_sampler=None):
+        if not t_end > t_start and eta:
+            raise ValueError("eta must be 0 for reverse sampling")
+        m = nfe // 3 + 1
+        ts = torch.linspace(float(t_start), float(t_end), m + 1)
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        for i, order in enumerate(orders):
+            t, t_next = ts[i], ts[i + 1]
+            t_next_, su = self._ancestral(t, t_next, t_end, eta)
+            e, cache = self.eps({}, "eps", x, t)
+            if self.info_callback is not None:
+                self.info_callback({"x": x, "i": i, "t": t, "t_up": t, "denoised": x - _f(self.sigma(t)) * e})
+            x, _ = (self.step1, self.step2, self.step3)[order - 1](x, t, t_next_, cache=cache)
+            if su:
+                x = x + noise_sampler(self.sigma(t), self.sigma(t_next)) * (su * s_noise)
+        return x
+
+    def adaptive(self, x, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0.0, icoeff=1.0,
+                 dcoeff=0.0, accept_safety=0.81, eta=0.0, s_noise=1.0, noise_sampler=None):
+        import math
+        if order not in (2, 3):
+            raise ValueError("order should be 2 or 3")
+        forward = bool(t_end > t_start)
+        if not forward and eta:
+            raise ValueError("eta must be 0 for reverse sampling")
+        h = abs(h_init) * (1 if forward else -1)
+        ctl_order = 1.5 if eta else order
+        b1, b2, b3 = (pcoeff + icoeff + dcoeff) / ctl_order, -(pcoeff + 2 * dcoeff) / ctl_order, dcoeff / ctl_order
+        errs = []
+        s, x_prev = t_start, x
+        info = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+        while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+            t = torch.minimum(t_end, s + h) if forward else torch.maximum(t_end, s + h)
+            t_, su = self._ancestral(s, t, t_end, eta)
+            e, cache = self.eps({}, "eps", x, s)
+            if order == 2:
+                x_low, cache = self.step1(x, s, t_, cache=cache)
+                x_high, cache = self.step2(x, s, t_, cache=cache)
+            else:
+                x_low, cache = self.step2(x, s, t_, r1=1 / 3, cache=cache)
+                x_high, cache = self.step3(x, s, t_, cache=cache)
+            delta = torch.maximum(torch.tensor(atol, device=x.device, dtype=x.dtype),
+                                  rtol * torch.maximum(x_low.abs(), x_prev.abs()))
+            error = float(torch.linalg.norm((x_low - x_high) / delta)) / x.numel() ** 0.5
+            inv = 1 / (error + 1e-8)                                     # PID step-size controller
+            if not errs:
+                errs = [inv, inv, inv]
+            errs[0] = inv
+            factor = 1 + math.atan(errs[0] ** b1 * errs[1] ** b2 * errs[2] ** b3 - 1)
+            accept = factor >= accept_safety
+            if accept:
+                errs[2], errs[1] = errs[1], errs[0]
+                x_prev = x_low
+                x = x_high
+                if su:
+                    x = x + noise_sampler(self.sigma(s), self.sigma(t)) * (su * s_noise)
+                s = t
+                info["n_accept"] += 1
+            else:
+                info["n_reject"] += 1
+            h *= factor
+            info["nfe"] += order
+            info["steps"] += 1
+            if self.info_callback is not None:
+                self.info_callback({"x": x, "i": info["steps"] - 1, "t": s, "t_up": s, "error": error, "h": h, **info})
+        return x, info
+
+
+def _solver_callback(solver: "DPMSolver", callback):
+    if callback is None:
+        return None
+    return lambda info: callback({"sigma": solver.sigma(info["t"]), "sigma_hat": solver.sigma(info["t_up"]), **info})
+
+
+@torch.no_grad()
+def sample_dpm_fast(model, x: Tensor, sigma_min, sigma_max, n: int, callback=None, eta: float = 0.0,
+                    s_noise: float = 1.0, noise_sampler=None, **_):
+    """DPM-Solver-Fast: fixed budget of n model evaluations between sigma_max and sigma_min."""
+    sigma_min, sigma_max = torch.as_tensor(sigma_min, dtype=torch.float32).cpu(), torch.as_tensor(sigma_max, dtype=torch.float32).cpu()
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    solver = DPMSolver(model)
+    solver.info_callback = _solver_callback(solver, callback)
+    return solver.fast(x, solver.t(sigma_max), solver.t(sigma_min), n, eta, s_noise, noise_sampler)
+
+
+@torch.no_grad()
+def sample_dpm_adaptive(model, x: Tensor, sigma_min, sigma_max, callback=None, order: int = 3, rtol: float = 0.05,
+                        atol: float = 0.0078, h_init: float = 0.05, pcoeff: float = 0.0, icoeff: float = 1.0,
+                        dcoeff: float = 0.0, accept_safety: float = 0.81, eta: float = 0.0, s_noise: float = 1.0,
+                        noise_sampler=None, return_info: bool = False, **_):
+    """DPM-Solver-12 / -23 with adaptive step size (the number of model evaluations is data dependent; the error norm
+    is taken over the whole batch, so - as in the reference - this sampler is not batch independent)."""
+    sigma_min, sigma_max = torch.as_tensor(sigma_min, dtype=torch.float32).cpu(), torch.as_tensor(sigma_max, dtype=torch.float32).cpu()
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    solver = DPMSolver(model)
+    solver.info_callback = _solver_callback(solver, callback)
+    x, info = solver.adaptive(x, solver.t(sigma_max), solver.t(sigma_min), order, rtol, atol, h_init, pcoeff, icoeff,
+                              dcoeff, accept_safety, eta, s_noise, noise_sampler)
+    return (x, info) if return_info else x
+
+
 SAMPLERS.update({
     "dpm_2_a": (sample_dpm_2_ancestral, {}),
     "lms": (sample_lms, {}),
+    "dpmpp_sde": (sample_dpmpp_sde, {}),
+    # these two take (sigma_min, sigma_max[, n]) instead of a sigma schedule (common_scheduler.py:590-594)
+    "dpm_fast": (sample_dpm_fast, {"_range": True, "_n": True}),
+    "dpm_adaptive": (sample_dpm_adaptive, {"_range": True}),
 })
 
 
 # ------------------------------------------------------------------------------
-# diffusers-scheduler loop (reference common_scheduler.py:179-314: DDIM, PLMS = PNDM(skip_prk_steps=True)).
+# diffusers-scheduler loop (reference common_scheduler.py:179-314: DDIM, PLMS = PNDM(skip_prk_steps=True),
+# DPMSolverMultistep orders 1-3).
 # The step arithmetic is diffusers' [3P, ~=0.16.0, not vendored]; restated from the published algorithms with the
 # SD1.x scheduler_config.json values (scaled_linear betas, steps_offset=1, set_alpha_to_one=False, no clipping).
 # Coefficients are host fp32/64 scalars applied to the device latents (no per-step sync).
 # ------------------------------------------------------------------------------
+DIFFUSERS_SAMPLERS = ("ddim", "plms", "dpmsolverpp_1", "dpmsolverpp_2", "dpmsolverpp_3")
+
+
 class DiffusersLikeScheduler:
     init_noise_sigma = 1.0
 
     def __init__(self, kind: str, num_train_timesteps: int = 1000, steps_offset: int = 1):
-        if kind not in ("ddim", "plms"):
+        if kind not in DIFFUSERS_SAMPLERS:
             raise NotImplementedError(kind)
         self.kind, self.T, self.steps_offset = kind, num_train_timesteps, steps_offset
+        self.solver_order = int(kind[-1]) if kind.startswith("dpmsolverpp_") else 0
         self.alphas_cumprod = DiscreteSchedule(num_train_timesteps).alphas_cumprod.double()
         self.final_alpha_cumprod = self.alphas_cumprod[0]  # set_alpha_to_one = False
 
     def set_timesteps(self, n: int):
         import numpy as np
         self.n = n
+        if self.solver_order:
+            # DPMSolverMultistepScheduler (diffusers ~0.16): n+1 points over [0, T-1], first one dropped at the end
+            self.timesteps = np.linspace(0, self.T - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+            self.outputs, self.lower_order_nums = [], 0
+            return
         ratio = self.T // n
         base = (np.arange(0, n) * ratio).round().astype(np.int64) + self.steps_offset
         if self.kind == "ddim":
@@ -521,7 +744,60 @@ class DiffusersLikeScheduler:
     def _ac(self, t: int) -> float:
         return float(self.alphas_cumprod[t]) if t >= 0 else float(self.final_alpha_cumprod)
 
+    # -- DPM-Solver++ multistep (Lu et al. 2022; reference samplers.py:34-45 selects solver_order 1/2/3 with the
+    # diffusers defaults: algorithm "dpmsolver++", midpoint solver, lower_order_final) -------------------------
+    def _lambda_alpha_sigma(self, t: int):
+        import math
+        a = float(self.alphas_cumprod[t])
+        alpha, sigma = math.sqrt(a), math.sqrt(1 - a)
+        return math.log(alpha) - math.log(sigma), alpha, sigma
+
+    def _dpmsolver_step(self, eps: Tensor, t: int, sample: Tensor) -> Tensor:
+        import math
+        ts = [int(v) for v in self.timesteps]
+        idx = ts.index(int(t))
+        last = idx == len(ts) - 1
+        prev_t = 0 if last else ts[idx + 1]
+        small = len(ts) < 15
+        lower_final = last and small
+        lower_second = idx == len(ts) - 2 and small
+        lam_s0, alpha_s0, sigma_s0 = self._lambda_alpha_sigma(t)
+        x0 = (sample - sigma_s0 * eps) / alpha_s0                       # data prediction from the eps model
+        self.outputs = (self.outputs + [(int(t), x0)])[-max(self.solver_order, 1):]
+        lam_t, alpha_t, sigma_t = self._lambda_alpha_sigma(prev_t)
+        h = lam_t - lam_s0
+        em1 = math.expm1(-h)                                            # e^{-h} - 1
+        order = self.solver_order
+        if order == 1 or self.lower_order_nums < 1 or lower_final:
+            use = 1
+        elif order == 2 or self.lower_order_nums < 2 or lower_second:
+            use = 2
+        else:
+            use = 3
+        m0 = self.outputs[-1][1]
+        out = (sigma_t / sigma_s0) * sample - (alpha_t * em1) * m0
+        if use >= 2:
+            s1, m1 = self.outputs[-2]
+            lam_s1 = self._lambda_alpha_sigma(s1)[0]
+            r0 = (lam_s0 - lam_s1) / h
+            d1_0 = (m0 - m1) * (1.0 / r0)
+            if use == 2:
+                out = out - (0.5 * alpha_t * em1) * d1_0
+            else:
+                s2, m2 = self.outputs[-3]
+                lam_s2 = self._lambda_alpha_sigma(s2)[0]
+                r1 = (lam_s1 - lam_s2) / h
+                d1_1 = (m1 - m2) * (1.0 / r1)
+                d1 = d1_0 + (d1_0 - d1_1) * (r0 / (r0 + r1))
+                d2 = (d1_0 - d1_1) * (1.0 / (r0 + r1))
+                out = out + (alpha_t * (em1 / h + 1.0)) * d1 - (alpha_t * ((em1 + h) / (h * h) - 0.5)) * d2
+        if self.lower_order_nums < order:
+            self.lower_order_nums += 1
+        return out
+
     def step(self, eps: Tensor, t: int, sample: Tensor) -> Tensor:
+        if self.solver_order:
+            return self._dpmsolver_step(eps, t, sample)
         ratio = self.T // self.n
         if self.kind == "ddim":
             prev_t = t - ratio
@@ -606,7 +882,6 @@ class DiffusersScheduler:
         return x
 
 
-DIFFUSERS_SAMPLERS = ("ddim", "plms")
 
 
 def make_scheduler(sampler, generators, device, dtype=torch.float32):

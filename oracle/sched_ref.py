@@ -231,3 +231,51 @@ def round_mask(mask: Tensor, threshold: float = 0.5) -> Tensor:
     mask[mask >= threshold] = 1
     mask[mask < 1] = 0
     return mask
+
+
+# ------------------------------------------------------------------------------
+# DPM-Solver++ multistep, orders 1-3 (reference samplers.py:34-45 -> diffusers DPMSolverMultistepScheduler, [3P]
+# ~=0.16.0, not vendored: PARITY UNPINNED; restated from Lu et al. 2022, "DPM-Solver++", Alg. 2 and eq. (12)-(13)
+# in data-prediction form with the diffusers defaults: midpoint 2nd-order form, lower_order_final for < 15 steps,
+# timesteps = round(linspace(0, 999, n+1))[::-1][:-1], last step to t = 0).
+# Written on tensors of lambda / alpha / sigma so that it shares no code with the product's scalar version.
+# ------------------------------------------------------------------------------
+def dpmsolverpp_multistep_ref(eps_model, x: Tensor, n: int, order: int, alphas_cumprod: Optional[Tensor] = None,
+                              start: int = 0) -> Tensor:
+    import numpy as np
+    ac = (get_alphas_cumprod(get_betas()) if alphas_cumprod is None else alphas_cumprod).double()
+    alpha, sigma = ac.sqrt(), (1 - ac).sqrt()
+    lam = alpha.log() - sigma.log()
+    ts = [int(v) for v in np.linspace(0, len(ac) - 1, n + 1).round()[::-1][:-1]]
+    hist = []            # (timestep, x0 prediction), newest last
+    warm = 0
+    for i in range(start, len(ts)):
+        s0 = ts[i]
+        t = ts[i + 1] if i + 1 < len(ts) else 0
+        x0 = (x - sigma[s0] * eps_model(x, s0)) / alpha[s0]
+        hist.append((s0, x0))
+        h = lam[t] - lam[s0]
+        phi = torch.expm1(-h)
+        k = min(order, warm + 1)
+        if len(ts) < 15:
+            if i == len(ts) - 1:
+                k = 1
+            elif i == len(ts) - 2:
+                k = min(k, 2)
+        new = sigma[t] / sigma[s0] * x - alpha[t] * phi * x0
+        if k >= 2:
+            s1, m1 = hist[-2]
+            r0 = (lam[s0] - lam[s1]) / h
+            d10 = (x0 - m1) / r0
+            if k == 2:
+                new = new - 0.5 * alpha[t] * phi * d10
+            else:
+                s2, m2 = hist[-3]
+                r1 = (lam[s1] - lam[s2]) / h
+                d11 = (m1 - m2) / r1
+                d1 = d10 + r0 / (r0 + r1) * (d10 - d11)
+                d2 = (d10 - d11) / (r0 + r1)
+                new = new + alpha[t] * (phi / h + 1.0) * d1 - alpha[t] * ((phi + h) / h ** 2 - 0.5) * d2
+        x = new.to(x.dtype)
+        warm = min(warm + 1, order)
+    return x

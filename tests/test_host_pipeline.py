@@ -207,7 +207,7 @@ def test_pipeline_errors(tiny):
     with pytest.raises(ValueError):
         pipe(seeds=[], text_embeddings=text, uncond_embeddings=unc)
     with pytest.raises(NotImplementedError):
-        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, sampler="dpm_adaptive")
+        pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, sampler="unipc")
 
 
 def test_more_samplers_on_linear_toy_problem():
@@ -286,3 +286,106 @@ def test_enhanced_inpaint_blend_pins_protected_area(tiny):
             assert torch.allclose(out[lm], orig[lm], atol=1e-5)
         assert torch.isfinite(out).all()
         assert not torch.allclose(out[~lm], orig[~lm], atol=1e-2)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("n", [6, 20])
+def test_dpmsolverpp_multistep_matches_oracle(order, n):
+    """diffusers-path samplers dpmsolverpp_1/2/3 (reference samplers.py:34-45) vs the tensor restatement in the oracle,
+    with a non-trivial eps model; order 1 equals DDIM's x0-space update on the same timesteps."""
+    sched = PS.make_scheduler(f"dpmsolverpp_{order}", gens([1]), "cpu")
+    ac = sched.sched.alphas_cumprod
+
+    def eps_model(x, t):
+        return torch.tanh(x) * float((1 - ac[t]) ** 0.5) + 0.05 * x
+
+    sched.set_eps_unet(eps_model)
+    sched.set_timesteps(n)
+    ts = [int(v) for v in sched.sched.timesteps]
+    assert len(ts) == n and ts[0] == 999 and ts == sorted(ts, reverse=True)
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(3)).double()
+    out = sched.loop(sched.prepare_initial_latents(x))
+    ref = S.dpmsolverpp_multistep_ref(eps_model, x, n, order)
+    assert sched.unet.evals == n
+    assert torch.allclose(out, ref, rtol=1e-9, atol=1e-9)
+    assert bool(torch.isfinite(out).all())
+
+
+def test_dpmsolverpp_orders_converge_and_img2img_offset(tiny):
+    """Higher order = closer to a 200-step first-order solve on a smooth problem; strength sets the start offset."""
+    ac = PS.DiscreteSchedule().alphas_cumprod.double()
+    eps_model = lambda x, t: (x - 0.3 * float(ac[t]) ** 0.5) / float((1 - ac[t]) ** 0.5 + 0.5)
+    x = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(4)).double()
+    fine = S.dpmsolverpp_multistep_ref(eps_model, x, 400, 1)
+    errs = []
+    for order in (1, 2, 3):
+        sched = PS.make_scheduler(f"dpmsolverpp_{order}", gens([1]), "cpu")
+        sched.set_eps_unet(eps_model)
+        sched.set_timesteps(20)
+        errs.append(float((sched.loop(x.clone()) - fine).abs().max()))
+    assert errs[1] < errs[0] and errs[2] < errs[0]
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    out = pipe(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128,
+               num_inference_steps=10, sampler="dpmsolverpp_2", image=image, strength=0.5, output_type="latent")
+    assert pipe.last_unet_evals == 5 and out.shape == (1, 4, 16, 16) and bool(torch.isfinite(out).all())
+
+
+def _toy_exact(x0, s_from, s_to):
+    """Probability-flow ODE solution for the denoiser x / (1 + sigma^2) (data ~ N(0, 1))."""
+    return x0 * ((1 + s_to ** 2) / (1 + s_from ** 2)) ** 0.5
+
+
+def test_dpm_solver_family_converges_on_toy_problem():
+    """dpm_fast / dpm_adaptive / dpmpp_sde(eta=0) are consistent ODE solvers: they approach the analytic solution of
+    the toy problem; dpmpp_sde with eta=1 keeps the marginal variance 1 + sigma_min^2."""
+    toy = lambda x, s: x / (1 + float(s) ** 2)
+    sch = PS.DiscreteSchedule()
+    smin, smax = float(sch.sigma_min), float(sch.sigma_max)
+    x0 = torch.randn(4, 4, 16, 16, generator=torch.Generator().manual_seed(1)).double() * (1 + smax ** 2) ** 0.5
+    exact = _toy_exact(x0, smax, smin)
+    fast = PS.sample_dpm_fast(toy, x0, smin, smax, 30)
+    assert float((fast - exact).abs().max() / exact.abs().max()) < 2e-3
+    coarse = PS.sample_dpm_fast(toy, x0, smin, smax, 9)
+    assert float((coarse - exact).abs().max()) > float((fast - exact).abs().max())
+    calls = []
+    counting = lambda x, s: (calls.append(1), toy(x, s))[1]
+    PS.sample_dpm_fast(counting, x0, smin, smax, 20)
+    assert len(calls) == 20                                               # the budget is exact: orders 3*6 + 2
+    ada, info = PS.sample_dpm_adaptive(toy, x0, smin, smax, return_info=True)
+    assert float((ada - exact).abs().max() / exact.abs().max()) < 5e-2
+    assert info["n_accept"] >= 3 and info["nfe"] == 3 * info["steps"]
+    tight = PS.sample_dpm_adaptive(toy, x0, smin, smax, rtol=1e-3, atol=1e-4)
+    assert float((tight - exact).abs().max()) < 0.2 * float((ada - exact).abs().max())
+    with pytest.raises(ValueError):
+        PS.sample_dpm_fast(toy, x0, 0.0, smax, 10)
+    with pytest.raises(ValueError):
+        PS.sample_dpm_adaptive(toy, x0, smin, smax, order=4)
+    sigmas = torch.cat([sch.t_to_sigma(torch.linspace(999, 0, 40)), torch.zeros(1)])
+    det = PS.sample_dpmpp_sde(toy, x0, sigmas, noise_sampler=lambda a, b: torch.zeros_like(x0), eta=0.0)
+    assert float((det - _toy_exact(x0, smax, 0.0)).abs().max() / exact.abs().max()) < 2e-2
+    g = torch.Generator().manual_seed(7)
+    sto = PS.sample_dpmpp_sde(toy, x0, sigmas, noise_sampler=lambda a, b: torch.randn(x0.shape, generator=g).double())
+    assert 0.85 < float(sto.var()) < 1.15
+
+
+@pytest.mark.parametrize("sampler", ["dpm_fast", "dpm_adaptive", "dpmpp_sde"])
+def test_pipeline_runs_dpm_solver_family(tiny, sampler):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    kw = dict(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=6,
+              sampler=sampler, output_type="latent")
+    out = pipe(**kw)
+    assert out.shape == (2, 4, 16, 16) and bool(torch.isfinite(out).all())
+    assert torch.equal(out, pipe(**kw))
+    if sampler == "dpm_fast":
+        assert pipe.last_unet_evals == 6
+    if sampler == "dpmpp_sde":
+        assert pipe.last_unet_evals == 11      # 2 per step, 1 on the last (sigma -> 0)
+    # inpaint blend works without a fixed step range: progress comes from the sigma's place in the schedule
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0
+    inp = pipe(image=image, mask_image=mask, strength=1.0, **kw)
+    assert bool(torch.isfinite(inp).all())
