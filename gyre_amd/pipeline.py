@@ -7,7 +7,7 @@ Host orchestration restating the reference's ``UnifiedPipeline.__call__``
   Img2imgMode                 unified_pipeline.py:240-337
   EnhancedInpaintMode         unified_pipeline.py:398-645 (per-step blend of original vs predicted latents)
   EnhancedRunwayInpaintMode   unified_pipeline.py:648-696 (9-channel UNet input assembly)
-  (strength >= 1 "shaped noise" fill, unified_pipeline.py:466-601, is not implemented)
+  strength >= 1 "shaped noise" fill (noise_mode 5)    unified_pipeline.py:402-417, 466-607
   Hires fix (mode tree of a natural-size and a full-size leaf)   unified_pipeline.py:1064-1200, 2100-2181
 
 Call stack per SURVEY.md 3.2/3.3: embeddings -> UNetWithEmbeddings -> (UnetWithExtraChannels)
@@ -56,6 +56,29 @@ def round_mask(mask: Tensor, threshold: float = 0.5) -> Tensor:
     mask[mask >= threshold] = 1
     mask[mask < 1] = 0
     return mask
+
+
+def fill_with_shaped_noise(init_latents: Tensor, latent_mask: Tensor, generators, shaped_noise_strength: float) -> Tensor:
+    """EnhancedInpaintMode._fillWithShapedNoise, noise_mode 5 (unified_pipeline.py:466-601): the repaint area of the
+    clean init latents is filled, per image and channel, with pixels drawn at random from the protected area (numpy
+    Generator seeded from the image's torch generator), mixed with white noise by ``shaped_noise_strength``."""
+    import numpy as np
+    high = round_mask(latent_mask, 0.001)
+    good = high[0, 0].ge(0.5)                                 # first image's mask selects the donor pixels
+    if not bool(good.any()):
+        raise ValueError("shaped-noise fill needs at least one protected latent cell in the mask")
+    s = float(shaped_noise_strength)
+    rows = []
+    for g, lat in zip(generators, (init_latents * high).split(1)):
+        seed = torch.randint(low=0, high=torch.iinfo(torch.int32).max, size=[1], generator=g, device=g.device,
+                             dtype=torch.int32).cpu()
+        npgen = np.random.default_rng(seed.numpy())
+        chans = [torch.from_numpy(npgen.choice(ch[0, 0][good].cpu().numpy(), tuple(ch.shape))).to(lat.device, lat.dtype)
+                 for ch in lat.split(1, dim=1)]
+        white = torch.zeros(lat.shape, dtype=lat.dtype, device=g.device).normal_(generator=g).to(lat.device)
+        rows.append(white * (1 - s) + torch.cat(chans, dim=1) * s)
+    noise = torch.cat(rows, dim=0)
+    return init_latents * latent_mask + noise * (1 - latent_mask)
 
 
 def txt2img_latents(generators, channels: int, lat_h: int, lat_w: int, unet_sample_size: int, device,
@@ -129,7 +152,7 @@ class GyrePipeline:
 
     # -- one mode-tree leaf ---------------------------------------------------------------------------
     def _build_leaf(self, *, height, width, image, mask_image, generators, text_embeddings, uncond_embeddings,
-                    guidance_scale, cfg_execution, B):
+                    guidance_scale, cfg_execution, B, fill_strength=None):
         """Everything one resolution needs: the CFG-wrapped epsilon UNet with its conditioning bound, the clean
         init latents (img2img / inpaint) and the inpaint blend data.  reference: a ModeTreeLeaf
         (unified_pipeline.py:1173-1200) + the mode built for it (Txt2img/Img2img/EnhancedInpaint/RunwayInpaint)."""
@@ -151,6 +174,8 @@ class GyrePipeline:
                     inpaint_mask = 1 - round_mask(latent_mask, 0.001)[:, [0]]           # 0 keep / 1 replace
                     leaf.extra = torch.cat([inpaint_mask, orig], dim=1)
                 leaf.init_latents = self.image_to_latents(img, generators)
+                if fill_strength is not None:     # strength >= 1: re-seed the repaint area (unified_pipeline.py:603-607)
+                    leaf.init_latents = fill_with_shaped_noise(leaf.init_latents, latent_mask, generators, fill_strength)
                 if not runway:
                     # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
                     # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
@@ -220,8 +245,18 @@ class GyrePipeline:
 
         if self.unet.config.in_channels == 9 and (image is None or mask_image is None):
             raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
-        if image is not None and not 0 <= strength <= 1:
-            raise NotImplementedError("strength outside [0,1] (shaped-noise fill) is not on the native path yet")
+        fill_strength = None
+        if image is not None:
+            if mask_image is not None:
+                # inpaint modes accept strength in [0, 2]: from 1 up the repaint area is first refilled with shaped
+                # noise, and the share of white noise in that fill grows to 100 % at 2 (unified_pipeline.py:402-417)
+                if strength < 0 or strength > 2:
+                    raise ValueError(f"The value of strength should in [0.0, 2.0] but is {strength}")
+                if strength >= 1.0:
+                    fill_strength = min(2 - strength, 1)
+                strength = min(strength, 1)
+            elif strength < 0 or strength > 1:
+                raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
 
         sched = S.make_scheduler(sampler, generators, dev, torch.float32)
         is_k = isinstance(sched, S.KDiffusionScheduler)
@@ -242,7 +277,7 @@ class GyrePipeline:
             raise ValueError("Can't use Diffuser schedulers with Hires fix. "
                              "Either use a K-Diffusion scheduler or disable Hires fix.")
         common = dict(generators=generators, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
-                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B)
+                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, fill_strength=fill_strength)
         leaves = []
         if use_hires:
             to_nat = lambda t: None if t is None else H.image_to_natural(natural_px, t if t.ndim == 4 else t[None],

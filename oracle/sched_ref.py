@@ -279,3 +279,25 @@ def dpmsolverpp_multistep_ref(eps_model, x: Tensor, n: int, order: int, alphas_c
         x = new.to(x.dtype)
         warm = min(warm + 1, order)
     return x
+
+
+# ------------------------------------------------------------------------------
+# EnhancedInpaintMode._fillWithShapedNoise, noise_mode 5 (reference unified_pipeline.py:466-601; lmask_mode 3 = high
+# mask).  Pinned by tests/golden shaped_noise_* (generated from the reference itself).
+# ------------------------------------------------------------------------------
+def fill_with_shaped_noise_ref(init_latents: Tensor, latent_mask: Tensor, generators, shaped_noise_strength: float) -> Tensor:
+    import numpy as np
+    high = round_mask(latent_mask, 0.001)
+    masked = init_latents * high
+    donor = high[0, 0] >= 0.5
+    filled = torch.empty_like(init_latents)
+    for b, g in enumerate(generators):
+        npseed = torch.randint(low=0, high=torch.iinfo(torch.int32).max, size=[1], generator=g, dtype=torch.int32)
+        rng = np.random.default_rng(npseed.numpy())
+        shuffled = torch.empty_like(masked[b])
+        for c in range(masked.shape[1]):
+            pool = masked[b, c][donor].numpy()
+            shuffled[c] = torch.from_numpy(rng.choice(pool, (1, 1) + tuple(masked.shape[2:])))[0, 0]
+        white = torch.zeros_like(masked[b:b + 1]).normal_(generator=g)[0]
+        filled[b] = white * (1 - shaped_noise_strength) + shuffled * shaped_noise_strength
+    return init_latents * latent_mask + filled * (1 - latent_mask)

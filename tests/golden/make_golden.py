@@ -258,6 +258,24 @@ def main():
     out["mask_round_high"] = mp.round_mask_high(soft).numpy()
     out["mask_round_low"] = mp.round_mask_low(soft).numpy()
 
+    # (9) EnhancedInpaintMode._fillWithShapedNoise (strength >= 1: shuffle-fill of the repaint area) ------------
+    gsn = torch.Generator().manual_seed(21)
+    sn_lat = torch.randn(2, 4, 8, 8, generator=gsn)
+    sn_mask = torch.ones(1, 1, 64, 64)
+    sn_mask[:, :, 16:48, 24:64] = 0.0                       # 1K0D: zero = repaint
+    sn_mask[:, :, 8:16, 24:64] = 0.4                         # soft edge
+    for tag, sns in (("s1", 1.0), ("s07", 0.7)):
+        em = object.__new__(up.EnhancedInpaintMode)
+        em.generators = gens(seeds)
+        em.latents_dtype = torch.float32
+        em.shaped_noise_strength = sns
+        em.latent_mask = torch.cat([em.mask_to_latent_mask(sn_mask)] * 2)
+        em.latent_high_mask = em.round_mask_high(em.latent_mask)
+        em.latent_low_mask = em.round_mask_low(em.latent_mask)
+        out[f"shaped_noise_{tag}_out"] = em._fillWithShapedNoise(sn_lat.clone()).numpy()
+    out["shaped_noise_latents"] = sn_lat.numpy()
+    out["shaped_noise_mask"] = sn_mask.numpy()
+
     # (10) VaeApproximator ---------------------------------------------------------
     from gyre.pipeline.vae_approximator import VaeApproximator
     va = VaeApproximator(device="cpu", dtype=torch.float32)

@@ -389,3 +389,37 @@ def test_pipeline_runs_dpm_solver_family(tiny, sampler):
     mask[:, :, 32:96, 32:96] = 1.0
     inp = pipe(image=image, mask_image=mask, strength=1.0, **kw)
     assert bool(torch.isfinite(inp).all())
+
+
+def test_product_shaped_noise_fill_matches_reference(golden):
+    from gyre_amd.pipeline import fill_with_shaped_noise
+    lat = torch.from_numpy(golden["shaped_noise_latents"])
+    lm = torch.cat([mask_to_latent_mask(torch.from_numpy(golden["shaped_noise_mask"]))] * 2)
+    for tag, sns in (("s1", 1.0), ("s07", 0.7)):
+        out = fill_with_shaped_noise(lat.clone(), lm, gens(golden["rng_seeds"]), sns)
+        assert np.allclose(out.numpy(), golden[f"shaped_noise_{tag}_out"], rtol=0, atol=1e-6)
+    keep = lm == 1
+    assert torch.equal(out[keep], lat[keep])                                # protected cells untouched
+    with pytest.raises(ValueError, match="protected"):
+        fill_with_shaped_noise(lat, torch.zeros_like(lm), gens([1, 2]), 1.0)
+
+
+def test_pipeline_inpaint_strength_above_one(tiny):
+    """strength in [1, 2] for the mask modes: repaint area re-seeded, full schedule; outside [0, 2] is an error."""
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0
+    kw = dict(seeds=[5, 6], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=5,
+              sampler="euler", image=image, mask_image=mask, output_type="latent")
+    a = pipe(strength=1.0, **kw)
+    assert pipe.last_unet_evals == 5
+    b = pipe(strength=1.5, **kw)
+    c = pipe(strength=0.999, **kw)
+    assert all(bool(torch.isfinite(t).all()) for t in (a, b, c))
+    assert not torch.allclose(a, b) and not torch.allclose(a, c)
+    with pytest.raises(ValueError, match=r"\[0.0, 2.0\]"):
+        pipe(strength=2.5, **kw)
+    with pytest.raises(ValueError, match=r"\[0.0, 1.0\]"):
+        pipe(**{**kw, "mask_image": None, "strength": 1.5})

@@ -122,3 +122,13 @@ def test_euler_ancestral_matches_intree_witness():
         if st > 0:
             x = x + S.batched_randn([2, 4, 8, 8], g2) * up
     assert torch.allclose(a, x, atol=1e-5)
+
+
+def test_shaped_noise_fill_matches_reference(golden):
+    """EnhancedInpaintMode._fillWithShapedNoise (strength >= 1) - oracle vs the vectors produced by the reference."""
+    lat = torch.from_numpy(golden["shaped_noise_latents"])
+    lm = torch.cat([S.mask_to_latent_mask(torch.from_numpy(golden["shaped_noise_mask"]))] * 2)
+    for tag, sns in (("s1", 1.0), ("s07", 0.7)):
+        gs = [torch.Generator().manual_seed(int(s)) for s in golden["rng_seeds"]]
+        out = S.fill_with_shaped_noise_ref(lat.clone(), lm, gs, sns)
+        assert np.allclose(out.numpy(), golden[f"shaped_noise_{tag}_out"], rtol=0, atol=1e-6)
