@@ -27,6 +27,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 from . import hires as H
+from . import images as I
 from . import schedulers as S
 
 Tensor = torch.Tensor
@@ -215,7 +216,8 @@ class GyrePipeline:
                  image: Optional[Tensor] = None, mask_image: Optional[Tensor] = None, strength: float = 0.8,
                  karras_rho: Optional[float] = None, eta: Optional[float] = None, cfg_execution: str = "parallel",
                  output_type: str = "image", callback=None, generator_device: str = "cpu",
-                 hires_fix: Optional[bool] = None, hires_oos_fraction: Optional[float] = None):
+                 hires_fix: Optional[bool] = None, hires_oos_fraction: Optional[float] = None,
+                 outmask_image: Optional[Tensor] = None):
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
@@ -323,4 +325,9 @@ class GyrePipeline:
             self.last_unet_evals = sched.unet.evals
         if output_type == "latent":
             return latents
-        return self.vae_decode(latents)
+        result = self.vae_decode(latents)
+        if image is not None and outmask_image is not None:         # unified_pipeline.py:2493-2510
+            src = image if image.ndim == 4 else image[None]
+            om = outmask_image if outmask_image.ndim == 4 else outmask_image[None]
+            result = I.outmask_composite(result, src.to(result.device), om.to(result.device))
+        return result

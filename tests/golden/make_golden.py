@@ -276,6 +276,15 @@ def main():
     out["shaped_noise_latents"] = sn_lat.numpy()
     out["shaped_noise_mask"] = sn_mask.numpy()
 
+    # (9b) histogram matching of the outmask composite (gyre/match_histograms.py via images.match_histograms) -------
+    from gyre.match_histograms import match_histograms as ref_match
+    ghm = torch.Generator().manual_seed(33)
+    hm_img = (torch.rand(2, 12, 10, 3, generator=ghm) ** 2 * 255).round().to(torch.uint8).numpy()
+    hm_ref = (torch.rand(2, 12, 10, 3, generator=ghm) * 200 + 30).round().to(torch.uint8).numpy()
+    out["histmatch_image_u8"] = hm_img
+    out["histmatch_reference_u8"] = hm_ref
+    out["histmatch_out_u8"] = ref_match(hm_img, hm_ref, channel_axis=3)
+
     # (10) VaeApproximator ---------------------------------------------------------
     from gyre.pipeline.vae_approximator import VaeApproximator
     va = VaeApproximator(device="cpu", dtype=torch.float32)

@@ -423,3 +423,36 @@ def test_pipeline_inpaint_strength_above_one(tiny):
         pipe(strength=2.5, **kw)
     with pytest.raises(ValueError, match=r"\[0.0, 1.0\]"):
         pipe(**{**kw, "mask_image": None, "strength": 1.5})
+
+
+def test_histogram_match_matches_reference(golden):
+    from gyre_amd import images as I
+    img, ref = torch.from_numpy(golden["histmatch_image_u8"]), torch.from_numpy(golden["histmatch_reference_u8"])
+    assert np.array_equal(I.match_histograms_u8(img, ref).numpy(), golden["histmatch_out_u8"])
+    # float wrapper = same thing through the 8-bit round trip
+    f = lambda t: t.permute(0, 3, 1, 2).float() / 255
+    out = I.match_histograms(f(img), f(ref))
+    assert np.array_equal((out * 255).round().to(torch.uint8).permute(0, 2, 3, 1).numpy(), golden["histmatch_out_u8"])
+    with pytest.raises(ValueError):
+        I.match_histograms_u8(img, ref[..., :2])
+    # composite: outside the outmask the source is returned untouched
+    res, src = torch.rand(2, 3, 16, 16), torch.rand(1, 4, 16, 16)
+    om = torch.zeros(1, 3, 16, 16)
+    om[:, :, 4:12, 4:12] = 1
+    comp = I.outmask_composite(res, src, om)
+    assert torch.equal(comp[:, :, :4], src[:, :3, :4].expand(2, -1, -1, -1)) and comp.shape == res.shape
+    assert float((comp[:, :, 4:12, 4:12] - res[:, :, 4:12, 4:12]).abs().max()) < 0.5
+
+
+def test_pipeline_outmask_composite(tiny):
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0
+    out = pipe(seeds=[5], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128,
+               num_inference_steps=3, sampler="euler", image=image, mask_image=mask, strength=1.0,
+               outmask_image=mask.expand(-1, 3, -1, -1))
+    assert out.shape == (1, 3, 128, 128)
+    assert torch.equal(out[:, :, :32], image[:, :, :32])          # outside the outmask: source pixels exactly
+    assert not torch.equal(out[:, :, 32:96, 32:96], image[:, :, 32:96, 32:96])
