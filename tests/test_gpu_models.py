@@ -172,3 +172,25 @@ def test_context_cache_matches_uncached_and_tracks_changes():
     rc = L.gyre_unet_forward(C.c_void_p(h), None, C.c_void_p(x3.data_ptr()), 0, C.c_void_p(t3.data_ptr()), None, 0, 3, 16, 16, 77,
                              C.c_void_p((ws.data_ptr() + 255) & ~255), ws.numel() - 256, C.c_void_p(o3.data_ptr()), 0)
     assert rc == -1 and b"set_context" in L.gyre_last_error()
+
+
+def test_lora_merge_on_native_unet():
+    """LoRA folded into the weights (gyre_amd/lora.py): the native forward follows the merged weights (vs the fp32
+    oracle run on the same merged state dict), and removing the LoRA restores the original output bit-exactly."""
+    from gyre_amd import lora as LR
+    from test_lora_host import kohya_lora
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x, t = randn(2, 4, 16, 16, seed=1), torch.tensor([700, 30])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    run = lambda: net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+    base = run()
+    lora = {k: v * 3 for k, v in kohya_lora(net).items()}
+    assert LR.apply_lora(net, lora, "a", scale=1.0) == 4
+    merged_sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
+    with_lora = run()
+    ref = M.unet_forward(merged_sd, cfg, x, t, ctx)
+    report("tiny unet + LoRA", with_lora, ref, 3e-2)
+    assert float((with_lora - base).norm() / base.norm()) > 1e-2        # the LoRA really changed the function
+    LR.remove_lora_from_model(net)
+    assert torch.equal(run(), base)

@@ -1,0 +1,105 @@
+"""LoRA merge (gyre_amd/lora.py) against the reference's hook semantics (gyre/pipeline/lora.py:96-160:
+output + up(down(input)) * alpha/r * scale), restated here with plain torch ops, on a tiny UNet shell (CPU)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gyre_amd import config as gcfg, lora as LR, weights
+from gyre_amd.modules import GyreHipUNet
+
+
+def make_unet():
+    cfg = gcfg.tiny_unet()
+    net = GyreHipUNet(cfg)
+    net.load_state_dict(weights.synthetic_state_dict(weights.unet_param_shapes(cfg)))
+    return net
+
+
+def kohya_lora(net, r=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = dict(net.named_parameters())
+    out = {}
+    for name, alpha in (("down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q", 2.0),
+                        ("mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj", None),
+                        ("up_blocks.1.attentions.0.proj_in", 4.0),                 # 1x1 conv
+                        ("down_blocks.1.resnets.0.conv1", 1.0)):                   # 3x3 conv
+        w = sd[name + ".weight"]
+        k = "lora_unet_" + name.replace(".", "_")
+        if w.ndim == 2:
+            out[k + ".lora_down.weight"] = torch.randn(r, w.shape[1], generator=g) * 0.1
+            out[k + ".lora_up.weight"] = torch.randn(w.shape[0], r, generator=g) * 0.1
+        else:
+            out[k + ".lora_down.weight"] = torch.randn(r, w.shape[1], *w.shape[2:], generator=g) * 0.1
+            out[k + ".lora_up.weight"] = torch.randn(w.shape[0], r, 1, 1, generator=g) * 0.1
+        if alpha is not None:
+            out[k + ".alpha"] = torch.tensor(alpha)
+    out["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight"] = torch.zeros(r, 8)
+    out["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"] = torch.zeros(8, r)
+    return out
+
+
+def test_detect_lora_type():
+    assert LR.detect_lora_type({"a.lora_up.weight": 0, "a.lora_down.weight": 0, "a.alpha": 0}) == "kohya-ss"
+    assert LR.detect_lora_type({"x.processor.to_k_lora.up.weight": 0}) == "diffusers"
+    assert LR.detect_lora_type({"unet:0:up": 0}) == "cloneofsimo"
+    with pytest.raises(ValueError, match="Unknown LoRA"):
+        LR.detect_lora_type({"foo": 0})
+    with pytest.raises(ValueError, match="Lycoris"):
+        LR.detect_lora_type({"a.lora_up.weight": 0, "a.hada_w1_a": 0})
+
+
+def test_merge_equals_hook_semantics():
+    """x W'^T == x W^T + up(down(x)) * alpha/r * scale for linear, 1x1 conv and 3x3 conv."""
+    g = torch.Generator().manual_seed(1)
+    W, up, down = torch.randn(24, 16, generator=g), torch.randn(24, 4, generator=g), torch.randn(4, 16, generator=g)
+    x = torch.randn(5, 16, generator=g)
+    d = LR.lora_delta(up, down, torch.tensor(2.0))
+    assert torch.allclose(F.linear(x, W + 0.7 * d), F.linear(x, W) + F.linear(F.linear(x, down), up) * (2.0 / 4) * 0.7, atol=1e-5)
+    Wc, upc, downc = torch.randn(12, 8, 3, 3, generator=g), torch.randn(12, 4, 1, 1, generator=g), torch.randn(4, 8, 3, 3, generator=g)
+    xc = torch.randn(2, 8, 9, 9, generator=g)
+    dc = LR.lora_delta(upc, downc)
+    ref = F.conv2d(xc, Wc, padding=1) + F.conv2d(F.conv2d(xc, downc, padding=1), upc) * 1.3
+    assert torch.allclose(F.conv2d(xc, Wc + 1.3 * dc, padding=1), ref, atol=1e-4)
+    with pytest.raises(ValueError):
+        LR.lora_delta(torch.randn(12, 4, 3, 3), downc)
+
+
+def test_apply_scale_remove_roundtrip():
+    net = make_unet()
+    base = {k: v.clone() for k, v in net.state_dict().items()}
+    lora = kohya_lora(net)
+    net._dirty = False
+    n = LR.apply_lora(net, lora, "a", scale=0.8)
+    assert n == 4 and net._dirty                                    # native copy flagged for re-upload
+    name = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+    k = "lora_unet_" + name[:-7].replace(".", "_")
+    want = base[name] + 0.8 * (2.0 / 4) * lora[k + ".lora_up.weight"] @ lora[k + ".lora_down.weight"]
+    assert torch.allclose(net.state_dict()[name], want, atol=1e-6)
+    changed = [k for k, v in net.state_dict().items() if not torch.equal(v, base[k])]
+    assert len(changed) == 4
+    LR.set_lora_scale(net, "a", 0.0)
+    assert all(torch.equal(v, base[k]) for k, v in net.state_dict().items())
+    # two LoRAs stack additively; removal restores the original weights bit-exactly
+    LR.set_lora_scale(net, "a", 0.5)
+    LR.apply_lora(net, kohya_lora(net, seed=1), "b", scale=1.0)
+    LR.remove_lora_from_model(net)
+    assert all(torch.equal(v, base[k]) for k, v in net.state_dict().items())
+    assert not net._lora_state["base"]
+    with pytest.raises(KeyError):
+        LR.set_lora_scale(net, "zzz", 1.0)
+
+
+def test_diffusers_format_and_errors():
+    net = make_unet()
+    base = net.state_dict()["mid_block.attentions.0.transformer_blocks.0.attn2.to_out.0.weight"].clone()
+    p = "mid_block.attentions.0.transformer_blocks.0.attn2.processor"
+    c = base.shape[0]
+    lora = {f"{p}.to_out_lora.down.weight": torch.ones(2, c) * 0.01, f"{p}.to_out_lora.up.weight": torch.ones(c, 2),
+            f"{p}.to_k_lora.down.weight": torch.zeros(2, 64), f"{p}.to_k_lora.up.weight": torch.zeros(c, 2)}
+    assert LR.apply_lora(net, lora, 0) == 2
+    got = net.state_dict()["mid_block.attentions.0.transformer_blocks.0.attn2.to_out.0.weight"]
+    assert torch.allclose(got, base + 0.02, atol=1e-6)
+    with pytest.raises(RuntimeError, match="Couldn't find"):
+        LR.apply_lora(net, {"lora_unet_nope.lora_down.weight": torch.zeros(1, 1), "lora_unet_nope.lora_up.weight": torch.zeros(1, 1)}, 1)
+    with pytest.raises(NotImplementedError):
+        LR.apply_lora(net, {"unet:0:up": torch.zeros(1)}, 2)
