@@ -36,9 +36,10 @@ int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float*
                      bf16_t* y);
 
 // weight repack: OIHW (any dtype) -> [O][KH][KW][Ipad] bf16 ; linear [O][I] -> bf16 (optionally GEGLU-interleaved)
-int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out);
+int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out,
+                       float scale = 1.f);
 int launch_repack_linear(hipStream_t st, const void* w, int dtype, int O, int I, int geglu_interleave, bf16_t* out);
-int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int geglu_interleave, float* out);
+int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int geglu_interleave, float* out, float scale = 1.f);
 int launch_copy_probe(hipStream_t st, const void* src, void* dst, size_t bytes);
 
 // ---- MFMA GEMM / implicit-GEMM conv (kernels_gemm.hip) -------------------------
@@ -80,5 +81,6 @@ struct AttnParams {
     const bf16_t* vt; int ldvt; // [B][H*D][ldvt] (V transposed: token index contiguous)
     bf16_t* o; int ldo;         // [B][Nq][ldo]
     int B, H, Nq, Nk, D;
+    int k_prescaled = 0;        // K already carries log2(e)/sqrt(D) (folded into the to_k weights at repack time)
 };
 int launch_attention(hipStream_t st, const AttnParams& p);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
 #pragma unroll
         for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const float sc = rsqrtf((float)D) * 1.4426950408889634f;  // scale * log2(e)
+    const float sc = p.k_prescaled ? 1.0f : rsqrtf((float)D) * 1.4426950408889634f;  // scale * log2(e)
 
     for (int kv0 = 0; kv0 < p.Nk; kv0 += 64) {
         __syncthreads();  // everyone is done reading the previous tile
@@ -216,8 +216,12 @@ __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
 typedef __attribute__((address_space(3))) void lds_void_a;
 typedef __attribute__((address_space(1))) const void gbl_void_a;
 
-template <int D, int QI, int PD>
-__global__ __launch_bounds__(256) void k_attn2(AttnParams p, const bf16_t* zero) {
+// FOLD (needs AttnParams::k_prescaled): K carries log2(e)/sqrt(D), so the MFMA output is already the exp2 argument
+// up to the row offset - and that offset (the reference maximum of the row) is subtracted by the MFMA itself through its
+// C input.  p = exp2(S') then costs one v_exp per score and nothing else; rows are re-centred in a wave-uniform branch
+// on the first tile and whenever a score exceeds the reference maximum by 2^TAU (practically never afterwards).
+template <int D, int QI, int PD, bool FOLD>
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, const bf16_t* zero) {
     constexpr int NS = PD + 2;               // ring depth: PD tiles in flight + the one being computed + one spare,
                                              // so a refill never targets a stage a slower wave may still be reading
     constexpr int DP = (D + 31) / 32 * 32;
@@ -291,11 +295,15 @@ __global__ __launch_bounds__(256) void k_attn2(AttnParams p, const bf16_t* zero)
     float m_run[QI], l_run[QI];
 #pragma unroll
     for (int qi = 0; qi < QI; ++qi) {
-        m_run[qi] = -1e30f; l_run[qi] = 0.f;
+        m_run[qi] = FOLD ? 0.f : -1e30f; l_run[qi] = 0.f;
 #pragma unroll
         for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const float sc = rsqrtf((float)D) * 1.4426950408889634f;
+    const float sc = p.k_prescaled ? 1.0f : rsqrtf((float)D) * 1.4426950408889634f;
+    // FOLD: a row is re-centred only when a score exceeds its reference maximum by 2^TAU.  p <= 2^60, row sums
+    // <= 2^60 * Nk and the fp32 PV accumulators stay far inside the fp32 range; every row keeps a term >= 1 from
+    // the tile that set its reference, so nothing underflows either.
+    constexpr float TAU = 60.f;
 
     auto tile = [&](int t, int kv0, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -304,9 +312,11 @@ __global__ __launch_bounds__(256) void k_attn2(AttnParams p, const bf16_t* zero)
 
         f32x4_t s[QI][4];
 #pragma unroll
-        for (int qi = 0; qi < QI; ++qi)
+        for (int qi = 0; qi < QI; ++qi) {
+            const float c0 = FOLD ? -m_run[qi] : 0.f;     // FOLD: S' = S - m_ref straight out of the matrix core
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
+        }
 #pragma unroll
         for (int ki = 0; ki < 4; ++ki) {
 #pragma unroll
@@ -318,8 +328,65 @@ __global__ __launch_bounds__(256) void k_attn2(AttnParams p, const bf16_t* zero)
                     s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
             }
         }
+        if (FOLD) {
+            // p = exp2(S') with no per-score arithmetic in the common case.  The reference maximum of a row moves only
+            // on the first tile (to the true maximum) or when a score exceeds it by more than 2^TAU - a wave-uniform
+            // branch that is essentially never taken after the first tiles.
+            float mxs[QI];
+            bool upd = t == 0;
 #pragma unroll
-        for (int qi = 0; qi < QI; ++qi) {
+            for (int qi = 0; qi < QI; ++qi) {
+                float mx = -1e30f;
+#pragma unroll
+                for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (TAIL) {
+                            const int kvl = 32 * (ki >> 1) + 8 * fq + 4 * (ki & 1) + r;
+                            if (kv0 + kvl >= p.Nk) s[qi][ki][r] = -1e30f;
+                        }
+                        mx = fmaxf(mx, s[qi][ki][r]);
+                    }
+                mxs[qi] = mx;              // this lane's 16 keys only: enough for the overflow check (ballot below)
+                upd |= mx > TAU;
+            }
+            if (__any(upd)) {
+                const float lo = t == 0 ? -1e30f : 0.f;
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi) {
+                    float mx = mxs[qi];
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float delta = fmaxf(mx, lo);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    m_run[qi] += delta;
+                    l_run[qi] *= alpha;
+#pragma unroll
+                    for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[qi][ki][r] -= delta;
+#pragma unroll
+                    for (int di = 0; di < DO; ++di) {
+                        o[qi][di][0] *= alpha; o[qi][di][1] *= alpha; o[qi][di][2] *= alpha; o[qi][di][3] *= alpha;
+                    }
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) {
+                float ls = 0.f;
+#pragma unroll
+                for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(s[qi][ki][r]);
+                        s[qi][ki][r] = pv;
+                        ls += pv;
+                    }
+                l_run[qi] += ls;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < (FOLD ? 0 : QI); ++qi) {
             float mx = -1e30f;
 #pragma unroll
             for (int ki = 0; ki < 4; ++ki)
@@ -443,7 +510,7 @@ static const bf16_t* attn_zero_page() {
 static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1 (register staged), 2 = v2 QI=2, 4 = v2 QI=4
 extern "C" int gyre_debug_force_attn_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
-template <int D, int QI>
+template <int D, int QI, bool FOLD = false>
 static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     constexpr int DO = (D + 15) / 16;
     constexpr int RAW = 64 * D * 2 + DO * 16 * 128;
@@ -452,7 +519,7 @@ static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     const size_t lds = (size_t)(PD + 2) * STAGE;
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
-    auto kern = k_attn2<D, QI, PD>;
+    auto kern = k_attn2<D, QI, PD, FOLD>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -491,6 +558,16 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.ldvt < (p.Nk + 7) / 8 * 8) GYRE_FAIL(-1, "attention: ldvt must cover Nk rounded up to 8");
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
     const int var = g_attn_variant;
+    if (p.k_prescaled && var != 1 && var != 2 && var != 4) {
+        switch (p.D) {
+            case 16: return launch_attn2_t<16, 2, true>(st, p);
+            case 32: return launch_attn2_t<32, 2, true>(st, p);
+            case 40: return launch_attn2_t<40, 2, true>(st, p);
+            case 64: return launch_attn2_t<64, 2, true>(st, p);
+            case 160: return launch_attn2_t<160, 2, true>(st, p);
+            default: break;   // D = 80: the folded form spills 7 registers at 2 waves/SIMD and is no faster (measured)
+        }
+    }
     if (var != 1) {
         const bool q4 = var == 4;  // 64 query rows per wave: measured slower than 32 at every SD shape (register pressure)
         switch (p.D) {

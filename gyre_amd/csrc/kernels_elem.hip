@@ -440,7 +440,7 @@ int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float*
 // new row 32p+i = value row 16p+i, new row 32p+16+i = gate row F+16p+i  (F = O/2).
 // ------------------------------------------------------------------------------
 __global__ void k_repack_conv(const void* __restrict__ w, int dtype, int O, int I, int KH, int KW, int Ipad,
-                              bf16_t* __restrict__ out, size_t total) {
+                              bf16_t* __restrict__ out, size_t total, float scale) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int ci = (int)(idx % Ipad);
@@ -449,12 +449,13 @@ __global__ void k_repack_conv(const void* __restrict__ w, int dtype, int O, int 
     int ky = (int)(r % KH); r /= KH;
     int o = (int)r;
     float v = ci < I ? load_as_f32(w, dtype, (((size_t)o * I + ci) * KH + ky) * KW + kx) : 0.f;
-    out[idx] = f32_to_bf16(v);
+    out[idx] = f32_to_bf16(v * scale);   // scale applied in fp32 before the single bf16 rounding
 }
-int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out) {
+int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out,
+                       float scale) {
     size_t total = (size_t)O * KH * KW * Ipad;
     hipLaunchKernelGGL(k_repack_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dtype, O, I, KH, KW,
-                       Ipad, out, total);
+                       Ipad, out, total, scale);
     GYRE_LAUNCH_CHECK();
     return 0;
 }
@@ -479,14 +480,14 @@ int launch_repack_linear(hipStream_t st, const void* w, int dtype, int O, int I,
     GYRE_LAUNCH_CHECK();
     return 0;
 }
-__global__ void k_cast_f32(const void* __restrict__ w, int dtype, size_t n, int inter, float* __restrict__ out) {
+__global__ void k_cast_f32(const void* __restrict__ w, int dtype, size_t n, int inter, float* __restrict__ out, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     size_t s = inter ? (size_t)geglu_src_row((int)i, (int)(n / 2)) : i;
-    out[i] = load_as_f32(w, dtype, s);
+    out[i] = load_as_f32(w, dtype, s) * scale;
 }
-int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int inter, float* out) {
-    hipLaunchKernelGGL(k_cast_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, dtype, n, inter, out);
+int launch_cast_f32(hipStream_t st, const void* w, int dtype, size_t n, int inter, float* out, float scale) {
+    hipLaunchKernelGGL(k_cast_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, dtype, n, inter, out, scale);
     GYRE_LAUNCH_CHECK();
     return 0;
 }

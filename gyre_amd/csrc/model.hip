@@ -9,6 +9,7 @@
 // their diffusers state-dict keys (gyre/manager.py:1068-1112, gyre/ckpt_utils.py:259-285).
 #include "../../include/gyre_hip.h"
 #include "kernels.h"
+#include <cmath>
 
 #include <algorithm>
 #include <cstring>
@@ -124,6 +125,7 @@ struct Param {
     int kind = PK_VEC;
     int o_pad = 0, i_pad = 0;    // padded out / in channels of the repacked matrix
     void* dev = nullptr;         // destination (inside `owner` allocation)
+    float scale = 1.f;           // folded into the values in fp32 before the bf16 rounding (attention K scale)
     bool set = false;
 };
 
@@ -200,13 +202,13 @@ struct Store {
                 // [O][I] -> [O][i_pad] (reuse the conv repack with a 1x1 window for the padding case)
                 if (p.i_pad != I || p.kind == PK_MAT) {
                     if (p.kind == PK_MAT_GEGLU) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "geglu weight with padded K");
-                    TRY(launch_repack_conv(st, src, dtype, O, I, 1, 1, p.i_pad, (bf16_t*)p.dev));
+                    TRY(launch_repack_conv(st, src, dtype, O, I, 1, 1, p.i_pad, (bf16_t*)p.dev, p.scale));
                 } else {
                     TRY(launch_repack_linear(st, src, dtype, O, I, 1, (bf16_t*)p.dev));
                 }
                 break;
             }
-            case PK_VEC: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 0, (float*)p.dev)); break;
+            case PK_VEC: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 0, (float*)p.dev, p.scale)); break;
             case PK_VEC_GEGLU: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 1, (float*)p.dev)); break;
         }
         p.set = true;
@@ -232,6 +234,7 @@ struct ResW {
 struct AttnW {
     int c = 0, heads = 1, kv_dim = 0;
     bf16_t *wqk = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    int k_prescaled = 0;         // to_k weights carry the softmax scale (UNet attention; not the VAE block)
     float *bqk = nullptr, *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;
 };
 struct TBlockW {
@@ -398,7 +401,7 @@ struct Exec {
         if (!dry()) {
             AttnParams a;
             a.q = qp; a.ldq = ldq; a.k = kp; a.ldk = ldk; a.vt = vtp; a.ldvt = ldvt; a.o = ao.p; a.ldo = C;
-            a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
+            a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = w.k_prescaled;
             TRY(launch_attention(st, a));
         }
         free(q); free(k); free(vt);
@@ -478,14 +481,18 @@ static void reg_resnet(Store& s, const std::string& p, int cin, int cout, bool t
     if (cin != cout) w.scw = s.mat(p + ".conv_shortcut", cout, cin, true, true, &w.scb);
 }
 static void reg_attn(Store& s, const std::string& p, int c, int heads, int kv_dim, bool self, AttnW& w) {
-    w.c = c; w.heads = heads; w.kv_dim = kv_dim;
+    w.c = c; w.heads = heads; w.kv_dim = kv_dim; w.k_prescaled = 1;
+    // The softmax scale log2(e)/sqrt(head_dim) is folded into the K projection weights (fp32, before their one bf16
+    // rounding): S = q.k then arrives from the matrix core already in the exp2 domain (AttnParams::k_prescaled)
+    const float kscale = 1.4426950408889634f / sqrtf((float)(c / heads));
     if (self) {
         w.wqk = (bf16_t*)s.dmalloc((size_t)2 * c * c * 2, true);
         s.add(p + ".to_q.weight", {c, c}, PK_MAT, w.wqk, c, c);
-        s.add(p + ".to_k.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c);
+        s.add(p + ".to_k.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c)->scale = kscale;
     } else {
         w.wq = s.mat(p + ".to_q", c, c, false, false, nullptr);
         w.wk = s.mat(p + ".to_k", c, kv_dim, false, false, nullptr);
+        s.by_key[p + ".to_k.weight"]->scale = kscale;
     }
     w.wv = s.mat(p + ".to_v", c, kv_dim, false, false, nullptr);
     w.wo = s.mat(p + ".to_out.0", c, c, false, true, &w.bo);
@@ -1133,6 +1140,14 @@ int gyre_op_attention(void* st, const void* q, int ldq, const void* k, int ldk, 
     AttnParams a;
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vt = (const bf16_t*)vt; a.ldvt = ldvt;
     a.o = (bf16_t*)o; a.ldo = ldo; a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    return launch_attention((hipStream_t)st, a);
+}
+int gyre_op_attention_ex(void* st, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int B,
+                         int heads, int Nq, int Nk, int D, void* o, int ldo, int k_prescaled) {
+    if (!q || !k || !vt || !o) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    AttnParams a;
+    a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vt = (const bf16_t*)vt; a.ldvt = ldvt;
+    a.o = (bf16_t*)o; a.ldo = ldo; a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = k_prescaled ? 1 : 0;
     return launch_attention((hipStream_t)st, a);
 }
 int gyre_op_nchw_to_nhwc(void* st, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y) {

@@ -215,6 +215,10 @@ int gyre_op_repack_bias(void* stream, const float* b, int n, int geglu_interleav
 /* o[B,Nq,H*D] = softmax(q k^T * D^-1/2) v ; q[B,Nq,H*D] (ldq), k[B,Nk,H*D] (ldk), vt[B,H*D,ldvt] (V transposed) */
 int gyre_op_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                       int B, int heads, int Nq, int Nk, int D, void* o, int ldo);
+/* Same, k_prescaled != 0: k already holds k * log2(e)/sqrt(D) (the UNet folds that factor into its to_k weights in
+ * fp32 before their bf16 rounding), which lets the kernel take exp2 of the matrix-core output directly. */
+int gyre_op_attention_ex(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
+                         int B, int heads, int Nq, int Nk, int D, void* o, int ldo, int k_prescaled);
 int gyre_op_nchw_to_nhwc(void* stream, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y_bf16);
 /* Device-side memcpy-rate probe used by bench.py to calibrate the HBM roofline on the box. */
 int gyre_op_copy_probe(void* stream, const void* src, void* dst, size_t bytes);

@@ -428,3 +428,50 @@ def test_groupnorm_statistics_do_not_depend_on_batch_size():
         full = run(x)
         assert torch.equal(run(x[3:4].contiguous()), full[3:4])
         assert torch.equal(run(x[1:4].contiguous()), full[1:4])
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D", [(2, 8, 1024, 1024, 40), (1, 4, 300, 77, 40), (2, 2, 200, 333, 16), (1, 4, 130, 64, 32),
+                                             (1, 5, 256, 1000, 64), (2, 8, 256, 256, 80), (1, 8, 64, 154, 160), (1, 8, 100, 7, 40),
+                                             (1, 1, 70, 70, 512)])
+def test_attention_prescaled_k(B, heads, Nq, Nk, D):
+    """gyre_op_attention_ex(k_prescaled=1): K carries log2(e)/sqrt(D) (as the UNet's scaled to_k weights produce it,
+    one bf16 rounding of the fp32 product) -> folded-softmax kernel for D in {16,32,40,64,160}, plain kernels with
+    unit scale otherwise.  Reference: fp32 softmax attention on the unrounded K."""
+    L = _lib.lib()
+    C_ = heads * D
+    q = bf16_round(randn(B, Nq, C_, seed=70))
+    k32 = randn(B, Nk, C_, seed=71)
+    v = bf16_round(randn(B, Nk, C_, seed=72))
+    ref = attn_ref(q, k32, v, heads)
+    kpre = (k32 * (1.4426950408889634 / math.sqrt(D))).to(torch.bfloat16).to(DEV)
+    ldvt = (Nk + 7) // 8 * 8
+    vt = torch.zeros((B, C_, ldvt), dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
+    o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), ldvt, B, heads, Nq, Nk, D, vp(o), C_, 1))
+    report(f"attention prescaled B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, 6e-3)
+
+
+def test_attention_prescaled_peaked_and_drifting_max():
+    """Folded softmax stress: (a) one key far above the rest in a late tile (re-centre branch after tile 0),
+    (b) scores that keep growing tile after tile by less than the re-centre threshold (no re-centre: large p),
+    (c) all scores very negative relative to tile 0."""
+    L = _lib.lib()
+    B, heads, N, D = 1, 2, 640, 40
+    C_ = heads * D
+    c = 1.4426950408889634 / math.sqrt(D)
+    q = bf16_round(randn(B, N, C_, seed=73) * 3)
+    k32 = randn(B, N, C_, seed=74) * 3
+    k32[:, 500] = q[:, 7] * 4                                 # (a) huge logit for query 7 in tile 7
+    ramp = torch.linspace(0, 1, N).view(1, N, 1)
+    k32 = k32 + q.mean(dim=1, keepdim=True) * ramp * 6        # (b) drift along the key axis
+    k32[:, :64] = k32[:, :64] + 0.0
+    v = bf16_round(randn(B, N, C_, seed=75))
+    for name, kk in (("peaked+drift", k32), ("late keys tiny", torch.cat([k32[:, :64], k32[:, 64:] * 0.01], dim=1))):
+        ref = attn_ref(q, kk, v, heads)
+        kpre = (kk * c).to(torch.bfloat16).to(DEV)
+        vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
+        o = torch.empty(B, N, C_, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
+        assert bool(torch.isfinite(o).all())
+        report(f"attention prescaled {name}", o.float().cpu(), ref, 3e-2)
