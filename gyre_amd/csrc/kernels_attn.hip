@@ -246,8 +246,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
     const bf16_t* kb = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const bf16_t* vb = p.vt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldvt;
 
+    // FOLD with a padded head dim (D = 40: V^T rows 40..47 are padding): row D of the staged V^T tile is fetched from a
+    // page of ones, so PV row D accumulates sum_k p = the softmax denominator inside the matrix core - no VALU adds,
+    // and the denominator sees exactly the bf16-rounded p the numerator does.
+    constexpr bool ONES = FOLD && (D % 16 != 0);
     // ---- per-lane DMA descriptors: element offset at tile 0, key index used for the tail check ----------
     int off[NW], kq[NW];
+    bool one_row[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int g = (i * 4 + wave) * 64 + lane;
@@ -263,16 +268,18 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             const int kg = sl ^ (d & 7);
             off[i] = d * p.ldvt + kg * 8;
             kq[i] = d < D ? kg * 8 : (1 << 28);
+            one_row[i] = ONES && d == D;
         } else {
-            off[i] = 0; kq[i] = 1 << 28;
+            off[i] = 0; kq[i] = 1 << 28; one_row[i] = false;
         }
+        if (g < KG) one_row[i] = false;
     }
     auto issue = [&](int kv0, int st) {
         char* sbase = smem + st * STAGE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
-            const bf16_t* src = zero;
+            const bf16_t* src = (ONES && one_row[i]) ? zero + 128 : zero;
             if (kv0 + kq[i] < p.Nk) src = isk ? kb + (size_t)kv0 * p.ldk + off[i] : vb + kv0 + off[i];
             __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(sbase + i * 4096), 16, 0, 0);
         }
@@ -380,9 +387,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
                     for (int r = 0; r < 4; ++r) {
                         float pv = __builtin_amdgcn_exp2f(s[qi][ki][r]);
                         s[qi][ki][r] = pv;
-                        ls += pv;
+                        if (!ONES) ls += pv;
                     }
-                l_run[qi] += ls;
+                if (!ONES) l_run[qi] += ls;
             }
         }
 #pragma unroll
@@ -471,9 +478,14 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
 
 #pragma unroll
     for (int qi = 0; qi < QI; ++qi) {
-        float l = l_run[qi];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (ONES) {   // O^T row D (block D/16, local row D%16 -> lanes fq = (D%16)/4, register (D%16)%4) for query fr
+            l = __shfl(o[qi][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr);
+        } else {
+            l = l_run[qi];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + qi * 16 + fr;
         if (q >= p.Nq) continue;
@@ -500,8 +512,9 @@ static const bf16_t* attn_zero_page() {
     std::lock_guard<std::mutex> g(mu);
     auto it = pages.find(dev);
     if (it != pages.end()) return (const bf16_t*)it->second;
-    void* p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    void* p = nullptr;   // 256 B of zeros followed by 256 B of bf16 ones (0x3f80)
+    if (hipMalloc(&p, 512) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    if (hipMemsetD16((hipDeviceptr_t)((char*)p + 256), 0x3f80, 128) != hipSuccess) return nullptr;
     (void)hipDeviceSynchronize();
     pages[dev] = p;
     return (const bf16_t*)p;

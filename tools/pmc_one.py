@@ -25,6 +25,7 @@ elif kind == "attn":
     Cc = h * D
     q, k, vt = rnd(B, Nq, Cc), rnd(B, Nk, Cc), rnd(B, Cc, Nk)
     o = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=DEV)
+    pre = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     for _ in range(5):
-        L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(vt), Nk, B, h, Nq, Nk, D, vp(o), Cc)
+        L.gyre_op_attention_ex(st(), vp(q), Cc, vp(k), Cc, vp(vt), Nk, B, h, Nq, Nk, D, vp(o), Cc, pre)
 torch.cuda.synchronize()
