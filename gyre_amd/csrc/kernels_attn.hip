@@ -502,6 +502,294 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v3 (prescaled K, D <= 64): the folded-softmax kernel, software-pipelined inside each wave.  One step of the loop
+// holds two score tiles in registers:
+//     A  p = exp2(S'_t), pack to bf16                       (VALU / transcendental)
+//     B  S'_{t+1} = K_{t+1} Q^T - m_ref                     (MFMA, independent of A -> overlaps it)
+//     C  O^T += V^T_t P^T_t                                 (MFMA, needs A)
+//     D  overflow check of S'_{t+1} (+ rare re-centre)      (VALU, overlaps C)
+// so the matrix core works on the next tile's scores while the vector unit exponentiates the current one, instead
+// of the two phases alternating.  Same LDS-DMA ring as v2; tile t+1 is waited for (counted vmcnt + one barrier) at
+// the top of step t and the slot of tile t-1 is refilled right after that barrier.  Loads past the last tile are
+// issued against the zero page so that the in-flight count stays constant (drained before the wave ends).
+// ------------------------------------------------------------------------------------------------
+template <int D, int PD>
+__global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* zero) {
+    constexpr int QI = 2;
+    constexpr int NS = PD + 2;
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = DP / 32;
+    constexpr int DO = (D + 15) / 16;
+    constexpr int KVEC = D / 8;
+    constexpr int VR = DO * 16;
+    constexpr int KBYTES = 64 * D * 2;
+    constexpr int RAW = KBYTES + VR * 128;
+    constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
+    constexpr int NW = STAGE / 4096;
+    constexpr int KG = 64 * KVEC, VG = VR * 8;
+    constexpr bool ONES = (D % 16 != 0);
+    constexpr float TAU = 60.f;
+    static_assert(KG % 64 == 0, "K granules fill whole wave instructions");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * (64 * QI) + wave * (16 * QI);
+    const bf16_t* qb = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* kb = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* vb = p.vt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldvt;
+
+    int off[NW], kq[NW];
+    bool one_row[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int g = (i * 4 + wave) * 64 + lane;
+        one_row[i] = false;
+        if (g < KG) {
+            const int rho = g / KVEC, vec = g - rho * KVEC;
+            const int ki = rho >> 4, ii = rho & 15;
+            const int key = 32 * (ki >> 1) + 8 * (ii >> 2) + 4 * (ki & 1) + (ii & 3);
+            off[i] = key * p.ldk + vec * 8;
+            kq[i] = key;
+        } else if (g - KG < VG) {
+            const int gv = g - KG, d = gv >> 3, sl = gv & 7;
+            const int kg = sl ^ (d & 7);
+            off[i] = d * p.ldvt + kg * 8;
+            kq[i] = d < D ? kg * 8 : (1 << 28);
+            one_row[i] = ONES && d == D;
+        } else {
+            off[i] = 0; kq[i] = 1 << 28;
+        }
+    }
+    auto issue = [&](int kv0, int st) {
+        char* sbase = smem + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
+            const bf16_t* src = (ONES && one_row[i]) ? zero + 128 : zero;
+            if (kv0 + kq[i] < p.Nk) src = isk ? kb + (size_t)kv0 * p.ldk + off[i] : vb + kv0 + off[i];
+            __builtin_amdgcn_global_load_lds((gbl_void_a*)src, (lds_void_a*)(sbase + i * 4096), 16, 0, 0);
+        }
+    };
+
+    bf16x8_t qf[QI][KS];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        const int q = q0 + qi * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = ks * 32 + fq * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.Nq && d < D) v = *(const uint4*)(qb + (size_t)q * p.ldq + d);
+            qf[qi][ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    f32x4_t o[QI][DO];
+    float m_ref[QI], l_run[QI];
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        m_ref[qi] = 0.f; l_run[qi] = 0.f;
+#pragma unroll
+        for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // B: scores of tile t (relative to the rows' reference maxima), keys past Nk masked when TAIL
+    auto qk = [&](int t, f32x4_t (&s)[QI][4], auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const char* k_lds = smem + (t % NS) * STAGE;
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            const float c0 = -m_ref[qi];
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
+        }
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8_t kf = __builtin_bit_cast(
+                    bf16x8_t, *(const uint4*)(k_lds + (ki * 16 + fr) * (D * 2) + (ks * 4 + fq) * 16));
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
+            }
+        }
+        if (TAIL) {
+            const int kv0 = t * 64;
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+                for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kvl = 32 * (ki >> 1) + 8 * fq + 4 * (ki & 1) + r;
+                        if (kv0 + kvl >= p.Nk) s[qi][ki][r] = -1e30f;
+                    }
+        }
+    };
+    // D: overflow check; re-centre the rows (wave-uniform branch: first tile, or a score above 2^TAU)
+    auto check = [&](bool first, f32x4_t (&s)[QI][4]) {
+        float mxs[QI];
+        bool upd = first;
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qi][ki][r]);
+            mxs[qi] = mx;
+            upd |= mx > TAU;
+        }
+        if (__any(upd)) {
+            const float lo = first ? -1e30f : 0.f;
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) {
+                float mx = mxs[qi];
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float delta = fmaxf(mx, lo);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref[qi] += delta;
+                l_run[qi] *= alpha;
+#pragma unroll
+                for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qi][ki][r] -= delta;
+#pragma unroll
+                for (int di = 0; di < DO; ++di) {
+                    o[qi][di][0] *= alpha; o[qi][di][1] *= alpha; o[qi][di][2] *= alpha; o[qi][di][3] *= alpha;
+                }
+            }
+        }
+    };
+    // A: p = exp2(S') in place, packed to the bf16 MFMA operand
+    auto softmax_pack = [&](f32x4_t (&s)[QI][4], bf16x8_t (&pf)[2][QI]) {
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            float ls = 0.f;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(s[qi][ki][r]);
+                    s[qi][ki][r] = pv;
+                    if (!ONES) ls += pv;
+                }
+            if (!ONES) l_run[qi] += ls;
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi) {
+                uint4 w;
+                w.x = pack_bf16x2(s[qi][2 * ks2][0], s[qi][2 * ks2][1]);
+                w.y = pack_bf16x2(s[qi][2 * ks2][2], s[qi][2 * ks2][3]);
+                w.z = pack_bf16x2(s[qi][2 * ks2 + 1][0], s[qi][2 * ks2 + 1][1]);
+                w.w = pack_bf16x2(s[qi][2 * ks2 + 1][2], s[qi][2 * ks2 + 1][3]);
+                pf[ks2][qi] = __builtin_bit_cast(bf16x8_t, w);
+            }
+    };
+    // C: O^T += V^T P^T for tile t
+    auto pv = [&](int t, bf16x8_t (&pf)[2][QI], auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const char* v_lds = smem + (t % NS) * STAGE + KBYTES;
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+            for (int di = 0; di < DO; ++di) {
+                const int d = di * 16 + fr;
+                uint4 vraw = *(const uint4*)(v_lds + d * 128 + (((ks2 * 4 + fq) ^ (d & 7)) * 16));
+                if (TAIL) {
+                    const int nvalid = p.Nk - (kv0 + ks2 * 32 + fq * 8);
+                    uint32_t w[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (2 * e >= nvalid) w[e] = 0;
+                        else if (2 * e + 1 >= nvalid) w[e] &= 0xffffu;
+                    }
+                    vraw = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vraw);
+#pragma unroll
+                for (int qi = 0; qi < QI; ++qi)
+                    o[qi][di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks2][qi], o[qi][di], 0, 0, 0);
+            }
+        }
+    };
+    // one pipeline step: cur = scores of tile t (checked), next receives tile t+1
+    auto step = [&](int t, f32x4_t (&cur)[QI][4], f32x4_t (&next)[QI][4], auto has_next, auto tail_next, auto tail_cur) {
+        constexpr bool HASNEXT = decltype(has_next)::value;
+        if (HASNEXT) {
+            // tile t+1 landed (tiles t+2 .. t+PD may still be in flight), every wave is done with tile t-1
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue((t + 1 + PD) * 64, (t + 1 + PD) % NS);
+        }
+        bf16x8_t pf[2][QI];
+        softmax_pack(cur, pf);
+        if (HASNEXT) qk(t + 1, next, tail_next);
+        pv(t, pf, tail_cur);
+        if (HASNEXT) check(false, next);
+    };
+
+    const int nt = (p.Nk + 63) / 64;
+#pragma unroll
+    for (int t0 = 0; t0 <= PD; ++t0) issue(t0 * 64, t0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4_t sa[QI][4], sb[QI][4];
+    if (nt == 1) qk(0, sa, std::true_type{}); else qk(0, sa, std::false_type{});
+    check(true, sa);
+
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    const int n_main = nt >= 2 ? nt - 2 : 0;
+    int t = 0;
+    for (; t + 1 < n_main; t += 2) {
+        step(t, sa, sb, T, F, F);
+        step(t + 1, sb, sa, T, F, F);
+    }
+    bool flip = false;
+    if (t < n_main) { step(t, sa, sb, T, F, F); ++t; flip = true; }
+    if (nt >= 2) {
+        if (!flip) step(t, sa, sb, T, T, F); else step(t, sb, sa, T, T, F);
+        ++t; flip = !flip;
+    }
+    if (!flip) step(t, sa, sb, F, F, T); else step(t, sb, sa, F, F, T);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end zero-page DMAs before the wave exits
+
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        float l;
+        if (ONES) {
+            l = __shfl(o[qi][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr);
+        } else {
+            l = l_run[qi];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + qi * 16 + fr;
+        if (q >= p.Nq) continue;
+        bf16_t* orow = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#pragma unroll
+        for (int di = 0; di < DO; ++di) {
+            const int d = di * 16 + 4 * fq;
+            if (d < D) {
+                uint2 pk = make_uint2(pack_bf16x2(o[qi][di][0] * inv, o[qi][di][1] * inv),
+                                      pack_bf16x2(o[qi][di][2] * inv, o[qi][di][3] * inv));
+                *(uint2*)(orow + d) = pk;
+            }
+        }
+    }
+}
+
 #include <mutex>
 #include <unordered_map>
 static const bf16_t* attn_zero_page() {
@@ -546,6 +834,29 @@ static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     return 0;
 }
 
+template <int D>
+static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
+    constexpr int DO = (D + 15) / 16;
+    constexpr int RAW = 64 * D * 2 + DO * 16 * 128;
+    constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
+    constexpr int PD = 2;
+    const size_t lds = (size_t)(PD + 2) * STAGE;
+    const bf16_t* zero = attn_zero_page();
+    if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
+    auto kern = k_attn3<D, PD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+    GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
+                        2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int D, int QI>
 static int launch_attn_t(hipStream_t st, const AttnParams& p) {
     constexpr int DP = (D + 31) / 32 * 32;
@@ -571,6 +882,17 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.ldvt < (p.Nk + 7) / 8 * 8) GYRE_FAIL(-1, "attention: ldvt must cover Nk rounded up to 8");
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
     const int var = g_attn_variant;
+    // software-pipelined folded kernel; with only a couple of key tiles (cross-attention, Nk = 77) its longer prologue
+    // costs more than the overlap wins (measured 47.8 vs 41.1 us), so short key sequences stay on the v2 form
+    if (p.k_prescaled && ((var == 0 && p.Nk >= 256) || var == 5)) {
+        switch (p.D) {
+            case 16: return launch_attn3_t<16>(st, p);
+            case 32: return launch_attn3_t<32>(st, p);
+            case 40: return launch_attn3_t<40>(st, p);
+            case 64: return launch_attn3_t<64>(st, p);
+            default: break;
+        }
+    }
     if (p.k_prescaled && var != 1 && var != 2 && var != 4) {
         switch (p.D) {
             case 16: return launch_attn2_t<16, 2, true>(st, p);

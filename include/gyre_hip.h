@@ -172,7 +172,8 @@ int gyre_debug_force_gemm_cfg(int cfg);
  * the caller's workspace).  Without it the single operators run the best single-split configuration. */
 int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
- * query rows per wave.  Returns the previous value. */
+ * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
+ * 16/32/40/64).  Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
 /* Tuning only: bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs (results are garbage). */
 int gyre_debug_gemm_ablation(int bits);

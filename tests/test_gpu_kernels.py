@@ -433,7 +433,8 @@ def test_groupnorm_statistics_do_not_depend_on_batch_size():
 @pytest.mark.parametrize("B,heads,Nq,Nk,D", [(2, 8, 1024, 1024, 40), (1, 4, 300, 77, 40), (2, 2, 200, 333, 16), (1, 4, 130, 64, 32),
                                              (1, 5, 256, 1000, 64), (2, 8, 256, 256, 80), (1, 8, 64, 154, 160), (1, 8, 100, 7, 40),
                                              (1, 1, 70, 70, 512)])
-def test_attention_prescaled_k(B, heads, Nq, Nk, D):
+@pytest.mark.parametrize("variant", [0, 3, 5])
+def test_attention_prescaled_k(variant, B, heads, Nq, Nk, D):
     """gyre_op_attention_ex(k_prescaled=1): K carries log2(e)/sqrt(D) (as the UNet's scaled to_k weights produce it,
     one bf16 rounding of the fp32 product) -> folded-softmax kernel for D in {16,32,40,64,160}, plain kernels with
     unit scale otherwise.  Reference: fp32 softmax attention on the unrounded K."""
@@ -448,8 +449,12 @@ def test_attention_prescaled_k(B, heads, Nq, Nk, D):
     vt = torch.zeros((B, C_, ldvt), dtype=torch.bfloat16, device=DEV)
     vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
     o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
-    _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), ldvt, B, heads, Nq, Nk, D, vp(o), C_, 1))
-    report(f"attention prescaled B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, 6e-3)
+    old = L.gyre_debug_force_attn_variant(variant)    # 0 planner, 3 folded v2, 5 software-pipelined v3 (where built)
+    try:
+        _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), ldvt, B, heads, Nq, Nk, D, vp(o), C_, 1))
+    finally:
+        L.gyre_debug_force_attn_variant(old)
+    report(f"attention prescaled v{variant} B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, 6e-3)
 
 
 def test_attention_prescaled_peaked_and_drifting_max():
@@ -471,7 +476,12 @@ def test_attention_prescaled_peaked_and_drifting_max():
         ref = attn_ref(q, kk, v, heads)
         kpre = (kk * c).to(torch.bfloat16).to(DEV)
         vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
-        o = torch.empty(B, N, C_, dtype=torch.bfloat16, device=DEV)
-        _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
-        assert bool(torch.isfinite(o).all())
-        report(f"attention prescaled {name}", o.float().cpu(), ref, 3e-2)
+        for variant in (3, 5):
+            o = torch.empty(B, N, C_, dtype=torch.bfloat16, device=DEV)
+            old = L.gyre_debug_force_attn_variant(variant)
+            try:
+                _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
+            finally:
+                L.gyre_debug_force_attn_variant(old)
+            assert bool(torch.isfinite(o).all())
+            report(f"attention prescaled v{variant} {name}", o.float().cpu(), ref, 3e-2)
