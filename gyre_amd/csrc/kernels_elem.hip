@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p, size_t total_vec) 
 
 int gn_pick_chunks(int B, int HW, int C) {
     // The chunking fixes the order the per-sample statistics are summed in, so it must not depend on B (batch
-    // independence): 16-pixel chunks up to 4096 pixels, then 256 chunks per sample with at most 256 pixels each,
-    // beyond that 256-pixel chunks (VAE resolutions).  Even B = 1 at 64x64 gets 256 blocks.
+    // independence): 64 chunks per sample for 1024 <= HW <= 16384 (what the batch-16 tuning used), 16-pixel chunks
+    // below, 256-pixel chunks above (VAE resolutions).
     (void)B; (void)C;
-    int ppc = HW / 256;
+    int ppc = HW / 64;
     ppc = ppc < 16 ? 16 : (ppc > 256 ? 256 : ppc);
     int n = (HW + ppc - 1) / ppc;
     return n < 1 ? 1 : n;

@@ -1010,6 +1010,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         }
     }
     if (cfg >= 4) {
+        if (p.geglu && cfg == 11) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         if (p.geglu && cfg == 9) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
@@ -1027,6 +1028,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 8: return launch_cfg8<128, 256, 2, 4, 3>(st, p, KC_G8_CONV_128x256, splits);  // experiment: 3-deep ring
         case 9: return launch_cfg4d<128, 320, 2, 2>(st, p, KC_G8_CONV_128x320, splits);     // 2 workgroups / CU
         case 10: return launch_cfg4d<128, 256, 2, 2>(st, p, KC_G8_CONV_128x256, splits);
+        case 11: return launch_cfg8<256, 320, 2, 4>(st, p, KC_G8_CONV_256x320, splits);    // experiment: 128x80 wave tiles
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }
