@@ -890,6 +890,7 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
             case 32: return launch_attn3_t<32>(st, p);
             case 40: return launch_attn3_t<40>(st, p);
             case 64: return launch_attn3_t<64>(st, p);
+            case 80: return launch_attn3_t<80>(st, p);
             default: break;
         }
     }
