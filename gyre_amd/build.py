@@ -28,6 +28,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-v
 # (gfx950 unified register file) instead of AGPRs, which removes ~90 v_accvgpr_read/write per KV tile
 PER_FILE_FLAGS = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
+# Kernels that synchronise LDS-DMA tiles with a *counted* s_waitcnt vmcnt(N) must not spill: scratch stores also
+# count in vmcnt and may be acknowledged before older loads, which would let the wait pass while a tile is still in
+# flight.  Every compile therefore records the register / scratch use of each kernel (clang remarks), and
+# tests/test_host_cpu.py::test_counted_vmcnt_kernels_do_not_spill checks it.  Kernels listed here drain with vmcnt(0).
+RESOURCE_FILES = ("kernels_attn.hip", "kernels_gemm.hip")
+SCRATCH_ALLOWED = ("k_attn3ILi80E",)
+RESOURCES_JSON = os.path.join(HERE, "build", "kernel_resources.json")
+
 
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -41,6 +49,39 @@ def _stale(out: str, deps) -> bool:
         return True
     t = os.path.getmtime(out)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _record_resources(source: str, remarks: str) -> None:
+    import json
+    import re
+    import threading
+    kernels, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r"VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch_bytes_per_lane", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy_waves_per_simd", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds_bytes", r"LDS Size \[bytes/block\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    with _RES_LOCK:
+        data = {}
+        if os.path.exists(RESOURCES_JSON):
+            try:
+                data = json.load(open(RESOURCES_JSON))
+            except Exception:
+                data = {}
+        data[source] = kernels
+        with open(RESOURCES_JSON, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+
+
+import threading as _threading
+_RES_LOCK = _threading.Lock()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -58,12 +99,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def cc(job):
         src, obj = job
         extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
+        base = os.path.basename(src)
+        if base in RESOURCE_FILES:
+            extra = [*extra, "-Rpass-analysis=kernel-resource-usage"]
         cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if base in RESOURCE_FILES:
+            _record_resources(base, r.stderr)
+            return ""
         return r.stderr
 
     if jobs:

@@ -519,8 +519,10 @@ template <int D, int PD>
 __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* zero) {
     constexpr int QI = 2;
     constexpr int NS = PD + 2;
-    constexpr int DP = (D + 31) / 32 * 32;
-    constexpr int KS = DP / 32;
+    // (a 16-wide v_mfma_f32_16x16x16_bf16 step for the head-dim remainder - D = 40 as 32 + 16 instead of 64 - was
+    // measured: no faster (the matrix core is not the limiter) and a dependent x32 -> x16 chain on one accumulator
+    // gave wrong results for D = 80 under this compiler, so the contraction stays padded to 32)
+    constexpr int KS = (D + 31) / 32;
     constexpr int DO = (D + 15) / 16;
     constexpr int KVEC = D / 8;
     constexpr int VR = DO * 16;
@@ -531,6 +533,9 @@ __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* ze
     constexpr int KG = 64 * KVEC, VG = VR * 8;
     constexpr bool ONES = (D % 16 != 0);
     constexpr float TAU = 60.f;
+    // D = 80 does not fit 256 registers without a few spills.  Scratch stores count in vmcnt and may retire before
+    // older loads, so a counted wait is not safe there: drain completely instead (one tile less of DMA lookahead).
+    constexpr bool DRAIN = D > 64;
     static_assert(KG % 64 == 0, "K granules fill whole wave instructions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -727,7 +732,8 @@ __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* ze
         constexpr bool HASNEXT = decltype(has_next)::value;
         if (HASNEXT) {
             // tile t+1 landed (tiles t+2 .. t+PD may still be in flight), every wave is done with tile t-1
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NW) : "memory");
+            if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NW) : "memory");
             __builtin_amdgcn_s_barrier();
             issue((t + 1 + PD) * 64, (t + 1 + PD) % NS);
         }
@@ -741,7 +747,8 @@ __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* ze
     const int nt = (p.Nk + 63) / 64;
 #pragma unroll
     for (int t0 = 0; t0 <= PD; ++t0) issue(t0 * 64, t0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NW) : "memory");
+    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NW) : "memory");
     __builtin_amdgcn_s_barrier();
     f32x4_t sa[QI][4], sb[QI][4];
     if (nt == 1) qk(0, sa, std::true_type{}); else qk(0, sa, std::false_type{});
@@ -909,9 +916,10 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
         switch (p.D) {
             case 16: return q4 ? launch_attn2_t<16, 4>(st, p) : launch_attn2_t<16, 2>(st, p);
             case 32: return q4 ? launch_attn2_t<32, 4>(st, p) : launch_attn2_t<32, 2>(st, p);
-            case 40: return q4 ? launch_attn2_t<40, 4>(st, p) : launch_attn2_t<40, 2>(st, p);
-            case 64: return q4 ? launch_attn2_t<64, 4>(st, p) : launch_attn2_t<64, 2>(st, p);
-            case 80: return q4 ? launch_attn2_t<80, 4>(st, p) : launch_attn2_t<80, 2>(st, p);
+            // (64 query rows per wave spill from head dim 40 up, which a counted-vmcnt kernel must not: not built)
+            case 40: return launch_attn2_t<40, 2>(st, p);
+            case 64: return launch_attn2_t<64, 2>(st, p);
+            case 80: return launch_attn2_t<80, 2>(st, p);
             case 128: return launch_attn2_t<128, 2>(st, p);
             case 160: return launch_attn2_t<160, 2>(st, p);
             default: break;

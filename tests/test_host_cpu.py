@@ -74,3 +74,21 @@ def test_sdxl_param_count_and_keys():
     assert shapes["down_blocks.1.attentions.0.proj_in.weight"] == (640, 640)        # linear projection
     assert shapes["add_embedding.linear_1.weight"] == (1280, 2816)
     assert not any(k.startswith("down_blocks.0.attentions") for k in shapes)
+
+
+def test_counted_vmcnt_kernels_do_not_spill():
+    """Kernels that wait for LDS-DMA tiles with a counted s_waitcnt vmcnt(N) must have no scratch traffic (spill
+    stores also count in vmcnt and may retire before older loads).  gyre_amd/build.py records clang's per-kernel
+    resource remarks at compile time; only the allow-listed kernel (which drains with vmcnt(0)) may use scratch."""
+    import json
+    from gyre_amd import build as B
+    B.build()
+    data = json.load(open(B.RESOURCES_JSON))
+    assert set(data) == set(B.RESOURCE_FILES)
+    n = 0
+    for src, kernels in data.items():
+        for name, r in kernels.items():
+            n += 1
+            if r.get("scratch_bytes_per_lane", 0) > 0:
+                assert any(a in name for a in B.SCRATCH_ALLOWED), f"{name} in {src} spills {r['scratch_bytes_per_lane']} B/lane"
+    assert n > 40
