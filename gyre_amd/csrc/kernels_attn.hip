@@ -542,8 +542,18 @@ __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* ze
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int q0 = blockIdx.x * (64 * QI) + wave * (16 * QI);
+    // 1-D grid, XCD-aware order: workgroups w, w+8, ... share an XCD (and its L2); give each XCD a contiguous run of
+    // (batch*head, query block) ids with the query block fastest, so the query blocks that stream the same K / V^T
+    // hit one L2 instead of fetching them into all eight (PMC: 755 MB -> K/V read once per XCD run)
+    const int nqb = (p.Nq + 64 * QI - 1) / (64 * QI);
+    const int ntot = nqb * p.B * p.H;
+    int wid;
+    {
+        const int qn = ntot >> 3, rn = ntot & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + loc;
+    }
+    const int bh = wid / nqb, b = bh / p.H, h = bh % p.H;
+    const int q0 = (wid - bh * nqb) * (64 * QI) + wave * (16 * QI);
     const bf16_t* qb = p.q + (size_t)b * p.Nq * p.ldq + h * D;
     const bf16_t* kb = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const bf16_t* vb = p.vt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldvt;
@@ -856,7 +866,7 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((p.Nq + 127) / 128, p.B * p.H);
+    dim3 grid((unsigned)(((p.Nq + 127) / 128) * p.B * p.H));
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
