@@ -16,7 +16,8 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for (B, h, Nq, Nk, D, scale) in [(16, 8, 4096, 4096, 40, 1.0), (16, 8, 1024, 1024, 80, 1.0), (16, 8, 256, 256, 160, 1.0),
-                                 (16, 8, 4096, 77, 40, 1.0), (4, 8, 4096, 4096, 40, 6.0), (2, 8, 1000, 1003, 40, 1.0)]:
+                                 (16, 8, 4096, 77, 40, 1.0), (4, 8, 4096, 4096, 40, 6.0), (2, 8, 1000, 1003, 40, 1.0),
+                                 (4, 8, 9216, 9216, 40, 1.0), (2, 10, 4096, 4096, 64, 1.0), (2, 8, 2304, 2304, 80, 1.0)]:
     Cc = h * D
     g = torch.Generator(device=DEV).manual_seed(0)
     q = (torch.randn(B, Nq, Cc, device=DEV, generator=g) * scale).to(torch.bfloat16)
