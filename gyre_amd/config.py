@@ -91,5 +91,10 @@ def tiny_sdxl_unet() -> UNetConfig:
                       projection_class_embeddings_input_dim=32 + 6 * 8)
 
 
+def sdxl_vae() -> VAEConfig:
+    """SDXL's AutoencoderKL: same topology as SD1.x, latent scaling 0.13025, 1024 px sample size."""
+    return VAEConfig(scaling_factor=0.13025, sample_size=1024)
+
+
 def tiny_vae() -> VAEConfig:
     return VAEConfig(block_out_channels=(32, 64, 64, 64), sample_size=64)

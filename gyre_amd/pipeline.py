@@ -107,7 +107,7 @@ class GyrePipeline:
     oracle adapters used by the tests).  text_encoder: optional callable ids[B,77] -> [B,77,D]."""
 
     vae_scale_factor = 8
-    latent_scale = 0.18215
+    latent_scale = 0.18215          # overridden per instance from vae.config.scaling_factor
     # hires-fix engine defaults (reference unified_pipeline.py:1368-1373)
     hires_fix = True
     hires_threshold_fraction = 0.0333
@@ -117,6 +117,8 @@ class GyrePipeline:
     def __init__(self, unet, vae, text_encoder: Optional[Callable] = None, device="cuda:0"):
         self.unet, self.vae, self.text_encoder = unet, vae, text_encoder
         self.device = torch.device(device)
+        # the reference hard-codes SD1.x's 0.18215 (unified_pipeline.py:319,2488); SDXL's VAE uses 0.13025
+        self.latent_scale = float(getattr(getattr(vae, "config", None), "scaling_factor", 0.18215))
 
     # -- text ---------------------------------------------------------------------------------
     def encode_ids(self, input_ids: Tensor) -> Tensor:
@@ -153,7 +155,7 @@ class GyrePipeline:
 
     # -- one mode-tree leaf ---------------------------------------------------------------------------
     def _build_leaf(self, *, height, width, image, mask_image, generators, text_embeddings, uncond_embeddings,
-                    guidance_scale, cfg_execution, B, fill_strength=None):
+                    guidance_scale, cfg_execution, B, fill_strength=None, added_cond=None, uncond_added_cond=None):
         """Everything one resolution needs: the CFG-wrapped epsilon UNet with its conditioning bound, the clean
         init latents (img2img / inpaint) and the inpaint blend data.  reference: a ModeTreeLeaf
         (unified_pipeline.py:1173-1200) + the mode built for it (Txt2img/Img2img/EnhancedInpaint/RunwayInpaint)."""
@@ -185,17 +187,21 @@ class GyrePipeline:
                 leaf.init_latents = self.image_to_latents(img, generators)
 
         # UNet stack: embeddings -> extra channels -> CFG
-        def bind(emb):
-            u = S.UNetWithEmbeddings(self.unet, emb)
+        def bind(emb, added=None):
+            u = S.UNetWithEmbeddings(self.unet, emb, added)
             return S.UnetWithExtraChannels(u, leaf.extra) if leaf.extra is not None else u
 
         if guidance_scale > 1.0:
             if cfg_execution == "sequential":
-                leaf.eps_unet = S.CFGUNet_Sequential(bind(text_embeddings), bind(uncond_embeddings), guidance_scale, B)
+                leaf.eps_unet = S.CFGUNet_Sequential(bind(text_embeddings, added_cond), bind(uncond_embeddings, uncond_added_cond),
+                                                     guidance_scale, B)
             else:
-                leaf.eps_unet = S.CFGUNet_Parallel(bind(torch.cat([uncond_embeddings, text_embeddings])), guidance_scale, B)
+                both = None
+                if added_cond is not None:
+                    both = {k: torch.cat([uncond_added_cond[k], added_cond[k]]) for k in added_cond}
+                leaf.eps_unet = S.CFGUNet_Parallel(bind(torch.cat([uncond_embeddings, text_embeddings]), both), guidance_scale, B)
         else:
-            leaf.eps_unet = bind(text_embeddings)
+            leaf.eps_unet = bind(text_embeddings, added_cond)
         return leaf
 
     def _leaf_initial_latents(self, leaf, sched, generators):
@@ -217,7 +223,8 @@ class GyrePipeline:
                  karras_rho: Optional[float] = None, eta: Optional[float] = None, cfg_execution: str = "parallel",
                  output_type: str = "image", callback=None, generator_device: str = "cpu",
                  hires_fix: Optional[bool] = None, hires_oos_fraction: Optional[float] = None,
-                 outmask_image: Optional[Tensor] = None):
+                 outmask_image: Optional[Tensor] = None, added_cond: Optional[dict] = None,
+                 uncond_added_cond: Optional[dict] = None):
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
@@ -245,6 +252,20 @@ class GyrePipeline:
             if uncond_embeddings.shape[0] == 1 and B > 1:
                 uncond_embeddings = uncond_embeddings.expand(B, -1, -1)
 
+        # SDXL added conditioning (BASELINE config 4; not in the reference): {"text_embeds": [B or 1, D], "time_ids": [B or 1, 6]}
+        if getattr(self.unet.config, "addition_embed_type", None) == "text_time":
+            if added_cond is None:
+                raise ValueError("this UNet needs added_cond={'text_embeds': ..., 'time_ids': ...}")
+            exp = lambda d: {k: (v.to(dev).expand(B, -1) if v.shape[0] == 1 and B > 1 else v.to(dev)) for k, v in d.items()}
+            added_cond = exp(added_cond)
+            if do_cfg:
+                uncond_added_cond = exp(uncond_added_cond if uncond_added_cond is not None else
+                                        {"text_embeds": torch.zeros_like(added_cond["text_embeds"]), "time_ids": added_cond["time_ids"]})
+            for d in (added_cond, uncond_added_cond if do_cfg else None):
+                if d is not None and any(v.shape[0] != B for v in d.values()):
+                    raise ValueError("added_cond tensors must have batch 1 or the number of seeds")
+        else:
+            added_cond = uncond_added_cond = None
         if self.unet.config.in_channels == 9 and (image is None or mask_image is None):
             raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
         fill_strength = None
@@ -279,7 +300,8 @@ class GyrePipeline:
             raise ValueError("Can't use Diffuser schedulers with Hires fix. "
                              "Either use a K-Diffusion scheduler or disable Hires fix.")
         common = dict(generators=generators, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
-                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, fill_strength=fill_strength)
+                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, fill_strength=fill_strength,
+                      added_cond=added_cond, uncond_added_cond=uncond_added_cond)
         leaves = []
         if use_hires:
             to_nat = lambda t: None if t is None else H.image_to_natural(natural_px, t if t.ndim == 4 else t[None],

@@ -78,10 +78,12 @@ class CFGUNet_Sequential:
 class UNetWithEmbeddings:
     """Binds encoder_hidden_states and takes `.sample` (reference unet/core.py:242-274)."""
 
-    def __init__(self, unet, text_embeddings: Tensor):
-        self.unet, self.text_embeddings = unet, text_embeddings
+    def __init__(self, unet, text_embeddings: Tensor, added_cond_kwargs: Optional[dict] = None):
+        self.unet, self.text_embeddings, self.added = unet, text_embeddings, added_cond_kwargs
 
     def __call__(self, latents: Tensor, t) -> Tensor:
+        if self.added is not None:   # SDXL "text_time" conditioning (pooled text embedding + size / crop ids)
+            return self.unet(latents, t, encoder_hidden_states=self.text_embeddings, added_cond_kwargs=self.added).sample
         return self.unet(latents, t, encoder_hidden_states=self.text_embeddings).sample
 
 

@@ -65,6 +65,9 @@ def generate_sharded(pipe, *, seeds: Sequence[int], text_embeddings: torch.Tenso
         ue = uncond_embeddings
         if ue is not None and ue.shape[0] != 1:
             ue = ue[s:e]
+        for key in ("added_cond", "uncond_added_cond"):     # per-image SDXL conditioning follows the slice
+            if kw.get(key) is not None:
+                kw[key] = {k: (v if v.shape[0] == 1 else v[s:e]) for k, v in kw[key].items()}
         prev = None
         if bit_exact:
             from .modules import set_batch_invariant

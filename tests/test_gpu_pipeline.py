@@ -118,3 +118,23 @@ def test_tiny_hires_fix_psnr(tiny):
     p = PR.psnr(img, ref)
     print(f"[parity] tiny hires-fix 192x256: PSNR {p:.1f} dB")
     assert img.shape == (2, 3, 192, 256) and p >= 30.0
+
+
+def test_tiny_sdxl_pipeline_psnr():
+    """SDXL-style conditioning through the pipeline (BASELINE config 4 plumbing): native UNet/VAE vs the same host flow
+    on the fp32 CPU oracle models."""
+    from test_host_pipeline import OracleUNet, OracleVAE
+    ucfg = gcfg.tiny_sdxl_unet()
+    vcfg = gcfg.VAEConfig(block_out_channels=(32, 64, 64, 64), sample_size=64, scaling_factor=0.13025)
+    usd, vsd, pipe = build(ucfg, vcfg)
+    g = torch.Generator().manual_seed(7)
+    text = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    unc = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g) * 0.5
+    added = {"text_embeds": torch.randn(2, 32, generator=g), "time_ids": torch.tensor([[128., 128, 0, 0, 128, 128]])}
+    kw = dict(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=6,
+              sampler="dpmpp_2m", guidance_scale=5.0, added_cond=added)
+    img = pipe(**kw).cpu()
+    ref = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")(**kw)
+    p = PR.psnr(img, ref)
+    print(f"[parity] tiny SDXL pipeline: PSNR {p:.1f} dB")
+    assert p >= 30.0

@@ -113,11 +113,12 @@ class OracleUNet:
     def __init__(self, sd, cfg):
         self.sd, self.config = sd, cfg
 
-    def __call__(self, latents, t, encoder_hidden_states=None):
+    def __call__(self, latents, t, encoder_hidden_states=None, added_cond_kwargs=None):
         t = torch.as_tensor(t)
         if t.ndim == 0:
             t = t.expand(latents.shape[0])
-        return SimpleNamespace(sample=M.unet_forward(self.sd, self.config, latents, t, encoder_hidden_states))
+        return SimpleNamespace(sample=M.unet_forward(self.sd, self.config, latents, t, encoder_hidden_states,
+                                                     added_cond=added_cond_kwargs))
 
 
 class OracleVAE:
@@ -456,3 +457,53 @@ def test_pipeline_outmask_composite(tiny):
     assert out.shape == (1, 3, 128, 128)
     assert torch.equal(out[:, :, :32], image[:, :, :32])          # outside the outmask: source pixels exactly
     assert not torch.equal(out[:, :, 32:96, 32:96], image[:, :, 32:96, 32:96])
+
+
+def test_pipeline_sdxl_added_conditioning_cpu():
+    """BASELINE config 4 plumbing (SDXL is not in the reference): pooled text embedding + time ids reach the UNet, the
+    unconditional half gets its own, the VAE scaling factor comes from the VAE config; the result equals a manual
+    Euler loop on the oracle UNet."""
+    ucfg = gcfg.tiny_sdxl_unet()
+    vcfg = gcfg.VAEConfig(block_out_channels=(32, 64, 64, 64), sample_size=64, scaling_factor=0.13025)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    g = torch.Generator().manual_seed(7)
+    text, unc = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g), torch.randn(2, 77, ucfg.cross_attention_dim, generator=g)
+    pooled = torch.randn(2, 32, generator=g)
+    ids = torch.tensor([[128., 128, 0, 0, 128, 128]] * 2)
+    seen = []
+
+    class Spy(OracleUNet):
+        def __call__(self, latents, t, encoder_hidden_states=None, added_cond_kwargs=None):
+            seen.append({k: v.clone() for k, v in added_cond_kwargs.items()})
+            return super().__call__(latents, t, encoder_hidden_states, added_cond_kwargs)
+
+    pipe = GyrePipeline(Spy(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    assert pipe.latent_scale == pytest.approx(0.13025)
+    kw = dict(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=3,
+              sampler="euler", output_type="latent")
+    out = pipe(added_cond={"text_embeds": pooled, "time_ids": ids[:1]}, **kw)
+    assert out.shape == (2, 4, 16, 16) and bool(torch.isfinite(out).all())
+    a = seen[0]
+    assert a["text_embeds"].shape == (4, 32) and a["time_ids"].shape == (4, 6)
+    assert torch.equal(a["text_embeds"][2:], pooled) and float(a["text_embeds"][:2].abs().max()) == 0   # default uncond: zeros
+    # manual reference loop
+    sched = PS.KDiffusionScheduler("euler", gens([1, 2]), "cpu")
+    sched.set_eps_unet(lambda x, t: x)
+    sched.set_timesteps(3)
+    x = txt2img_latents(gens([1, 2]), 4, 16, 16, ucfg.sample_size, "cpu") * float(sched.sigmas[0])
+    sch = PS.DiscreteSchedule()
+    both = {"text_embeds": torch.cat([torch.zeros_like(pooled), pooled]), "time_ids": torch.cat([ids, ids])}
+    for i in range(3):
+        s0, s1 = float(sched.sigmas[i]), float(sched.sigmas[i + 1])
+        t = int(sch.sigma_to_t(torch.tensor(s0)))
+        xin = torch.cat([x, x]) / (s0 ** 2 + 1) ** 0.5
+        e = M.unet_forward(usd, ucfg, xin, torch.full((4,), t), torch.cat([unc, text]), added_cond=both)
+        eps = e[:2] + 7.5 * (e[2:] - e[:2])
+        den = x - eps * s0
+        x = x + (x - den) / s0 * (s1 - s0)
+    assert torch.allclose(out, x, rtol=1e-4, atol=1e-3)      # values are O(20): fp32 summation-order noise only
+    with pytest.raises(ValueError, match="added_cond"):
+        pipe(**kw)
+    with pytest.raises(ValueError, match="batch 1 or"):
+        pipe(added_cond={"text_embeds": torch.zeros(3, 32), "time_ids": ids[:1]}, **kw)

@@ -56,7 +56,17 @@ xl = fill(GyreHipUNet(gcfg.sdxl_unet()).to(torch.bfloat16).to(dev), 1)
 added = {"text_embeds": torch.randn(2, 1280, device=dev, generator=g), "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * 2, device=dev)}
 compare("SDXL 128x128 B=2", xl, torch.randn(2, 4, 128, 128, device=dev, generator=g), torch.full((2,), 500, device=dev),
         torch.randn(2, 77, 2048, device=dev, generator=g), added_cond_kwargs=added)
-del xl
+vae_xl = fill(GyreHipVAE(gcfg.sdxl_vae()).to(torch.bfloat16).to(dev), 5)
+pxl = GyrePipeline(xl, vae_xl, None, device=dev)
+tx = torch.randn(2, 77, 2048, generator=torch.Generator().manual_seed(1)); un = torch.randn(2, 77, 2048, generator=torch.Generator().manual_seed(2))
+for rep in range(2):
+    t0 = time.time()
+    img = pxl(seeds=[1, 2], text_embeddings=tx, uncond_embeddings=un, height=1024, width=1024, num_inference_steps=30,
+              sampler="euler_a", guidance_scale=5.0, added_cond={k: v.cpu() for k, v in added.items()})
+    torch.cuda.synchronize()
+    print(f"config 4 per-GPU share (SDXL 1024^2, 2 images, 30 steps euler_a, CFG): {time.time() - t0:.2f} s, "
+          f"finite {bool(torch.isfinite(img).all())}, shape {tuple(img.shape)}")
+del xl, vae_xl, pxl
 torch.cuda.empty_cache()
 
 inp = fill(GyreHipUNet(gcfg.sd15_unet(9)).to(torch.bfloat16).to(dev), 2)
