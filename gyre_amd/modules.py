@@ -144,10 +144,14 @@ class _NativeModule(nn.Module):
         return cls(config, **kw) if config is not None else cls(**kw)
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = None, **_ignored):
+    def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = None, variant: Optional[str] = None,
+                        subfolder: Optional[str] = None, **_ignored):
         """Reads the HF diffusers folder layout (config.json + *.safetensors) without diffusers;
-        signature subset of what gyre/manager.py:1176-1242 passes."""
+        signature subset of what gyre/manager.py:1176-1242 passes (torch_dtype, variant="fp16", and kwargs it only
+        forwards when present in the signature)."""
         from safetensors.torch import load_file
+        if subfolder:
+            path = os.path.join(path, subfolder)
         cfg = None
         cj = os.path.join(path, "config.json")
         if os.path.exists(cj):
@@ -157,7 +161,12 @@ class _NativeModule(nn.Module):
         files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
         if not files:
             raise FileNotFoundError(f"no *.safetensors in {path}")
-        model.load_state_dict(load_file(os.path.join(path, files[0])))
+        # diffusers naming: diffusion_pytorch_model[.<variant>].safetensors; prefer the requested variant, else the
+        # un-suffixed file, else whatever single file is there (manager.py:1068-1112 fallback behaviour)
+        want = [f for f in files if variant and f.endswith(f".{variant}.safetensors")]
+        plain = [f for f in files if f.count(".") == 1]
+        pick = (want or plain or files)[0]
+        model.load_state_dict(load_file(os.path.join(path, pick)))
         if torch_dtype is not None:
             model = model.to(torch_dtype)
         model._source = path
@@ -188,16 +197,27 @@ class GyreHipUNet(_NativeModule):
         boc = tuple(j.get("block_out_channels", (320, 640, 1280, 1280)))
         n = len(boc)
         down = j.get("down_block_types", ["CrossAttnDownBlock2D"] * (n - 1) + ["DownBlock2D"])
-        ahd = j.get("attention_head_dim", 8)
+        # diffusers quirk kept by every SD config: "attention_head_dim" holds the NUMBER of heads per level
+        ahd = j.get("num_attention_heads") or j.get("attention_head_dim", 8)
         heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * n
+        tl = j.get("transformer_layers_per_block", 1)
+        depth = tuple(tl) if isinstance(tl, (list, tuple)) else (tl,) * n
+        kw = {}
+        if j.get("addition_embed_type") == "text_time":          # SDXL
+            kw = dict(addition_embed_type="text_time", addition_time_embed_dim=j.get("addition_time_embed_dim", 256),
+                      projection_class_embeddings_input_dim=j.get("projection_class_embeddings_input_dim", 2816))
+        elif j.get("addition_embed_type") is not None:
+            raise NotImplementedError(f"addition_embed_type {j['addition_embed_type']!r}")
+        if j.get("class_embed_type") is not None or j.get("num_class_embeds") is not None:
+            raise NotImplementedError("class-conditioned UNets are outside the native hot path")
         return UNetConfig(in_channels=j.get("in_channels", 4), out_channels=j.get("out_channels", 4),
                           block_out_channels=boc, layers_per_block=j.get("layers_per_block", 2),
                           attn_levels=tuple("CrossAttn" in d for d in down), num_heads=heads,
                           cross_attention_dim=j.get("cross_attention_dim", 768),
-                          norm_num_groups=j.get("norm_num_groups", 32), transformer_depth=(1,) * n,
+                          norm_num_groups=j.get("norm_num_groups", 32), transformer_depth=depth,
                           use_linear_projection=bool(j.get("use_linear_projection", False)),
                           sample_size=j.get("sample_size", 64), flip_sin_to_cos=j.get("flip_sin_to_cos", True),
-                          freq_shift=float(j.get("freq_shift", 0)))
+                          freq_shift=float(j.get("freq_shift", 0)), **kw)
 
     def _c_cfg(self):
         c, cfg = self.config, _lib.UNetCfg()

@@ -120,6 +120,28 @@ class GyrePipeline:
         # the reference hard-codes SD1.x's 0.18215 (unified_pipeline.py:319,2488); SDXL's VAE uses 0.13025
         self.latent_scale = float(getattr(getattr(vae, "config", None), "scaling_factor", 0.18215))
 
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = torch.bfloat16, device="cuda:0",
+                        variant: Optional[str] = None, text_encoder: Optional[Callable] = None):
+        """Build the pipeline from a diffusers-layout model folder (model_index.json, unet/, vae/[, text_encoder/])
+        without importing diffusers - the layout the reference's manager resolves engines to (manager.py:1024-1252).
+        The CLIP text encoder is loaded through transformers when its folder is present and no callable is given."""
+        import os
+        from .modules import GyreHipUNet, GyreHipVAE
+        if not os.path.exists(os.path.join(path, "model_index.json")) and not os.path.isdir(os.path.join(path, "unet")):
+            raise FileNotFoundError(f"{path} is not a diffusers model folder (no model_index.json / unet/)")
+        unet = GyreHipUNet.from_pretrained(path, subfolder="unet", torch_dtype=torch_dtype, variant=variant)
+        vae = GyreHipVAE.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype, variant=variant)
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            unet, vae = unet.to(dev), vae.to(dev)
+        te_dir = os.path.join(path, "text_encoder")
+        if text_encoder is None and os.path.isdir(te_dir):
+            from transformers import CLIPTextModel
+            te = CLIPTextModel.from_pretrained(te_dir, torch_dtype=torch_dtype).to(dev).eval()
+            text_encoder = lambda ids: te(input_ids=ids)[0]
+        return cls(unet, vae, text_encoder, device=dev)
+
     # -- text ---------------------------------------------------------------------------------
     def encode_ids(self, input_ids: Tensor) -> Tensor:
         if self.text_encoder is None:

@@ -92,3 +92,61 @@ def test_counted_vmcnt_kernels_do_not_spill():
             if r.get("scratch_bytes_per_lane", 0) > 0:
                 assert any(a in name for a in B.SCRATCH_ALLOWED), f"{name} in {src} spills {r['scratch_bytes_per_lane']} B/lane"
     assert n > 40
+
+
+def test_from_pretrained_reads_diffusers_layout(tmp_path):
+    """config.json + safetensors in the HF diffusers folder layout, without diffusers (reference manager.py:1176-1252
+    calls Class.from_pretrained(path, torch_dtype=..., variant=...)): SD1.x-style and SDXL-style UNet configs, variant
+    selection, the >= 0.17 VAE attention key names, and the pipeline-level loader."""
+    import json
+    from safetensors.torch import save_file
+    from gyre_amd import config as gcfg, weights
+    from gyre_amd.modules import GyreHipUNet, GyreHipVAE
+    from gyre_amd.pipeline import GyrePipeline
+    root = tmp_path / "model"
+    (root / "unet").mkdir(parents=True)
+    (root / "vae").mkdir()
+    (root / "model_index.json").write_text(json.dumps({"_class_name": "StableDiffusionPipeline"}))
+    ucfg = gcfg.tiny_unet()
+    (root / "unet" / "config.json").write_text(json.dumps({
+        "_class_name": "UNet2DConditionModel", "in_channels": 4, "out_channels": 4, "sample_size": 16,
+        "block_out_channels": [32, 64, 128, 128], "layers_per_block": 2, "cross_attention_dim": 64,
+        "attention_head_dim": [2, 2, 4, 4], "norm_num_groups": 32,
+        "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]}))
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    save_file({k: v.contiguous() for k, v in usd.items()}, str(root / "unet" / "diffusion_pytorch_model.safetensors"))
+    save_file({k: (v * 0).contiguous() for k, v in usd.items()}, str(root / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    vcfg = gcfg.tiny_vae()
+    (root / "vae" / "config.json").write_text(json.dumps({
+        "_class_name": "AutoencoderKL", "block_out_channels": [32, 64, 64, 64], "sample_size": 64, "scaling_factor": 0.18215}))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    new_names = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+    renamed = {}
+    for k, v in vsd.items():
+        for a, b in new_names.items():
+            k = k.replace(a, b)
+        renamed[k] = v.contiguous()
+    save_file(renamed, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+
+    unet = GyreHipUNet.from_pretrained(str(root / "unet"), torch_dtype=torch.bfloat16)
+    assert unet.config == ucfg and unet.dtype == torch.bfloat16 and unet._source.endswith("unet")
+    got = unet.state_dict()["conv_in.weight"].float()
+    assert torch.allclose(got, usd["conv_in.weight"].to(torch.bfloat16).float())
+    zero = GyreHipUNet.from_pretrained(str(root), subfolder="unet", variant="fp16")
+    assert float(zero.state_dict()["conv_in.weight"].abs().max()) == 0
+    vae = GyreHipVAE.from_pretrained(str(root / "vae"))
+    assert vae.config.block_out_channels == (32, 64, 64, 64)
+    assert torch.equal(vae.state_dict()["decoder.mid_block.attentions.0.query.weight"], vsd["decoder.mid_block.attentions.0.query.weight"])
+    pipe = GyrePipeline.from_pretrained(str(root), device="cpu")
+    assert isinstance(pipe.unet, GyreHipUNet) and isinstance(pipe.vae, GyreHipVAE) and pipe.text_encoder is None
+    with pytest.raises(FileNotFoundError):
+        GyrePipeline.from_pretrained(str(tmp_path / "nope"))
+    # SDXL-style config keys
+    xl = GyreHipUNet._config_from_json({
+        "block_out_channels": [320, 640, 1280], "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+        "attention_head_dim": [5, 10, 20], "transformer_layers_per_block": [1, 2, 10], "cross_attention_dim": 2048,
+        "use_linear_projection": True, "sample_size": 128, "addition_embed_type": "text_time",
+        "addition_time_embed_dim": 256, "projection_class_embeddings_input_dim": 2816})
+    assert xl == gcfg.sdxl_unet()
+    with pytest.raises(NotImplementedError):
+        GyreHipUNet._config_from_json({"class_embed_type": "timestep"})
