@@ -20,6 +20,13 @@
 //     in that layout directly (OUT_BF16_T epilogue), so no in-kernel transpose is needed.
 //   * head dims 40/80/160 are zero-padded in LDS only (QK^T contraction to a multiple of 32, PV
 //     output to a multiple of 16); global traffic is the unpadded Q/K/V/O.
+//
+// Three kernels, chosen in launch_attention():
+//   k_attn   (v1)  register-staged K / V^T tiles; any head dim up to 512 (the VAE mid block)
+//   k_attn2  (v2)  LDS-DMA ring; plain online softmax, or FOLD (K prescaled: scale in the to_k weights, running max in
+//                  the MFMA C input) for short key sequences (cross-attention) and D = 160
+//   k_attn3  (v3)  FOLD + software pipeline inside the wave (exp of tile t overlaps QK^T of tile t+1); all UNet
+//                  self-attention with D in {16,32,40,64,80}
 #include "kernels.h"
 #include <type_traits>
 
@@ -825,7 +832,7 @@ static const bf16_t* attn_zero_page() {
     return (const bf16_t*)p;
 }
 
-static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1 (register staged), 2 = v2 QI=2, 4 = v2 QI=4
+static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1, 2 = v2 plain, 3 = v2 folded, 4 = v2 QI=4 (D <= 32), 5 = v3
 extern "C" int gyre_debug_force_attn_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
 template <int D, int QI, bool FOLD = false>
