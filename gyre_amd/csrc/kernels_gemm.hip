@@ -291,6 +291,120 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
     constexpr int LPW = AR + BR;   // DMA instructions per wave per K step
+    if constexpr (NST == 4) {
+        // ---- phased schedule ("8-phase" form of the CDNA4 guide, cdna_hip_programming.md 5 / T3-T5) -----------------
+        // A K step is cut into NP = NI/2 phases of 16 MFMAs (all MI row fragments x two column fragments x K = 64).
+        // Each phase: ds_read the register sub-tile it needs | issue a share of the NEXT K step's LDS-DMA granules |
+        // counted vmcnt | barrier | MFMA cluster at raised priority | barrier.  The two halves of the workgroup
+        // (waves 0-3 / 4-7 = the two waves of each SIMD) run one barrier apart, so one half's MFMA cluster always
+        // covers the other half's ds_read / DMA-issue section; DMA loads stay in flight across barriers (vmcnt is
+        // never drained inside the loop), which removes the per-K-step stage+wait+barrier stall of the 2-phase loop.
+        // MEASURED (tools/square_gemm.py, cfg_compare.py, geglu_compare.py; config 13 vs 6): bit-identical results;
+        // 8192^3 1142 vs 1085 TFLOP/s, long-K linears +5-10 %, K = 320 layers -7 %, 3x3 convs -4 % (per-granule address
+        // regeneration); the stagger itself is worth only ~2 % here because the 2-phase loop already runs two waves per
+        // SIMD that cover each other.  Not selected by the planner; kept as a tested experiment.
+        // Granule g (64 rows x 128 B, one DMA instruction per thread): A0..A3, then B0..B(BR-1).  Issue order and
+        // the wait counts below are derived in DESIGN.md (a granule is read one phase after the wait that retires
+        // it on every wave, and re-staged at least two phases after its last read).
+        static_assert(WM == 4 && WN == 2 && NI % 2 == 0 && AR == 4 && (BR == 5 || BR == 4), "phased schedule: 256 x {320,256}");
+        constexpr int NP = NI / 2;
+        auto issue_gran = [&](int kc, int s, int g) {      // g is a compile-time constant after unrolling
+            char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
+            const int k = kc * BK + kvs * 8;
+            const bool kok = k < p.K && kc < nk;             // past the last K step: zero page (keeps vmcnt counts fixed)
+            if (g < AR) {
+                const int i = g;
+                const bf16_t* src = zero;
+                if (MODE == GEMM_LINEAR) {
+                    if (kok && a_base[i] >= 0)
+                        src = k < p.C1 ? p.A + (size_t)a_base[i] * p.lda + k : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
+                } else {
+                    int tap, c;
+                    if (UNIFORM_TAP) { const int chunk = kc / 9; tap = kc - chunk * 9; c = chunk * BK + kvs * 8; }
+                    else { tap = k / p.Cin; c = k - tap * p.Cin; }
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                    if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                        if (p.ups) { iy >>= 1; ix >>= 1; }
+                        size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
+                        src = c < p.C1 ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
+                    }
+                }
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 8192), 16, 0, 0);
+            } else {
+                const int i = g - AR;
+                int kw = k;
+                if (MODE == GEMM_CONV3 && UNIFORM_TAP) { const int chunk = kc / 9, tap = kc - chunk * 9; kw = tap * p.Cin + chunk * BK + kvs * 8; }
+                const int n = n0 + r0 + 64 * i;
+                const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < LPW; ++g) issue_gran(kc0, 0, g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int gsel = (p.debug >> 4) & 3;                 // tuning: which waves form the late half
+        const bool late_half = gsel == 0 ? wave >= 4 : gsel == 1 ? (wave & 1) : gsel == 2 ? ((wave >> 1) & 1) : false;
+        if (late_half) __builtin_amdgcn_s_barrier();         // stagger: this half runs one barrier behind
+        bf16x8_t af[MI][2];
+        for (int kc = kc0; kc < nk; ++kc) {
+            const int cur = (kc - kc0) & 1;
+            const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
+            const uint4* b = a + BM * 8;
+#pragma unroll
+            for (int ph = 0; ph < NP; ++ph) {
+                if (ph == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            const int r = wm * TM + i * 16 + fr;
+                            af[i][ks] = __builtin_bit_cast(bf16x8_t, a[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+                        }
+                }
+                bf16x8_t bfr[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int r = wn * TN + (2 * ph + jj) * 16 + fr;
+                        bfr[jj][ks] = __builtin_bit_cast(bf16x8_t, b[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
+                    }
+                // next K step's granules for this phase + the counted wait that retires what phase ph+1 will read
+                if constexpr (BR == 5) {
+                    if (ph == 0) { issue_gran(kc + 1, cur ^ 1, 0); issue_gran(kc + 1, cur ^ 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    if (ph == 1) { issue_gran(kc + 1, cur ^ 1, 2); issue_gran(kc + 1, cur ^ 1, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+                    if (ph == 2) { issue_gran(kc + 1, cur ^ 1, AR + 0); issue_gran(kc + 1, cur ^ 1, AR + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+                    if (ph == 3) { issue_gran(kc + 1, cur ^ 1, AR + 3); issue_gran(kc + 1, cur ^ 1, AR + 1); }
+                    if (ph == 4) { issue_gran(kc + 1, cur ^ 1, AR + 4); asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+                } else {
+                    if (ph == 0) { issue_gran(kc + 1, cur ^ 1, 0); issue_gran(kc + 1, cur ^ 1, 1); }
+                    if (ph == 1) { issue_gran(kc + 1, cur ^ 1, 2); issue_gran(kc + 1, cur ^ 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    if (ph == 2) { issue_gran(kc + 1, cur ^ 1, AR + 0); issue_gran(kc + 1, cur ^ 1, AR + 2); }
+                    if (ph == 3) { issue_gran(kc + 1, cur ^ 1, AR + 1); issue_gran(kc + 1, cur ^ 1, AR + 3); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc[i][2 * ph + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj][ks], af[i][ks], acc[i][2 * ph + jj], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the past-the-end zero-page granules
+        if (!late_half) __builtin_amdgcn_s_barrier();        // re-align the two halves
+        __syncthreads();
+    } else {
     issue_stage(kc0, 0);
     if (NST == 3 && kc0 + 1 < nk) issue_stage(kc0 + 1, 1);
     if (NST == 2) {
@@ -341,6 +455,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
     }
     if (NST == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    }
     if (splits > 1) {
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
@@ -655,7 +770,7 @@ template <int BM, int BN, int WM, int WN, int NST = 2>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    const size_t lds = (size_t)NST * (BM + BN) * 128;
+    const size_t lds = (size_t)(NST == 4 ? 2 : NST) * (BM + BN) * 128;   // NST == 4: phased schedule on a double buffer
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
@@ -1029,6 +1144,9 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 9: return launch_cfg4d<128, 320, 2, 2>(st, p, KC_G8_CONV_128x320, splits);     // 2 workgroups / CU
         case 10: return launch_cfg4d<128, 256, 2, 2>(st, p, KC_G8_CONV_128x256, splits);
         case 11: return launch_cfg8<256, 320, 2, 4>(st, p, KC_G8_CONV_256x320, splits);    // experiment: 128x80 wave tiles
+        // experiment: phased ("8-phase") K loop, see the NST == 4 branch of k_gemm8.  Only the 256x256 tile is built: the
+        // 256x320 form needs > 256 registers and a counted-vmcnt kernel must not spill.
+        case 13: return launch_cfg8<256, 256, 4, 2, 4>(st, p, KC_G8_CONV_256x256, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }

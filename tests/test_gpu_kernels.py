@@ -254,7 +254,7 @@ def test_error_paths():
 
 
 # ---- every GEMM tile configuration, forced, on shapes with M / N / K tails -------------------------
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize("M,K,N,bias,res", [(1000, 320, 640, True, True), (4096 + 37, 200, 1280, True, False),
                                             (513, 1280, 320 * 4, False, True)])
 def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
@@ -276,7 +276,7 @@ def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
     report(f"linear cfg{cfg} M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7, 8, 10])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7, 8, 10, 13])
 def test_geglu_forced_tile_config(cfg):
     L = _lib.lib()
     M, K, F_ = 700, 320, 1280
@@ -295,7 +295,7 @@ def test_geglu_forced_tile_config(cfg):
     report(f"geglu cfg{cfg}", y.float().cpu(), ref, TOL)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,asym,res", [
     (2, 24, 20, 320, 640, 1, 0, 0, True), (1, 16, 16, 72, 1280, 1, 1, 0, False), (2, 18, 18, 128, 1280, 2, 0, 1, False),
 ])
@@ -383,7 +383,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
     b = randn(Cout, seed=62).to(DEV)
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 11, 13):
         y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
@@ -398,7 +398,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     xl = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
     wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 11, 13):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
