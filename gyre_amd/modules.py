@@ -275,10 +275,15 @@ class GyreHipUNet(_NativeModule):
         x = sample.contiguous()
         ctx = encoder_hidden_states.to(dev).contiguous()
         _lib.require_gpu_tensor(x, "latents")
-        t = torch.as_tensor(timestep, device=dev)
-        t = t.to(torch.int64).reshape(-1)
-        if t.numel() == 1:
-            t = t.expand(B)
+        if isinstance(timestep, torch.Tensor):
+            t = timestep.to(dev).to(torch.int64).reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(B)
+        else:
+            # a Python scalar (what the k-diffusion wrapper passes): fill on the device.  torch.as_tensor(int, device=...)
+            # is a pageable host-to-device copy, which on ROCm blocks the host until the stream has drained - one
+            # pipeline bubble per UNet call.
+            t = torch.full((B,), int(timestep), dtype=torch.int64, device=dev)
         if t.numel() != B:
             raise ValueError(f"timestep must be a scalar or have {B} elements")
         t = t.contiguous()
