@@ -52,6 +52,7 @@ _SIGS = {
     "gyre_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_unet_set_context": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
     "gyre_vae_destroy": (None, [_vp]),

@@ -36,6 +36,7 @@ int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float*
                      bf16_t* y);
 
 // weight repack: OIHW (any dtype) -> [O][KH][KW][Ipad] bf16 ; linear [O][I] -> bf16 (optionally GEGLU-interleaved)
+int launch_nhwc_to_nchw_f32(hipStream_t st, const bf16_t* x, int B, int C, int HW, int Cpad, float* y);
 int launch_repack_conv(hipStream_t st, const void* w, int dtype, int O, int I, int KH, int KW, int Ipad, bf16_t* out,
                        float scale = 1.f);
 int launch_repack_linear(hipStream_t st, const void* w, int dtype, int O, int I, int geglu_interleave, bf16_t* out);

@@ -28,6 +28,19 @@ __global__ void k_nchw_to_nhwc(const void* __restrict__ x, int dtype, int C, int
         *(uint4*)(y + pix * Cpad + c0) = pack8(f);
     }
 }
+// NHWC bf16 (Cpad channels per pixel) -> NCHW f32 (C channels): debug taps only
+__global__ void k_nhwc_to_nchw_f32(const bf16_t* __restrict__ x, int C, int HW, int Cpad, float* __restrict__ y, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW (output order)
+    if (i >= total) return;
+    size_t p = i % HW, c = (i / HW) % C, n = i / ((size_t)HW * C);
+    y[i] = bf16_to_f32(x[(n * HW + p) * Cpad + c]);
+}
+int launch_nhwc_to_nchw_f32(hipStream_t st, const bf16_t* x, int B, int C, int HW, int Cpad, float* y) {
+    size_t total = (size_t)B * C * HW;
+    hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, C, HW, Cpad, y, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
 int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y) {
     size_t total = (size_t)B * HW;
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, dtype, C, HW, Cpad, y,

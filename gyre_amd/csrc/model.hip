@@ -533,6 +533,8 @@ struct gyre_unet {
     struct Level { std::vector<ResW> res; std::vector<TransW> attn; ConvW resample; bool has_resample = false; };
     std::vector<Level> down, up;
     ResW mid0, mid1; TransW mid_attn;
+    // debug taps (parity tests): name -> (device f32 NCHW buffer, capacity in bytes); consumed by the next forward
+    std::map<std::string, std::pair<float*, size_t>> taps;
     // text-context cache (cross-attention K / V^T per layer, and the bf16 copy of the context)
     std::vector<CtxKV> kv_cache;
     void* kv_buf = nullptr; size_t kv_bytes = 0;
@@ -710,6 +712,14 @@ struct gyre_unet {
         e.free(emb); e.free(t1); e.free(t2);
         const float* tproj = (const float*)tp.p;
 
+        auto tap = [&](const std::string& name, const Tn& t, int channels) -> int {
+            if (dry) return 0;
+            auto it = taps.find(name);
+            if (it == taps.end()) return 0;
+            const size_t need = (size_t)t.B * channels * t.H * t.W * sizeof(float);
+            if (it->second.second < need) GYRE_FAIL(GYRE_ERR_INVALID, "tap buffer too small for " + name);
+            return launch_nhwc_to_nchw_f32(st, t.p, t.B, channels, t.H * t.W, t.C, it->second.first);
+        };
         std::vector<Tn> skips;
         Tn h;
         TRY(e.conv3(xin, conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
@@ -731,6 +741,7 @@ struct gyre_unet {
                 TRY(e.conv3(skips.back(), down[i].resample, 2, 1, 0, nullptr, 0, nullptr, d));
                 skips.push_back(d);
             }
+            TRY(tap("down" + std::to_string(i), skips.back(), c.block_out_channels[i]));
         }
         {
             Tn a, b2;
@@ -739,6 +750,7 @@ struct gyre_unet {
             e.free(a);
             TRY(e.resnet(b2, nullptr, mid1, tproj, temb_cols, 1e-5f, h));
             e.free(b2);
+            TRY(tap("mid", h, c.block_out_channels[n - 1]));
         }
         for (int i = 0; i < n; ++i) {
             const int lvl = n - 1 - i;
@@ -759,7 +771,9 @@ struct gyre_unet {
                 TRY(e.conv3(h, up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u));
                 e.free(h); h = u;
             }
+            TRY(tap("up" + std::to_string(i), h, c.block_out_channels[lvl]));
         }
+        if (!dry) taps.clear();
         Tn a;
         TRY(e.groupnorm(h, nullptr, ong, onb, 1e-5f, 1, a));
         e.free(h);
@@ -989,6 +1003,11 @@ int gyre_unet_set_context(gyre_unet* h, void* st, const void* ctx, int cdt, int 
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     if (cdt < 0 || cdt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     return h->set_context((hipStream_t)st, ctx, cdt, B, S);
+}
+int gyre_unet_debug_tap(gyre_unet* h, const char* name, float* out_nchw_f32, size_t out_bytes) {
+    if (!h || !name || !out_nchw_f32) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    h->taps[name] = {out_nchw_f32, out_bytes};
+    return 0;
 }
 int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                          int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add) {

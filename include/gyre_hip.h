@@ -129,6 +129,11 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
  * In the reference the same tensor is re-projected on every call (unet/core.py:253-259 binds it per wrapper). */
 int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_dtype, int B, int S);
 
+/* Parity tests only: the next forward copies the named intermediate activation (f32, NCHW) into out.  Names follow
+ * the oracle's taps: "down<i>" (end of down level i, after its downsampler), "mid", "up<i>" (end of up level i, after
+ * its upsampler).  Taps are cleared by that forward. */
+int gyre_unet_debug_tap(gyre_unet* h, const char* name, float* out_nchw_f32, size_t out_bytes);
+
 /* Same, plus an optional additive term for the time embedding: temb_add[B, 4*block_out_channels[0]] (f32, dev) is
  * added to time_embedding(t) before it feeds the ResNet blocks.  This is how SDXL's `text_time` added conditioning
  * (add_embedding MLP over pooled text + size/crop ids, a few MFLOP) enters: the MLP stays host PyTorch. */

@@ -194,3 +194,36 @@ def test_lora_merge_on_native_unet():
     assert float((with_lora - base).norm() / base.norm()) > 1e-2        # the LoRA really changed the function
     LR.remove_lora_from_model(net)
     assert torch.equal(run(), base)
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_unet_per_level_parity(full):
+    """SURVEY 8(d) per-block gate (bf16 native vs fp32 oracle, rel-L2 <= 2e-2 per block): the activations at the end of
+    every down level, the mid block and every up level, taken from one forward through gyre_unet_debug_tap, against
+    the oracle's taps.  full=True is the SD1.5 architecture at 32x32 latents (CPU oracle stays in seconds)."""
+    import ctypes as C
+    from gyre_amd import _lib
+    cfg = gcfg.sd15_unet() if full else gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    H = W = 32 if full else 16
+    x, t = randn(2, 4, H, W, seed=1), torch.tensor([901, 77])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    taps = {}
+    ref = M.unet_forward(sd, cfg, x, t, ctx, taps=taps)
+    net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))          # uploads weights, creates the handle
+    n = len(cfg.block_out_channels)
+    names = [f"down{i}" for i in range(n)] + ["mid"] + [f"up{i}" for i in range(n)]
+    bufs = {k: torch.empty(taps[k].shape, dtype=torch.float32, device=DEV) for k in names}
+    L = _lib.lib()
+    for k, b in bufs.items():
+        _lib.check(L.gyre_unet_debug_tap(C.c_void_p(net._handle), k.encode(), C.c_void_p(b.data_ptr()), b.numel() * 4))
+    out = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    torch.cuda.synchronize()
+    for k in names:
+        report(f"{'sd15' if full else 'tiny'} unet level {k} {tuple(taps[k].shape)}", bufs[k].cpu(), taps[k], 2e-2)
+    report("unet eps", out.cpu(), ref, 3e-2)
+    # a too-small tap buffer is an error, and taps do not persist into the following forward
+    small = torch.empty(4, device=DEV)
+    _lib.check(L.gyre_unet_debug_tap(C.c_void_p(net._handle), b"mid", C.c_void_p(small.data_ptr()), 16))
+    with pytest.raises(ValueError):
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))
