@@ -66,6 +66,7 @@ struct GemmParams {
     const bf16_t* zero_page = nullptr;      // >= 16 zero bytes in global memory (filled in by launch_gemm)
     int force_cfg = 0;                      // tests/tuning: 0 auto, else tile-config id (see launch_gemm)
     int debug = 0;                          // tuning ablations: bit0 = no operand loads in the K loop, bit1 = no MFMAs
+    int Hup = 0, Wup = 0;         // ups: logical size of the upsampled image (0 = 2*Hi x 2*Wi); < 2x crops the last row/col
     int samples = 0;              // batch entries folded into M (0 = unknown); used by the batch-invariant planner
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;  // fp32 partial slabs [splits][M][N] (see gemm_plan)
 };

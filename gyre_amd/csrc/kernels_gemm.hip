@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
             a_x0[i] = ox * p.stride - p.pad;
         }
     }
-    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+    const int Hlim = p.ups ? (p.Hup ? p.Hup : 2 * p.Hi) : p.Hi, Wlim = p.ups ? (p.Wup ? p.Wup : 2 * p.Wi) : p.Wi;
     const bf16_t* zero = p.zero_page;
 
     auto issue_stage = [&](int kc, int s) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
         }
     }
     const int C2 = p.Cin - p.C1;
-    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+    const int Hlim = p.ups ? (p.Hup ? p.Hup : 2 * p.Hi) : p.Hi, Wlim = p.ups ? (p.Wup ? p.Wup : 2 * p.Wi) : p.Wi;
 
     uint4 ra[AR], rb[BR];
     auto load_stage = [&](int kc) {
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm4d(GemmParams p, int tiles_m, in
             a_x0[i] = ox * p.stride - p.pad;
         }
     }
-    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+    const int Hlim = p.ups ? (p.Hup ? p.Hup : 2 * p.Hi) : p.Hi, Wlim = p.ups ? (p.Wup ? p.Wup : 2 * p.Wi) : p.Wi;
     const bf16_t* zero = p.zero_page;
 
     auto issue_stage = [&](int kc, int s) {

@@ -320,14 +320,20 @@ struct Exec {
         return rc;
     }
     // 3x3 conv; x2 = second channel source (skip concat), rowbias = per-sample channel bias (temb)
+    // ups: nearest-neighbour upsampling fused into the gather.  (Hup, Wup) = size of the upsampled image, by default
+    // 2x; diffusers resizes to the skip connection's size when the latent is not a multiple of 2^levels
+    // (UNet2DConditionModel forward_upsample_size), which for sizes 2H-1 is the 2x image minus its last row / column.
     int conv3(const Tn& x, const ConvW& w, int stride, int pad, int ups, const float* rowbias, int ld_rowbias,
-              const Tn* residual, Tn& y) {
-        int Hin = ups ? 2 * x.H : x.H, Win = ups ? 2 * x.W : x.W;
+              const Tn* residual, Tn& y, int Hup = 0, int Wup = 0) {
+        if (ups && ((Hup && (Hup > 2 * x.H || Hup < 2 * x.H - 1)) || (Wup && (Wup > 2 * x.W || Wup < 2 * x.W - 1))))
+            GYRE_FAIL(GYRE_ERR_INVALID, "upsample target must be 2x or 2x-1 of the input");
+        int Hin = ups ? (Hup ? Hup : 2 * x.H) : x.H, Win = ups ? (Wup ? Wup : 2 * x.W) : x.W;
         int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
         TRY(alloc(y, x.B, Ho, Wo, pad8(w.cout)));
         GemmParams p;
         p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
         p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad; p.ups = ups;
+        p.Hup = ups ? Hin : 0; p.Wup = ups ? Win : 0;
         p.W = w.w; p.K = 9 * x.C; p.N = pad8(w.cout); p.M = x.B * Ho * Wo;
         p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
         if (residual) { p.residual = residual->p; p.ldr = residual->C; }
@@ -680,8 +686,6 @@ struct gyre_unet {
         const gyre_unet_cfg& c = cfg;
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
-        if ((H % (1 << (n - 1))) || (W % (1 << (n - 1))))
-            GYRE_FAIL(GYRE_ERR_INVALID, "unet: latent H, W must be multiples of 2^(n_levels-1)");
         ex.arena.reset((char*)ws, ws_bytes, dry);
         ex.st = st; ex.batch = B;
         Exec& e = ex;
@@ -767,8 +771,8 @@ struct gyre_unet {
                 h = r;
             }
             if (up[i].has_resample) {
-                Tn u;
-                TRY(e.conv3(h, up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u));
+                Tn u;   // resize to the next skip connection's size (= 2x unless the latent size is odd at this level)
+                TRY(e.conv3(h, up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u, skips.back().H, skips.back().W));
                 e.free(h); h = u;
             }
             TRY(tap("up" + std::to_string(i), h, c.block_out_channels[lvl]));

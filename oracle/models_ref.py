@@ -222,7 +222,8 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
                 h = transformer_2d(h, encoder_hidden_states, sd, f"up_blocks.{i}.attentions.{j}",
                                    cfg.num_heads[lvl], g, cfg.transformer_depth[lvl], cfg.use_linear_projection)
         if i < nlev - 1:
-            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            # diffusers resizes to the next skip connection's size (forward_upsample_size) - 2x unless a level is odd
+            h = F.interpolate(h, size=skips[-1].shape[-2:], mode="nearest")
             h = _conv(h, sd, f"up_blocks.{i}.upsamplers.0.conv")
         if taps is not None:
             taps[f"up{i}"] = h

@@ -138,3 +138,16 @@ def test_tiny_sdxl_pipeline_psnr():
     p = PR.psnr(img, ref)
     print(f"[parity] tiny SDXL pipeline: PSNR {p:.1f} dB")
     assert p >= 30.0
+
+
+def test_tiny_txt2img_odd_latent_size_psnr(tiny):
+    """144x112 px -> 18x14 latents (not a multiple of 8): the reference accepts any size divisible by 8 px
+    (unified_pipeline.py:168-173) and diffusers resizes each upsample to its skip connection."""
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    img = pipe(seeds=[5, 6], text_embeddings=text[:2], uncond_embeddings=unc[:2], height=144, width=112,
+               num_inference_steps=5, sampler="euler", hires_fix=False).cpu()
+    ref, _ = PR.generate_ref(usd, ucfg, vsd, vcfg, text[:2], unc[:2], [5, 6], 144, 112, 5, 7.5, "euler",
+                             unet_sample_size=ucfg.sample_size)
+    p = PR.psnr(img, ref)
+    print(f"[parity] tiny txt2img 144x112: PSNR {p:.1f} dB")
+    assert img.shape == (2, 3, 144, 112) and p >= 30.0
