@@ -35,13 +35,18 @@ def empty_prompt_ids(batch: int) -> torch.Tensor:
 class ClipTextEncoder:
     """ids [B,77] -> last_hidden_state [B,77,768] (final LayerNorm applied, as SD1.x uses)."""
 
-    def __init__(self, model, device, dtype=torch.float32):
+    def __init__(self, model, device, dtype=torch.float32, layer="final"):
+        """layer: "final" | "penultimate" | n (n-th hidden state from the end) - the reference's TextEncoderAltLayer
+        (text_encoder_alt_layer.py:6-36, "clip skip"): earlier layers are passed through the final LayerNorm."""
+        if not (layer in ("final", "penultimate") or (isinstance(layer, int) and layer >= 1)):
+            raise ValueError(f"layer must be 'final', 'penultimate' or a positive int, got {layer!r}")
         self.model = model.to(device=device, dtype=dtype).eval()
         self.device = device
+        self.layer = layer
 
     @classmethod
     def synthetic(cls, device="cuda:0", dtype=torch.float32, seed: int = 0, hidden: int = 768, layers: int = 12,
-                  heads: int = 12):
+                  heads: int = 12, layer="final"):
         from transformers import CLIPTextConfig, CLIPTextModel
         cfg = CLIPTextConfig(vocab_size=VOCAB, hidden_size=hidden, intermediate_size=4 * hidden,
                              num_hidden_layers=layers, num_attention_heads=heads, max_position_embeddings=MAX_LEN,
@@ -49,12 +54,21 @@ class ClipTextEncoder:
         torch.manual_seed(seed)
         with torch.device(device):  # initialise straight on the target device (CPU init of 123 M params takes ~15 s)
             model = CLIPTextModel(cfg)
-        return cls(model, device, dtype)
+        return cls(model, device, dtype, layer)
+
+    def _final_layer_norm(self):
+        # transformers <= 4.x nests the tower under .text_model (what the reference uses); 5.x flattens it
+        tower = getattr(self.model, "text_model", self.model)
+        return tower.final_layer_norm
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor) -> torch.Tensor:
-        out = self.model(input_ids=input_ids.to(self.device), return_dict=True)
-        return out.last_hidden_state.float()
+        final = self.layer == "final"
+        out = self.model(input_ids=input_ids.to(self.device), output_hidden_states=not final, return_dict=True)
+        if final:
+            return out.last_hidden_state.float()
+        back = 2 if self.layer == "penultimate" else int(self.layer)
+        return self._final_layer_norm()(out.hidden_states[-back]).float()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -43,3 +43,25 @@ def test_lpw_embedder_long_prompt_chunks():
     assert calls == [(1, 77), (1, 77), (1, 77), (1, 77)]
     short, _ = emb.get_embeddings(["(x:1.5) y"])
     assert short.shape == (1, 77, 8)
+
+
+def test_clip_alt_layer():
+    """TextEncoderAltLayer semantics (reference text_encoder_alt_layer.py:6-36): 'final' = last_hidden_state,
+    'penultimate' / n = final LayerNorm of an earlier hidden state."""
+    import torch
+    from gyre_amd.text import ClipTextEncoder, synthetic_prompt_ids
+    ids = synthetic_prompt_ids(2, seed=3)
+    enc = ClipTextEncoder.synthetic("cpu", hidden=64, layers=3, heads=4, seed=1)
+    with torch.no_grad():
+        full = enc.model(input_ids=ids, output_hidden_states=True, return_dict=True)
+    ln = enc._final_layer_norm()
+    assert torch.allclose(enc(ids), full.last_hidden_state.float())
+    for layer, idx in (("penultimate", -2), (2, -2), (3, -3), (1, -1)):
+        e = ClipTextEncoder(enc.model, "cpu", layer=layer)
+        with torch.no_grad():
+            want = ln(full.hidden_states[idx]).float()
+        assert torch.allclose(e(ids), want, atol=1e-6), layer
+    assert torch.allclose(ClipTextEncoder(enc.model, "cpu", layer=1)(ids), enc(ids), atol=1e-5)   # last state + LN == final
+    import pytest
+    with pytest.raises(ValueError):
+        ClipTextEncoder(enc.model, "cpu", layer="first")
