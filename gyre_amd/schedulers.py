@@ -147,6 +147,20 @@ class KDiffusionUNetWrapper:
         return x + eps * (-float(s))
 
 
+class KDiffusionVUNetWrapper(KDiffusionUNetWrapper):
+    """v-prediction models (SD2.x 768-v): reference common_scheduler.py:350-355 over [3P] k_diffusion
+    DiscreteVDDPMDenoiser with sigma_data = 1:  x0 = v(x * c_in, t(sigma)) * c_out + x * c_skip,
+    c_skip = 1/(sigma^2+1), c_out = -sigma/sqrt(sigma^2+1), c_in = 1/sqrt(sigma^2+1)."""
+
+    def __call__(self, x: Tensor, sigma: Tensor) -> Tensor:
+        s = sigma.reshape(-1)[0].to("cpu", torch.float32)
+        d = float(s ** 2 + 1.0)
+        t = int(self.schedule.sigma_to_t(s))
+        self.evals += 1
+        v = self.inner_model(x * (1.0 / d ** 0.5), t)
+        return v * (-float(s) / d ** 0.5) + x * (1.0 / d)
+
+
 # ------------------------------------------------------------------------------
 # samplers.  `model(x, sigma)` returns the denoised prediction; sigmas is a HOST fp32 tensor.
 # ------------------------------------------------------------------------------
@@ -354,11 +368,15 @@ class KDiffusionScheduler:
         self.eps_unet = self.eps_unets[-1] if self.eps_unets else None
 
     def set_timesteps(self, num_inference_steps: int, start_offset: Optional[int] = None,
-                      strength: Optional[float] = None, config: SchedulerConfig = SchedulerConfig()):
+                      strength: Optional[float] = None, config: SchedulerConfig = SchedulerConfig(),
+                      prediction_type: str = "epsilon"):
         if self.eps_unet is None:
             raise ValueError("Epsilon unet needs to be set before timesteps")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type {prediction_type!r}")
         s = self.schedule
-        self.unets = [KDiffusionUNetWrapper(e, s) for e in self.eps_unets]
+        wrapper = KDiffusionVUNetWrapper if prediction_type == "v_prediction" else KDiffusionUNetWrapper
+        self.unets = [wrapper(e, s) for e in self.eps_unets]
         self.unet = self.unets[-1]
         sigma_min, sigma_max = config.sigma_min, config.sigma_max
         if sigma_min is not None:
@@ -845,9 +863,13 @@ class DiffusersScheduler:
     def set_eps_unet(self, eps_unet):
         self.eps_unet = eps_unet
 
-    def set_timesteps(self, num_inference_steps: int, start_offset=None, strength=None, config=None):
+    def set_timesteps(self, num_inference_steps: int, start_offset=None, strength=None, config=None,
+                      prediction_type: str = "epsilon"):
         if self.eps_unet is None:
             raise ValueError("Epsilon unet needs to be set before timesteps")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type {prediction_type!r}")
+        self.prediction_type = prediction_type
         self.sched.set_timesteps(num_inference_steps)
         if strength is not None:
             init = min(int(num_inference_steps * strength), num_inference_steps)
@@ -874,6 +896,10 @@ class DiffusersScheduler:
         u_off = self.start_offset / max(len(self.sched.timesteps), 1)
         for i, t in enumerate(ts):
             eps = self.eps_unet(x, int(t))
+            if getattr(self, "prediction_type", "epsilon") == "v_prediction":
+                # eps = sqrt(abar) v + sqrt(1 - abar) x   (x0 = sqrt(abar) x - sqrt(1 - abar) v)
+                a = float(self.sched.alphas_cumprod[int(t)])
+                eps = a ** 0.5 * eps + (1 - a) ** 0.5 * x
             self.unet.evals += 1
             x = self.sched.step(eps, int(t), x)
             if d_wrap is not None:

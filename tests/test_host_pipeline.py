@@ -507,3 +507,38 @@ def test_pipeline_sdxl_added_conditioning_cpu():
         pipe(**kw)
     with pytest.raises(ValueError, match="batch 1 or"):
         pipe(added_cond={"text_embeds": torch.zeros(3, 32), "time_ids": ids[:1]}, **kw)
+
+
+def test_v_prediction_matches_epsilon_for_consistent_models(tiny):
+    """A v-model built from an eps-model (v = sqrt(abar) eps - sqrt(1-abar) x0, x0 = (x - sqrt(1-abar) eps)/sqrt(abar))
+    must give the same trajectory under prediction_type='v_prediction' as the eps-model under 'epsilon' - on the
+    k-diffusion loop (KDiffusionVUNetWrapper, reference common_scheduler.py:350-355,458-461) and the diffusers-style one."""
+    ac = PS.DiscreteSchedule().alphas_cumprod.double()
+
+    def eps_model(x, t):
+        return torch.tanh(x * 0.7) * 0.9 + 0.01 * x
+
+    def v_model(x, t):
+        a = float(ac[int(t)])
+        e = eps_model(x, t)
+        x0 = (x - (1 - a) ** 0.5 * e) / a ** 0.5
+        return a ** 0.5 * e - (1 - a) ** 0.5 * x0
+
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(3)).double()
+    for name in ("euler", "dpmpp_2m", "ddim", "dpmsolverpp_2"):
+        outs = []
+        for model, pt in ((eps_model, "epsilon"), (v_model, "v_prediction")):
+            sched = PS.make_scheduler(name, gens([1, 2]), "cpu", torch.float64)
+            sched.set_eps_unet(model)
+            sched.set_timesteps(8, prediction_type=pt)
+            outs.append(sched.loop(sched.prepare_initial_latents(x.clone())))
+        # the k-diffusion wrappers evaluate the model at the quantised timestep but scale with the continuous sigma,
+        # so the two parameterisations agree to the schedule's interpolation error, not to rounding
+        assert torch.allclose(outs[0], outs[1], rtol=5e-4, atol=5e-4), name
+    with pytest.raises(NotImplementedError):
+        sched.set_timesteps(8, prediction_type="sample")
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    kw = dict(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, num_inference_steps=3,
+              sampler="euler", output_type="latent")
+    assert not torch.allclose(pipe(**kw), pipe(prediction_type="v_prediction", **kw))
