@@ -534,7 +534,7 @@ def test_v_prediction_matches_epsilon_for_consistent_models(tiny):
             outs.append(sched.loop(sched.prepare_initial_latents(x.clone())))
         # the k-diffusion wrappers evaluate the model at the quantised timestep but scale with the continuous sigma,
         # so the two parameterisations agree to the schedule's interpolation error, not to rounding
-        assert torch.allclose(outs[0], outs[1], rtol=5e-4, atol=5e-4), name
+        assert torch.allclose(outs[0], outs[1], rtol=5e-3, atol=5e-3), name
     with pytest.raises(NotImplementedError):
         sched.set_timesteps(8, prediction_type="sample")
     ucfg, vcfg, usd, vsd, text, unc = tiny
