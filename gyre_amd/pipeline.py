@@ -246,7 +246,9 @@ class GyrePipeline:
                  output_type: str = "image", callback=None, generator_device: str = "cpu",
                  hires_fix: Optional[bool] = None, hires_oos_fraction: Optional[float] = None,
                  outmask_image: Optional[Tensor] = None, added_cond: Optional[dict] = None,
-                 uncond_added_cond: Optional[dict] = None, prediction_type: str = "epsilon"):
+                 uncond_added_cond: Optional[dict] = None, prediction_type: str = "epsilon",
+                 churn: Optional[float] = None, churn_tmin: float = 0.0, churn_tmax: float = float("inf"),
+                 sigma_min: Optional[float] = None, sigma_max: Optional[float] = None):
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
@@ -334,7 +336,9 @@ class GyrePipeline:
 
         sched.set_eps_unets([l.eps_unet for l in leaves]) if is_k else sched.set_eps_unet(leaves[-1].eps_unet)
         sched.set_timesteps(num_inference_steps, strength=strength if image is not None else None,
-                            config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho), prediction_type=prediction_type)
+                            config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho, churn=churn, churn_tmin=churn_tmin,
+                                                     churn_tmax=churn_tmax, sigma_min=sigma_min, sigma_max=sigma_max),
+                            prediction_type=prediction_type)
         for leaf in leaves:
             leaf.latents = self._leaf_initial_latents(leaf, sched, generators)
 

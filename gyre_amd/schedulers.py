@@ -209,17 +209,34 @@ def get_ancestral_step(sigma_from: Tensor, sigma_to: Tensor, eta: float = 1.0):
     return sigma_down, sigma_up
 
 
+def _churn(x: Tensor, sigmas: Tensor, i: int, s_churn: float, s_tmin: float, s_tmax: float, s_noise: float, noise_sampler):
+    """Karras et al. (2022) Alg. 2 "churn" as in [3P] k_diffusion sample_euler / heun / dpm_2 (the reference passes
+    s_churn / s_tmin / s_tmax from SchedulerConfig, common_scheduler.py:582-588): raise the noise level to
+    sigma_hat = sigma * (1 + gamma) by adding fresh noise before the step.  The noise comes from the per-image
+    generators (the reference routes torch.randn_like there through TorchRandOverride, randtools.py:67-141)."""
+    sigma = sigmas[i]
+    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= float(sigma) <= s_tmax else 0.0
+    sigma_hat = sigma * (gamma + 1)
+    if gamma > 0:
+        if noise_sampler is None:
+            raise ValueError("churn needs a noise_sampler")
+        x = x + noise_sampler(sigma, sigma_hat) * (s_noise * _f((sigma_hat ** 2 - sigma ** 2) ** 0.5))
+    return x, sigma_hat
+
+
 @torch.no_grad()
-def sample_euler(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
+def sample_euler(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, s_churn: float = 0.0, s_tmin: float = 0.0,
+                 s_tmax: float = float("inf"), s_noise: float = 1.0, noise_sampler=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
         if step_cb is not None:
             step_cb(i)
-        denoised = model(x, sigmas[i])
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise, noise_sampler)
+        denoised = model(x, sigma_hat)
         if callback is not None:
-            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        d = (x - denoised) / _f(sigmas[i])
-        x = x + d * _f(sigmas[i + 1] - sigmas[i])
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigma_hat, "denoised": denoised})
+        d = (x - denoised) / _f(sigma_hat)
+        x = x + d * _f(sigmas[i + 1] - sigma_hat)
     return x
 
 
@@ -242,16 +259,18 @@ def sample_euler_ancestral(model, x: Tensor, sigmas: Tensor, noise_sampler=None,
 
 
 @torch.no_grad()
-def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
+def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, s_churn: float = 0.0, s_tmin: float = 0.0,
+                s_tmax: float = float("inf"), s_noise: float = 1.0, noise_sampler=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
         if step_cb is not None:
             step_cb(i)
-        denoised = model(x, sigmas[i])
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise, noise_sampler)
+        denoised = model(x, sigma_hat)
         if callback is not None:
-            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        d = (x - denoised) / _f(sigmas[i])
-        dt = _f(sigmas[i + 1] - sigmas[i])
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigma_hat, "denoised": denoised})
+        d = (x - denoised) / _f(sigma_hat)
+        dt = _f(sigmas[i + 1] - sigma_hat)
         if sigmas[i + 1] == 0:
             x = x + d * dt
         else:
@@ -263,23 +282,25 @@ def sample_heun(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, *
 
 
 @torch.no_grad()
-def sample_dpm_2(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, **_):
+def sample_dpm_2(model, x: Tensor, sigmas: Tensor, callback=None, step_cb=None, s_churn: float = 0.0, s_tmin: float = 0.0,
+                 s_tmax: float = float("inf"), s_noise: float = 1.0, noise_sampler=None, **_):
     sigmas = sigmas.to("cpu", torch.float32)
     for i in range(len(sigmas) - 1):
         if step_cb is not None:
             step_cb(i)
-        denoised = model(x, sigmas[i])
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise, noise_sampler)
+        denoised = model(x, sigma_hat)
         if callback is not None:
-            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        d = (x - denoised) / _f(sigmas[i])
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigma_hat, "denoised": denoised})
+        d = (x - denoised) / _f(sigma_hat)
         if sigmas[i + 1] == 0:
-            x = x + d * _f(sigmas[i + 1] - sigmas[i])
+            x = x + d * _f(sigmas[i + 1] - sigma_hat)
         else:
-            sigma_mid = sigmas[i].log().lerp(sigmas[i + 1].log(), 0.5).exp()
-            x_2 = x + d * _f(sigma_mid - sigmas[i])
+            sigma_mid = sigma_hat.log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            x_2 = x + d * _f(sigma_mid - sigma_hat)
             denoised_2 = model(x_2, sigma_mid)
             d_2 = (x_2 - denoised_2) / _f(sigma_mid)
-            x = x + d_2 * _f(sigmas[i + 1] - sigmas[i])
+            x = x + d_2 * _f(sigmas[i + 1] - sigma_hat)
     return x
 
 
@@ -333,6 +354,8 @@ def get_sigmas_karras(n: int, sigma_min: float, sigma_max: float, rho: float = 7
 class SchedulerConfig:
     eta: Optional[float] = None
     churn: Optional[float] = None
+    churn_tmin: float = 0.0
+    churn_tmax: float = float("inf")
     sigma_min: Optional[float] = None
     sigma_max: Optional[float] = None
     karras_rho: Optional[float] = None
@@ -395,6 +418,7 @@ class KDiffusionScheduler:
             t = torch.linspace(t_max, t_min, num_inference_steps)
             self.sigmas = torch.cat([s.t_to_sigma(t), torch.zeros(1)])
         self.eta = config.eta
+        self.churn, self.churn_tmin, self.churn_tmax = config.churn, config.churn_tmin, config.churn_tmax
         self.num_inference_steps = num_inference_steps
         if strength is not None:
             if start_offset is not None:
@@ -424,6 +448,8 @@ class KDiffusionScheduler:
         by_range, wants_n = kwargs.pop("_range", False), kwargs.pop("_n", False)
         if self.eta is not None:
             kwargs["eta"] = self.eta
+        if getattr(self, "churn", None):
+            kwargs.update(s_churn=self.churn, s_tmin=self.churn_tmin, s_tmax=self.churn_tmax)
         kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
         model = self.unet
         if k_wrap is not None or k_model is not None:

@@ -542,3 +542,42 @@ def test_v_prediction_matches_epsilon_for_consistent_models(tiny):
     kw = dict(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, num_inference_steps=3,
               sampler="euler", output_type="latent")
     assert not torch.allclose(pipe(**kw), pipe(prediction_type="v_prediction", **kw))
+
+
+def test_churn_semantics_and_pipeline_options(tiny):
+    """s_churn raises sigma to sigma_hat = sigma (1 + gamma) with fresh per-image noise (k-diffusion euler / heun / dpm_2);
+    gamma = min(churn / n, sqrt(2) - 1) inside [tmin, tmax], 0 outside; churn = 0 reproduces the plain sampler."""
+    sch = PS.DiscreteSchedule()
+    sigmas = torch.cat([sch.t_to_sigma(torch.linspace(999, 0, 10)), torch.zeros(1)])
+    toy = lambda x, s: x / (1 + float(s) ** 2)
+    x0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1)) * sigmas[0]
+    for fn in (PS.sample_euler, PS.sample_heun, PS.sample_dpm_2):
+        seen = []
+        model = lambda x, s: (seen.append(float(s)), toy(x, s))[1]
+        g = gens([1, 2])
+        ns = lambda a, b: PS.batched_randn([2, 4, 8, 8], g, "cpu", torch.float32)
+        plain = fn(toy, x0, sigmas)
+        assert torch.equal(fn(toy, x0, sigmas, s_churn=0.0, noise_sampler=ns), plain)
+        out = fn(model, x0, sigmas, s_churn=5.0, s_tmin=1.0, s_tmax=10.0, noise_sampler=ns)
+        assert bool(torch.isfinite(out).all()) and not torch.allclose(out, plain)
+        gamma = min(5.0 / 10, 2 ** 0.5 - 1)
+        firsts = {round(float(s), 4) for s in sigmas[:-1]}
+        hats = [s for s in seen if round(s, 4) not in firsts]
+        assert hats, fn.__name__
+        for i in range(10):
+            s = float(sigmas[i])
+            if 1.0 <= s <= 10.0:
+                assert any(abs(h - s * (1 + gamma)) < 1e-4 * s for h in seen), (fn.__name__, s)
+            else:
+                assert any(abs(h - s) < 1e-5 * max(s, 1) for h in seen), (fn.__name__, s)
+    with pytest.raises(ValueError, match="noise_sampler"):
+        PS.sample_euler(toy, x0, sigmas, s_churn=5.0)
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    kw = dict(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, num_inference_steps=4,
+              sampler="euler", output_type="latent")
+    base = pipe(**kw)
+    churned = pipe(churn=2.0, **kw)
+    clipped = pipe(sigma_max=5.0, sigma_min=0.1, **kw)
+    assert not torch.allclose(base, churned) and not torch.allclose(base, clipped)
+    assert torch.equal(churned, pipe(churn=2.0, **kw))
