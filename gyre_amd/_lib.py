@@ -83,6 +83,7 @@ _SIGS = {
     "gyre_op_repack_linear_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gyre_op_repack_bias": (_i, [_vp, _vp, _i, _i, _vp]),
     "gyre_op_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "gyre_op_qkv": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i]),
     "gyre_op_attention_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i]),
     "gyre_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gyre_op_copy_probe": (_i, [_vp, _vp, _vp, _sz]),

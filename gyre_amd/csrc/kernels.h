@@ -63,6 +63,9 @@ struct GemmParams {
     int geglu = 0;                    // W has 2*N_out rows interleaved in 16-row value/gate groups; N == 2*N_out
     void* out = nullptr; int ldc = 0; int out_mode = OUT_BF16; int out_dtype = 1;
     int tokens_per_batch = 0; int ldt = 0;  // OUT_BF16_T: out[(b*N + col)*ldt + tok]
+    // fused Q|K|V projection (8-wave kernels, OUT_BF16): columns >= vt_col0 are written transposed to
+    // vt_out[(b*(N - vt_col0) + col - vt_col0)*ldt + tok] instead of `out` (V^T for the attention kernel)
+    bf16_t* vt_out = nullptr; int vt_col0 = 0;
     const bf16_t* zero_page = nullptr;      // >= 16 zero bytes in global memory (filled in by launch_gemm)
     int force_cfg = 0;                      // tests/tuning: 0 auto, else tile-config id (see launch_gemm)
     int debug = 0;                          // tuning ablations: bit0 = no operand loads in the K loop, bit1 = no MFMAs

@@ -169,6 +169,37 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
     }
 }
 
+// Transposed variant for the V columns of a fused Q|K|V projection: the 16-row slab is read back column-wise, 8
+// consecutive tokens of one channel per lane -> one 16-byte store into V^T[b][channel][token].
+template <int MI, int NI, int TN>
+__device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
+                                                       int fr, int fq, int lane, float* my) {
+    constexpr int rowf = TN + 4;
+    const int cv_total = p.N - p.vt_col0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n_base + j * 16 + 4 * fq;
+            float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (p.bias && n < p.N) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+            *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
+        }
+#pragma unroll
+        for (int v = lane; v < TN * 2; v += 64) {
+            const int col = v >> 1, half = v & 1;
+            const int m = m_base + i * 16 + half * 8, n = n_base + col;
+            if (m < p.M && n < p.N) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = my[(half * 8 + e) * rowf + col];
+                const int b = m / p.tokens_per_batch, t = m - b * p.tokens_per_batch;
+                *(uint4*)(p.vt_out + ((size_t)b * cv_total + (n - p.vt_col0)) * p.ldt + t) = pack8(f);
+            }
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -485,6 +516,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
         (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
         float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
+        if (p.vt_out && n0 + wn * TN >= p.vt_col0) {             // V columns of a fused Q|K|V projection (wave-uniform)
+            gemm_epilogue_staged_t<MI, NI, TN>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+            return;
+        }
         if constexpr (NI % 2 == 0) {
             if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my); return; }
         }
@@ -1114,6 +1149,11 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.geglu && (p.N % 32)) GYRE_FAIL(-1, "gemm: GEGLU needs N % 32 == 0");
     if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
+    if (p.vt_out) {
+        if (p.out_mode != OUT_BF16 || p.geglu || p.residual || p.tokens_per_batch <= 0 || p.tokens_per_batch % 8 || p.ldt % 8 ||
+            p.vt_col0 <= 0 || p.vt_col0 >= p.N || p.N % 8)
+            GYRE_FAIL(-1, "gemm: bad fused Q|K|V arguments");
+    }
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
     if (p.force_cfg) { cfg = p.force_cfg & 0xff; splits = (p.force_cfg >> 8) & 0xff; if (splits < 1) splits = 1; }
@@ -1123,6 +1163,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             splits = 1;   // no slab space: best single-split configuration instead
             cfg = pick_cfg_nosplit(p);
         }
+    }
+    if (p.vt_out) {
+        const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
+        if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
     if (cfg >= 4) {
         if (p.geglu && cfg == 11) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");

@@ -9,6 +9,7 @@
 // their diffusers state-dict keys (gyre/manager.py:1068-1112, gyre/ckpt_utils.py:259-285).
 #include "../../include/gyre_hip.h"
 #include "kernels.h"
+#include <cstdlib>
 #include <cmath>
 
 #include <algorithm>
@@ -235,6 +236,7 @@ struct AttnW {
     int c = 0, heads = 1, kv_dim = 0;
     bf16_t *wqk = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
     int k_prescaled = 0;         // to_k weights carry the softmax scale (UNet attention; not the VAE block)
+    bool qkv_fused = false;      // wqk holds [3C][C] = Q | K | V rows (UNet self-attention)
     float *bqk = nullptr, *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;
 };
 struct TBlockW {
@@ -382,9 +384,26 @@ struct Exec {
         if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, 2 * C));
-            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
             TRY(alloc(vt, B, C, 1, ldvt));
-            TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
+            bool fused = false;
+            if (w.qkv_fused && !w.bqk && !w.bv && Nq % 8 == 0) {
+                // Q | K | V in one launch: the V tiles write V^T through the transposing epilogue (needs an 8-wave
+                // tile config whose wave tiles line up with the V columns; else two launches as before)
+                GemmParams p;
+                p.A = xq.p; p.lda = C; p.mode = GEMM_LINEAR; p.W = w.wqk; p.K = C; p.N = 3 * C; p.M = B * Nq; p.samples = B;
+                p.out = q.p; p.ldc = 2 * C; p.out_mode = OUT_BF16;
+                p.vt_out = vt.p; p.vt_col0 = 2 * C; p.tokens_per_batch = Nq; p.ldt = ldvt;
+                GemmPlan pl = gemm_plan(p);
+                const int tn = pl.cfg == 4 ? 160 : pl.cfg == 5 ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
+                if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
+                    fused = true;
+                    if (!dry()) TRY(launch_gemm(st, p));
+                }
+            }
+            if (!fused) {
+                TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
+                TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
+            }
             qp = q.p; kp = dry() ? nullptr : q.p + C; vtp = vt.p; ldq = ldk = 2 * C;
         } else {
             Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
@@ -491,16 +510,19 @@ static void reg_attn(Store& s, const std::string& p, int c, int heads, int kv_di
     // The softmax scale log2(e)/sqrt(head_dim) is folded into the K projection weights (fp32, before their one bf16
     // rounding): S = q.k then arrives from the matrix core already in the exp2 domain (AttnParams::k_prescaled)
     const float kscale = 1.4426950408889634f / sqrtf((float)(c / heads));
-    if (self) {
-        w.wqk = (bf16_t*)s.dmalloc((size_t)2 * c * c * 2, true);
+    if (self) {   // one [3C][C] matrix: rows Q | K | V, so that the three projections can run as a single GEMM
+        w.wqk = (bf16_t*)s.dmalloc((size_t)3 * c * c * 2, true);
         s.add(p + ".to_q.weight", {c, c}, PK_MAT, w.wqk, c, c);
         s.add(p + ".to_k.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c)->scale = kscale;
+        w.wv = w.wqk + (size_t)2 * c * c;
+        s.add(p + ".to_v.weight", {c, c}, PK_MAT, w.wv, c, c);
+        w.qkv_fused = true;
     } else {
         w.wq = s.mat(p + ".to_q", c, c, false, false, nullptr);
         w.wk = s.mat(p + ".to_k", c, kv_dim, false, false, nullptr);
         s.by_key[p + ".to_k.weight"]->scale = kscale;
+        w.wv = s.mat(p + ".to_v", c, kv_dim, false, false, nullptr);
     }
-    w.wv = s.mat(p + ".to_v", c, kv_dim, false, false, nullptr);
     w.wo = s.mat(p + ".to_out.0", c, c, false, true, &w.bo);
 }
 static void reg_transformer(Store& s, const std::string& p, int c, int heads, int ctx_dim, int depth, bool linproj,
@@ -1164,6 +1186,16 @@ int gyre_op_attention(void* st, const void* q, int ldq, const void* k, int ldk, 
     a.q = (const bf16_t*)q; a.ldq = ldq; a.k = (const bf16_t*)k; a.ldk = ldk; a.vt = (const bf16_t*)vt; a.ldvt = ldvt;
     a.o = (bf16_t*)o; a.ldo = ldo; a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
     return launch_attention((hipStream_t)st, a);
+}
+int gyre_op_qkv(void* st, const void* x, int M, int C, const void* w_qkv, int tokens, void* qk_out, void* vt_out, int ldt) {
+    if (!x || !w_qkv || !qk_out || !vt_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (tokens <= 0 || M % tokens) GYRE_FAIL(GYRE_ERR_INVALID, "M must be a multiple of tokens");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = C; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w_qkv; p.K = C; p.N = 3 * C; p.M = M;
+    p.samples = M / tokens;
+    p.out = qk_out; p.ldc = 2 * C; p.out_mode = OUT_BF16;
+    p.vt_out = (bf16_t*)vt_out; p.vt_col0 = 2 * C; p.tokens_per_batch = tokens; p.ldt = ldt;
+    return launch_gemm((hipStream_t)st, p);
 }
 int gyre_op_attention_ex(void* st, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int B,
                          int heads, int Nq, int Nk, int D, void* o, int ldo, int k_prescaled) {

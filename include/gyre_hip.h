@@ -221,6 +221,11 @@ int gyre_op_repack_bias(void* stream, const float* b, int n, int geglu_interleav
 /* o[B,Nq,H*D] = softmax(q k^T * D^-1/2) v ; q[B,Nq,H*D] (ldq), k[B,Nk,H*D] (ldk), vt[B,H*D,ldvt] (V transposed) */
 int gyre_op_attention(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                       int B, int heads, int Nq, int Nk, int D, void* o, int ldo);
+/* Fused Q|K|V projection as the UNet self-attention runs it: x[M,C] (bf16) times w_qkv[3C,C] (rows Q | K | V, repacked
+ * with gyre_op_repack_linear_weight) -> qk_out[M,2C] row-major and vt_out[M/tokens][C][ldt] = V transposed per batch
+ * entry.  Needs an 8-wave tile configuration whose wave tiles align with column 2C (GYRE_ERR_UNSUPPORTED otherwise;
+ * the model then issues two GEMMs). */
+int gyre_op_qkv(void* stream, const void* x, int M, int C, const void* w_qkv, int tokens, void* qk_out, void* vt_out, int ldt);
 /* Same, k_prescaled != 0: k already holds k * log2(e)/sqrt(D) (the UNet folds that factor into its to_k weights in
  * fp32 before their bf16 rounding), which lets the kernel take exp2 of the matrix-core output directly. */
 int gyre_op_attention_ex(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,

@@ -485,3 +485,39 @@ def test_attention_prescaled_peaked_and_drifting_max():
                 L.gyre_debug_force_attn_variant(old)
             assert bool(torch.isfinite(o).all())
             report(f"attention prescaled v{variant} {name}", o.float().cpu(), ref, 3e-2)
+
+
+@pytest.mark.parametrize("cfg,B,tokens,C", [(0, 16, 4096, 320), (4, 4, 1024, 320), (5, 2, 1024, 320), (6, 2, 1024, 640), (7, 2, 512, 640),
+                                            (0, 16, 1024, 640), (5, 3, 264, 320)])
+def test_fused_qkv_projection(cfg, B, tokens, C):
+    """Q | K | V in one GEMM launch; the V tiles go through the transposing epilogue into V^T[b][c][token]."""
+    L = _lib.lib()
+    M = B * tokens
+    x = bf16_round(randn(M, C, seed=80))
+    w = bf16_round(randn(3 * C, C, seed=81) / math.sqrt(C))
+    ref = F.linear(x, w)
+    qk = torch.empty(M, 2 * C, dtype=torch.bfloat16, device=DEV)
+    ldt = tokens
+    vt = torch.full((B, C, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_qkv(st(), vp(to_dev_bf16(x)), M, C, vp(repack_linear(w)), tokens, vp(qk), vp(vt), ldt))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"qkv cfg{cfg} QK part", qk.float().cpu(), ref[:, :2 * C], TOL)
+    v_ref = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
+    report(f"qkv cfg{cfg} V^T part", vt.float().cpu(), v_ref, TOL)
+
+
+def test_fused_qkv_rejects_unaligned_configs():
+    L = _lib.lib()
+    x = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(960, 320, dtype=torch.bfloat16, device=DEV)
+    qk = torch.empty(256, 640, dtype=torch.bfloat16, device=DEV); vt = torch.empty(1, 320, 256, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(1)     # 4-wave config: no transposing epilogue
+    try:
+        rc = L.gyre_op_qkv(st(), vp(x), 256, 320, vp(w), 256, vp(qk), vp(vt), 256)
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    assert rc == -6
+    assert L.gyre_op_qkv(st(), vp(x), 256, 320, vp(w), 100, vp(qk), vp(vt), 256) == -1   # tokens must divide M
