@@ -522,9 +522,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
 // the top of step t and the slot of tile t-1 is refilled right after that barrier.  Loads past the last tile are
 // issued against the zero page so that the in-flight count stays constant (drained before the wave ends).
 // ------------------------------------------------------------------------------------------------
-template <int D, int PD>
+template <int D, int PD, int QI = 2>
 __global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* zero) {
-    constexpr int QI = 2;
     constexpr int NS = PD + 2;
     // (a 16-wide v_mfma_f32_16x16x16_bf16 step for the head-dim remainder - D = 40 as 32 + 16 instead of 64 - was
     // measured: no faster (the matrix core is not the limiter) and a dependent x32 -> x16 chain on one accumulator
@@ -858,7 +857,7 @@ static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     return 0;
 }
 
-template <int D>
+template <int D, int QI = 2>
 static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     constexpr int DO = (D + 15) / 16;
     constexpr int RAW = 64 * D * 2 + DO * 16 * 128;
@@ -867,13 +866,13 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     const size_t lds = (size_t)(PD + 2) * STAGE;
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
-    auto kern = k_attn3<D, PD>;
+    auto kern = k_attn3<D, PD, QI>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((unsigned)(((p.Nq + 127) / 128) * p.B * p.H));
+    dim3 grid((unsigned)(((p.Nq + 64 * QI - 1) / (64 * QI)) * p.B * p.H));
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
@@ -908,6 +907,7 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     const int var = g_attn_variant;
     // software-pipelined folded kernel; with only a couple of key tiles (cross-attention, Nk = 77) its longer prologue
     // costs more than the overlap wins (measured 47.8 vs 41.1 us), so short key sequences stay on the v2 form
+    // (48 query rows per wave, QI = 3, was tried for D = 40: 232 B/lane of spills at 2 waves/SIMD - not built)
     if (p.k_prescaled && ((var == 0 && p.Nk >= 256) || var == 5)) {
         switch (p.D) {
             case 16: return launch_attn3_t<16>(st, p);
