@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
 // issued against the zero page so that the in-flight count stays constant (drained before the wave ends).
 // ------------------------------------------------------------------------------------------------
 template <int D, int PD, int QI = 2>
-__global__ __launch_bounds__(256, 2) void k_attn3(AttnParams p, const bf16_t* zero) {
+__global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, const bf16_t* zero) {
     constexpr int NS = PD + 2;
     // (a 16-wide v_mfma_f32_16x16x16_bf16 step for the head-dim remainder - D = 40 as 32 + 16 instead of 64 - was
     // measured: no faster (the matrix core is not the limiter) and a dependent x32 -> x16 chain on one accumulator
@@ -908,6 +908,8 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     // software-pipelined folded kernel; with only a couple of key tiles (cross-attention, Nk = 77) its longer prologue
     // costs more than the overlap wins (measured 47.8 vs 41.1 us), so short key sequences stay on the v2 form
     // (48 query rows per wave, QI = 3, was tried for D = 40: 232 B/lane of spills at 2 waves/SIMD - not built)
+    // (64 rows per wave at ONE wave per SIMD, QI = 4 with 412 registers: 625 vs 619 us at 64x64, 10-40 % slower on
+    //  the smaller shapes - not built)
     if (p.k_prescaled && ((var == 0 && p.Nk >= 256) || var == 5)) {
         switch (p.D) {
             case 16: return launch_attn3_t<16>(st, p);

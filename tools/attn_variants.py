@@ -33,7 +33,7 @@ for (B, h, Nq, Nk, D, scale) in [(16, 8, 4096, 4096, 40, 1.0), (16, 8, 1024, 102
     for var in variants:
         L.gyre_debug_force_attn_variant(var)
         o = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=DEV)
-        if var in (3, 5):      # prescaled-K path: 3 = folded v2 kernel, 5 = software-pipelined v3
+        if var in (3, 5, 6):      # prescaled-K path: 3 = folded v2 kernel, 5 = software-pipelined v3
             L.gyre_debug_force_attn_variant(var)
             run = lambda: L.gyre_op_attention_ex(st(), vp(q), Cc, vp(kpre), Cc, vp(vt), ldvt, B, h, Nq, Nk, D, vp(o), Cc, 1)
         else:
