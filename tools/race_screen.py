@@ -1,0 +1,80 @@
+"""Race screen (GPU): the LDS-DMA kernels order their tiles with counted vmcnt + barriers, so a placement bug would show as
+rare wrong tiles that come and go with shape and memory load.  Randomised shapes, every kernel run several times under
+background memory traffic, results compared bit-for-bit with the first run and against an independent kernel family."""
+import ctypes as C, math, os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gyre_amd import _lib
+L = _lib.lib(); DEV = "cuda:0"
+vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N_ATT, N_GEMM, REPS = 60, 60, 4
+noise_src = torch.randn(64 << 20, device=DEV)           # 256 MB streamed on a side stream as background load
+side = torch.cuda.Stream()
+def background():
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            noise_src.add_(1e-3)
+bad = 0
+for it in range(N_ATT):
+    D = rng.choice([40, 40, 64, 80, 32])
+    h = rng.choice([1, 2, 5, 8]); B = rng.choice([1, 2, 3])
+    Nq = rng.choice([64, 100, 256, 1000, 1024, 2304, 4096]); Nk = rng.choice([256, 333, 1024, 1003, 2304, 4096])
+    Cc = h * D
+    g = torch.Generator(device=DEV).manual_seed(it)
+    q = torch.randn(B, Nq, Cc, device=DEV, generator=g).to(torch.bfloat16)
+    k = (torch.randn(B, Nk, Cc, device=DEV, generator=g) * (1.4426950408889634 / math.sqrt(D))).to(torch.bfloat16)
+    ldvt = (Nk + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, ldvt, dtype=torch.bfloat16, device=DEV); vt[:, :, :Nk] = torch.randn(B, Cc, Nk, device=DEV, generator=g).to(torch.bfloat16)
+    outs = {}
+    for var in (5, 2):          # pipelined v3 vs plain v2 (both take the prescaled K)
+        L.gyre_debug_force_attn_variant(var)
+        first = None
+        for r in range(REPS):
+            o = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=DEV)
+            background()
+            rc = L.gyre_op_attention_ex(st(), vp(q), Cc, vp(k), Cc, vp(vt), ldvt, B, h, Nq, Nk, D, vp(o), Cc, 1)
+            assert rc == 0, (rc, L.gyre_last_error())
+            torch.cuda.synchronize()
+            if first is None: first = o
+            elif not torch.equal(o, first):
+                bad += 1; print("ATTN NONDETERMINISTIC", var, B, h, Nq, Nk, D)
+        outs[var] = first.float()
+    err = float((outs[5] - outs[2]).norm() / outs[2].norm())
+    if not (err < 8e-3):
+        bad += 1; print("ATTN MISMATCH v3 vs v2", B, h, Nq, Nk, D, err)
+L.gyre_debug_force_attn_variant(0)
+ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
+for it in range(N_GEMM):
+    conv = rng.random() < 0.5
+    g = torch.Generator(device=DEV).manual_seed(1000 + it)
+    if conv:
+        Bc = rng.choice([1, 2, 4]); H = rng.choice([8, 16, 24, 32, 33]); W = rng.choice([8, 16, 20, 32]); Ci = rng.choice([64, 128, 320, 640]); Co = rng.choice([320, 640, 1280])
+        x = torch.randn(Bc, H, W, Ci, device=DEV, generator=g).to(torch.bfloat16); w = (torch.randn(Co, 9 * Ci, device=DEV, generator=g) / math.sqrt(9 * Ci)).to(torch.bfloat16)
+        run = lambda y: L.gyre_op_conv3x3(st(), vp(x), Bc, H, W, Ci, vp(w), Co, None, None, 1, 0, 0, vp(y))
+        mk = lambda: torch.empty(Bc, H, W, Co, dtype=torch.bfloat16, device=DEV)
+        desc = ("conv", Bc, H, W, Ci, Co)
+    else:
+        M = rng.choice([256, 777, 4096, 10000, 16384]); K = rng.choice([320, 640, 1280, 2560]); N = rng.choice([320, 640, 1280])
+        x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16); w = (torch.randn(N, K, device=DEV, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        run = lambda y: L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, None, None, 0, vp(y))
+        mk = lambda: torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        desc = ("linear", M, K, N)
+    ref = None
+    for cfg in (1, 4, 5, 6, 7, 13, 0):
+        L.gyre_debug_force_gemm_cfg(cfg)
+        for r in range(REPS if cfg else 2):
+            y = mk(); background()
+            rc = run(y)
+            if rc != 0: break
+            torch.cuda.synchronize()
+            if ref is None: ref = y
+            elif cfg != 0 and not torch.equal(y, ref):
+                bad += 1; print("GEMM MISMATCH", desc, "cfg", cfg, float((y.float() - ref.float()).abs().max()))
+            elif cfg == 0 and float((y.float() - ref.float()).norm() / ref.float().norm()) > 4e-3:   # planner may split K
+                bad += 1; print("GEMM PLANNER MISMATCH", desc)
+L.gyre_debug_force_gemm_cfg(0)
+print("race screen: problems =", bad)
+sys.exit(1 if bad else 0)
