@@ -229,7 +229,13 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int ntiles = tiles_m * tiles_n;
     const int split = blockIdx.x / ntiles;
     const int bid = xcd_tile_id(blockIdx.x - split * ntiles, ntiles);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    // Within an XCD chunk, run fastest along the dimension whose operand is SMALL so that the big operand is shared by
+    // neighbouring workgroups in that L2.  Usually the activations are the big one (tn fastest: same A rows).  In the
+    // deep UNet levels the weights dominate (8x8 level: 1024 rows of 1280 channels vs 29 MB of weights): there tm
+    // runs fastest, so the workgroups of one XCD stream the same weight slice together (measured +14-17 % on the
+    // 8x8 convs, +1 % at 16x16; debug bit 8 forces the default order).
+    const bool tm_fast = (long)p.M < (MODE == GEMM_CONV3 ? 9L : 1L) * p.N && !(p.debug & 0x100);
+    const int tn = tm_fast ? bid / tiles_m : bid % tiles_n, tm = tm_fast ? bid % tiles_m : bid / tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

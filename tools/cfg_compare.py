@@ -7,7 +7,7 @@ L = _lib.lib(); DEV = "cuda:0"
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 rnd = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
-cfgs = [int(a, 0) for a in sys.argv[1:]] or [0, 4, 5, 9]   # cfg | splits << 8
+cfgs = [int(a, 0) for a in sys.argv[1:]] or [0, 4, 5, 9]   # cfg | splits << 8 | ablation bits << 16
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
 L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
 def timeit(fn, iters=8):
@@ -26,9 +26,9 @@ for (Bc, H, W, Ci, Co) in [(B,64,64,320,320),(B,64,64,960,320),(B,32,32,320,640)
     fl = 2.0 * Bc * H * W * Co * 9 * Ci
     r = []
     for c in cfgs:
-        L.gyre_debug_force_gemm_cfg(c)
+        L.gyre_debug_force_gemm_cfg(c & 0xffff); L.gyre_debug_gemm_ablation(c >> 16)
         rc = L.gyre_op_conv3x3(st(), vp(x), Bc, H, W, Ci, vp(w), Co, vp(b), None, 1, 0, 0, vp(y))
-        r.append(f"cfg{c&255}s{c>>8}: {fl/timeit(lambda: L.gyre_op_conv3x3(st(), vp(x), Bc, H, W, Ci, vp(w), Co, vp(b), None, 1, 0, 0, vp(y)))/1e6:6.0f}" if rc == 0 else f"cfg{c&255}s{c>>8}:   n/a")
+        r.append(f"cfg{c&255}s{(c>>8)&255}/{c>>16:#x}: {fl/timeit(lambda: L.gyre_op_conv3x3(st(), vp(x), Bc, H, W, Ci, vp(w), Co, vp(b), None, 1, 0, 0, vp(y)))/1e6:6.0f}" if rc == 0 else f"cfg{c&255}s{c>>8}:   n/a")
     print(f"conv {Bc}x{H}x{W} {Ci:4d}->{Co:4d}: " + " | ".join(r) + " TF/s")
 for (M, K, N, res) in [(65536,320,320,1),(65536,320,640,0),(65536,1280,320,1),(16384,640,640,1),(16384,640,1280,0),(16384,2560,640,1),(4096,1280,1280,1),(4096,5120,1280,1)]:
     x, w, b = rnd(M, K), rnd(N, K), torch.zeros(N, device=DEV)
@@ -40,4 +40,4 @@ for (M, K, N, res) in [(65536,320,320,1),(65536,320,640,0),(65536,1280,320,1),(1
         rc = L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), vp(rs), 0, vp(y))
         r.append(f"cfg{c&255}s{c>>8}: {timeit(lambda: L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), vp(rs), 0, vp(y))):6.1f}us" if rc == 0 else f"cfg{c&255}s{c>>8}:   n/a")
     print(f"linear {M}x{K}x{N} res={res}: " + " | ".join(r))
-L.gyre_debug_force_gemm_cfg(0)
+L.gyre_debug_force_gemm_cfg(0); L.gyre_debug_gemm_ablation(0)
