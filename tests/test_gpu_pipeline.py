@@ -151,3 +151,36 @@ def test_tiny_txt2img_odd_latent_size_psnr(tiny):
     p = PR.psnr(img, ref)
     print(f"[parity] tiny txt2img 144x112: PSNR {p:.1f} dB")
     assert img.shape == (2, 3, 144, 112) and p >= 30.0
+
+
+def test_every_sampler_and_option_edge_cases(tiny):
+    """Every sampler name with 1 and 2 steps, CFG modes, strength end points, inpaint strength 2, Karras schedule, eta 0:
+    finite output of the right shape; CFG parallel == sequential bit for bit (batch equivariance of the kernels)."""
+    from gyre_amd import schedulers as S
+    ucfg, vcfg, usd, vsd, pipe, text, unc = tiny
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(1, 3, 128, 128, generator=g)
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1
+    base = dict(seeds=[1], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, output_type="latent")
+
+    def run(**kw):
+        out = pipe(**{**base, **kw})
+        assert out.shape == (1, 4, 16, 16) and bool(torch.isfinite(out).all()), kw
+        return out
+
+    for s in list(S.SAMPLERS) + list(S.DIFFUSERS_SAMPLERS):
+        for n in (1, 2):
+            run(sampler=s, num_inference_steps=n)
+    a = run(sampler="euler", num_inference_steps=3, cfg_execution="sequential")
+    b = run(sampler="euler", num_inference_steps=3)
+    assert torch.equal(a, b)
+    run(sampler="euler", num_inference_steps=3, guidance_scale=1.0)
+    for st_ in (0.0, 0.01, 1.0):
+        run(sampler="dpmpp_2m", num_inference_steps=4, image=img, strength=st_)
+    run(sampler="euler_a", num_inference_steps=4, image=img, mask_image=mask, strength=2.0)
+    run(sampler="plms", num_inference_steps=4, image=img, mask_image=mask, strength=0.5)
+    run(sampler="heun", num_inference_steps=4, karras_rho=7.0)
+    run(sampler="euler_a", num_inference_steps=4, eta=0.0)
+    run(sampler="heun", num_inference_steps=4, churn=3.0)
+    run(sampler="euler", num_inference_steps=4, prediction_type="v_prediction")
