@@ -1050,6 +1050,192 @@ static int launch_cfg4d(hipStream_t st, const GemmParams& p, int kcls_base, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv with HALO REUSE (stride 1, pad 1, whole image rows per tile).  The implicit-GEMM kernels above fetch the A
+// tile of every tap from L2 again (nine shifted copies of nearly the same pixels); here the input window of a tile -
+// its R = BM / W image rows plus one halo row above / below and one zero column left / right - is brought into LDS
+// ONCE per 32-channel chunk and the nine taps read it at shifted row offsets.  Per chunk the L2->LDS traffic drops
+// from 9 x (A + B) to A_window + 9 x B  (256x320 tile at 64x64: 324 KB -> 205 KB, -37 %), on the path that limits
+// the other kernels.  K order: 32-channel chunk outer, tap inner (so not bit-identical to the 64-channel-chunk
+// kernels; the planner picks it from per-sample shape only, see pick_cfg).
+// LDS: window [ (R+2) x (W+2) rows ][ 64 B ] double-buffered per chunk + weight tiles [BN][64 B] of two taps,
+// double-buffered per barrier step; 16-byte slots XOR-swizzled with (row >> 2) & 3 on the DMA source and on the ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512) void k_conv8h(GemmParams p, int tiles_m, int tiles_n) {
+    constexpr int BM = 256, WM = 4, WN = 2, BKS = 32;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 16, NI = TN / 16;
+    constexpr int BI = (BN / 16 + 7) / 8;            // weight-tile DMA instructions per wave (16 rows each, 8 waves)
+    constexpr int BBYTES = BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int ntiles = tiles_m * tiles_n;
+    const int bid = xcd_tile_id(blockIdx.x, ntiles);
+    const int tn = bid % tiles_n, tm = bid / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rl = lane >> 2;
+    const int gsrc = (lane & 3) ^ ((lane >> 4) & 3);   // k-granule this lane fetches into slot (lane & 3)
+
+    const int W = p.Wi, H = p.Hi, W2 = W + 2;
+    const int R = BM / W;                              // image rows per tile (host guarantees BM % W == 0, H % R == 0)
+    const int wrows = (R + 2) * W2;
+    const int wbytes = (wrows * 64 + 1023) & ~1023;    // window buffer, whole DMA instructions
+    const int nwi = wbytes / 1024;                     // wave-instructions per window
+    const int hw = H * W;
+    const int ns = m0 / hw, y0 = (m0 - ns * hw) / W;   // sample and first image row of this tile
+    char* wbuf0 = smem_raw;
+    char* bbuf0 = smem_raw + 2 * wbytes;
+    const bf16_t* zero = p.zero_page;
+
+    // window rows staged by this lane: instruction q = wave + 8*i covers rows 16q .. 16q+15
+    constexpr int WI_MAX = 5;                          // up to (R+2)(W+2) <= 640 rows  (W >= 16)
+    int wpix[WI_MAX];
+#pragma unroll
+    for (int i = 0; i < WI_MAX; ++i) {
+        const int q = wave + 8 * i;
+        const int wr = q * 16 + rl;
+        int pix = -1;
+        if (q < nwi && wr < wrows) {
+            const int ry = wr / W2, cx = wr - ry * W2;
+            const int y = y0 - 1 + ry, x = cx - 1;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) pix = ns * hw + y * W + x;
+        }
+        wpix[i] = pix;
+    }
+    auto issue_window = [&](int chunk, int s) {
+        char* dst = wbuf0 + s * wbytes;
+        const int c = chunk * BKS + gsrc * 8;
+        const bool first = c < p.C1;
+#pragma unroll
+        for (int i = 0; i < WI_MAX; ++i) {
+            const int q = wave + 8 * i;
+            if (q < nwi) {                              // wave-uniform
+                const bf16_t* src = zero;
+                if (wpix[i] >= 0) src = first ? p.A + (size_t)wpix[i] * p.lda + c : p.A2 + (size_t)wpix[i] * p.lda2 + (c - p.C1);
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_weights_to = [&](int chunk, int tap, char* dst) {
+        const int kw = tap * p.Cin + chunk * BKS + gsrc * 8;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int q = wave + 8 * i;
+            if (q * 16 < BN) {                          // wave-uniform
+                const int n = n0 + q * 16 + rl;
+                const bf16_t* src = n < p.N ? p.W + (size_t)n * p.K + kw : zero;
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // window row of (output row r, tap 0): (ty + 0) * (W+2) + (tx + 0)
+    int abase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * TM + i * 16 + fr;
+        const int ty = r / W, tx = r - ty * W;
+        abase[i] = ty * W2 + tx;
+    }
+    f32x4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Taps are a flat stream g = chunk * 9 + tap; one barrier step handles TWO of them (80 MFMAs per wave between
+    // barriers, like the BK = 64 kernels), pairs may straddle a chunk boundary - both windows are resident.
+    const int nchunks = p.Cin / BKS;
+    const int G = 9 * nchunks;
+    auto issue_pair = [&](int g, int s) {        // weight tiles of taps g, g+1 into pair buffer s
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (g + h < G) { const int c = (g + h) / 9; issue_weights_to(c, g + h - 9 * c, bbuf0 + (2 * s + h) * BBYTES); }
+    };
+    issue_window(0, 0);
+    issue_pair(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int next_win = 1;
+    for (int g0 = 0, st = 0; g0 < G; g0 += 2, ++st) {
+        const int cur = st & 1;
+        const int c_lo = g0 / 9;
+        // window next_win goes into the buffer chunk next_win - 2 used: free once every tap below 9 * (next_win - 1) is done
+        if (next_win < nchunks && next_win - 1 <= c_lo) { issue_window(next_win, next_win & 1); ++next_win; }
+        issue_pair(g0 + 2, cur ^ 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = g0 + h;
+            if (g < G) {                                              // wave-uniform
+                const int chunk = g / 9, tap = g - 9 * chunk;
+                const char* wb = wbuf0 + (chunk & 1) * wbytes;
+                const char* bb = bbuf0 + (2 * cur + h) * BBYTES;
+                const int toff = (tap / 3) * W2 + (tap % 3);
+                bf16x8_t af[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int wr = abase[i] + toff;
+                    af[i] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(wb + wr * 64 + ((fq ^ ((wr >> 2) & 3)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int r = wn * TN + j * 16 + fr;
+                    bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(bb + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int n_out = p.N;
+    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
+        float* my = (float*)smem_raw + wave * (16 * (TN + 4));
+        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+        return;
+    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+}
+
+// can the halo kernel run this problem?  (per-sample shape only - the batch size never enters)
+static bool conv8h_eligible(const GemmParams& p, int BN) {
+    if (p.mode != GEMM_CONV3 || p.stride != 1 || p.pad != 1 || p.ups || p.geglu || p.out_mode != OUT_BF16) return false;
+    if (p.Cin % 32 || p.C1 % 32 || p.N % BN) return false;
+    const int W = p.Wi, H = p.Hi;
+    if (W < 16 || 256 % W) return false;
+    const int R = 256 / W;
+    if (R > H || H % R) return false;
+    if ((R + 2) * (W + 2) > 5 * 8 * 16) return false;                     // WI_MAX instructions per lane
+    const size_t lds = 2 * (size_t)((((R + 2) * (W + 2) * 64) + 1023) & ~1023) + 4 * (size_t)BN * 64;
+    return lds <= 160 * 1024 && (size_t)8 * 16 * (BN / 2 + 4) * 4 <= lds;   // staged epilogue reuses the operand LDS
+}
+template <int BN>
+static int launch_conv8h(hipStream_t st, const GemmParams& p, int kcls) {
+    const int tiles_m = p.M / 256, tiles_n = p.N / BN;
+    const int W = p.Wi, R = 256 / W;
+    const size_t lds = 2 * (size_t)((((R + 2) * (W + 2) * 64) + 1023) & ~1023) + 4 * (size_t)BN * 64;
+    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
+                        (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0 + (double)p.N * p.K * 2.0 +
+                            (double)p.M * p.N * 2.0 * (p.residual ? 2.0 : 1.0));
+    auto kern = k_conv8h<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, p, tiles_m, tiles_n);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 // Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
 // 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256.
 static int pick_cfg(const GemmParams& p, int* splits_out) {
@@ -1197,6 +1383,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         // experiment: phased ("8-phase") K loop, see the NST == 4 branch of k_gemm8.  Only the 256x256 tile is built: the
         // 256x320 form needs > 256 registers and a counted-vmcnt kernel must not spill.
         case 13: return launch_cfg8<256, 256, 4, 2, 4>(st, p, KC_G8_CONV_256x256, splits);
+        case 16: if (!conv8h_eligible(p, 320)) GYRE_FAIL(-6, "gemm: halo conv kernel does not apply to this problem");
+                 return launch_conv8h<320>(st, p, KC_G8_CONV_256x320);
+        case 17: if (!conv8h_eligible(p, 256)) GYRE_FAIL(-6, "gemm: halo conv kernel does not apply to this problem");
+                 return launch_conv8h<256>(st, p, KC_G8_CONV_256x256);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }

@@ -521,3 +521,39 @@ def test_fused_qkv_rejects_unaligned_configs():
         L.gyre_debug_force_gemm_cfg(old)
     assert rc == -6
     assert L.gyre_op_qkv(st(), vp(x), 256, 320, vp(w), 100, vp(qk), vp(vt), 256) == -1   # tokens must divide M
+
+
+@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,res", [(16, 2, 32, 32, 320, 640, True), (16, 1, 64, 64, 64, 320, False), (17, 2, 16, 16, 128, 1280, True),
+                                                    (16, 3, 16, 16, 96, 320, False), (17, 1, 32, 32, 32, 256, True), (16, 1, 128, 128, 32, 320, False)])
+def test_conv_halo_reuse_kernel(cfg, B, H, W, Cin, Cout, res):
+    """3x3 conv with the input window staged once per 32-channel chunk (k_conv8h): vs fp32 conv2d, incl. image borders,
+    several samples per launch, bias and residual."""
+    L = _lib.lib()
+    x = bf16_round(randn(B, Cin, H, W, seed=90))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=91) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=92)
+    ref = F.conv2d(x, w, b, padding=1)
+    r = bf16_round(randn(B, Cout, H, W, seed=93)) if res else None
+    if res:
+        ref = ref + r
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+                                     vp(to_dev_bf16(nhwc(r))) if res else None, 1, 0, 0, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"halo conv cfg{cfg} {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+
+
+def test_conv_halo_reuse_rejects_ineligible_shapes():
+    L = _lib.lib()
+    x = torch.zeros(1, 24, 20, 320, dtype=torch.bfloat16, device=DEV)      # W = 20 does not divide 256
+    w = torch.zeros(320, 9 * 320, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(1, 24, 20, 320, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(16)
+    try:
+        assert L.gyre_op_conv3x3(st(), vp(x), 1, 24, 20, 320, vp(w), 320, None, None, 1, 0, 0, vp(y)) == -6
+        assert L.gyre_op_conv3x3(st(), vp(x), 1, 24, 20, 320, vp(w), 320, None, None, 2, 0, 0, vp(y)) == -6   # stride 2
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
