@@ -85,3 +85,17 @@ struct GyreProfScope {  // RAII: records start/stop events around one launch whe
     ~GyreProfScope();
     hipStream_t st_;
 };
+
+// Large dynamic-LDS kernels need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE (a process may drive
+// several GPUs from different threads, reference manager.py:2107-2139).  Returns true when the caller still has to set
+// the attribute for the current device; `done` is the launcher's function-local bitmask.
+#include <atomic>
+static inline bool gyre_lds_attr_needed(std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+

@@ -844,11 +844,9 @@ static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
     auto kern = k_attn2<D, QI, PD, FOLD>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (gyre_lds_attr_needed(attr_done))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     dim3 grid((p.Nq + 64 * QI - 1) / (64 * QI), p.B * p.H);
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
@@ -867,11 +865,9 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
     auto kern = k_attn3<D, PD, QI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (gyre_lds_attr_needed(attr_done))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     dim3 grid((unsigned)(((p.Nq + 64 * QI - 1) / (64 * QI)) * p.B * p.H));
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
@@ -886,11 +882,9 @@ static int launch_attn_t(hipStream_t st, const AttnParams& p) {
     constexpr int DO = (D + 15) / 16;
     const size_t lds = (size_t)64 * (DP * 2 + 16) + (size_t)DO * 16 * (64 * 2 + 16);
     auto kern = k_attn<D, QI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (gyre_lds_attr_needed(attr_done))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     dim3 grid((p.Nq + 64 * QI - 1) / (64 * QI), p.B * p.H);
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));

@@ -769,11 +769,9 @@ static int launch_cfg(hipStream_t st, const GemmParams& p) {
 #define GYRE_GEMM_GO(MODE_, UNI_, TR_)                                                                              \
     do {                                                                                                            \
         auto kern = k_gemm<BM, BN, WM, WN, MODE_, UNI_, TR_>;                                                       \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static std::atomic<unsigned long long> attr_done{0};                                                                               \
+        if (gyre_lds_attr_needed(attr_done))                                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n);                              \
     } while (0)
     if (p.mode == GEMM_LINEAR) {
@@ -821,11 +819,9 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
 #define GYRE_GEMM8_GO(MODE_, UNI_)                                                                                  \
     do {                                                                                                            \
         auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_, NST>;                                                        \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static std::atomic<unsigned long long> attr_done{0};                                                                               \
+        if (gyre_lds_attr_needed(attr_done))                                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
     if (p.mode == GEMM_LINEAR) {
@@ -1027,11 +1023,9 @@ static int launch_cfg4d(hipStream_t st, const GemmParams& p, int kcls_base, int 
 #define GYRE_GEMM4D_GO(MODE_, UNI_)                                                                                 \
     do {                                                                                                            \
         auto kern = k_gemm4d<BM, BN, WM, WN, MODE_, UNI_>;                                                          \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
+        static std::atomic<unsigned long long> attr_done{0};                                                        \
+        if (gyre_lds_attr_needed(attr_done))                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
     if (p.mode == GEMM_LINEAR) {
@@ -1226,11 +1220,9 @@ static int launch_conv8h(hipStream_t st, const GemmParams& p, int kcls) {
                         (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0 + (double)p.N * p.K * 2.0 +
                             (double)p.M * p.N * 2.0 * (p.residual ? 2.0 : 1.0));
     auto kern = k_conv8h<BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (gyre_lds_attr_needed(attr_done))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, p, tiles_m, tiles_n);
     GYRE_LAUNCH_CHECK();
     return 0;
