@@ -119,8 +119,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
     const int n_out_base = gg ? n_base / 2 : n_base;
     const int n_out = gg ? p.N / 2 : p.N;
     constexpr int vec_per_row = tno / 8;
+    constexpr int NV = (16 * vec_per_row + 63) / 64;       // row-wise vectors per lane per slab
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        // the residual vectors of this slab are requested first, so their latency runs under the LDS round trip
+        // (requesting slab i+1's as well was tried: spills in the 256x320 kernel, slower)
+        uint4 rres[NV];
+        if (p.residual) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int v = lane + 64 * q;
+                const int row = v / vec_per_row, c8 = v - row * vec_per_row;
+                const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
+                rres[q] = make_uint4(0, 0, 0, 0);
+                if (v < 16 * vec_per_row && mm < p.M && nn < n_out) rres[q] = *(const uint4*)(p.residual + (size_t)mm * p.ldr + nn);
+            }
+        }
         const int m = m_base + i * 16 + fr;
         const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
         if (gg) {
@@ -150,7 +164,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
         }
         // read the slab back row-wise: 8 consecutive channels (32 B fp32) per lane -> one 16-byte store
 #pragma unroll
-        for (int v = lane; v < 16 * vec_per_row; v += 64) {
+        for (int q = 0; q < NV; ++q) {
+            const int v = lane + 64 * q;
+            if (v >= 16 * vec_per_row) break;
             const int row = v / vec_per_row, c8 = v - row * vec_per_row;
             const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
             const float4 lo = *(const float4*)(my + row * rowf + c8 * 8);
@@ -159,7 +175,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (p.residual) {
                     float r[8];
-                    unpack8(*(const uint4*)(p.residual + (size_t)mm * p.ldr + nn), r);
+                    unpack8(rres[q], r);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += r[e];
                 }
