@@ -20,7 +20,7 @@ def timeit(fn, iters=8):
     return e0.elapsed_time(e1) / iters * 1e3
 B = 16
 print("cfgs:", cfgs, "(0 = planner)")
-for (Bc, H, W, Ci, Co) in [(B,64,64,320,320),(B,64,64,960,320),(B,32,32,320,640),(B,32,32,640,640),(B,32,32,1280,640),(B,32,32,1920,640),(B,16,16,640,1280),(B,16,16,1280,1280),(B,16,16,2560,1280),(B,8,8,1280,1280),(B,8,8,2560,1280)]:
+for (Bc, H, W, Ci, Co) in [(B,64,64,320,320),(B,64,64,960,320),(B,32,32,320,640),(B,32,32,640,640),(B,32,32,960,640),(B,32,32,1280,640),(B,32,32,1920,640),(B,16,16,640,1280),(B,16,16,1280,1280),(B,16,16,2560,1280),(B,8,8,1280,1280),(B,8,8,2560,1280)]:
     x, w, b = rnd(Bc, H, W, Ci), rnd(Co, 9 * Ci), torch.zeros(Co, device=DEV)
     y = torch.empty(Bc, H, W, Co, dtype=torch.bfloat16, device=DEV)
     fl = 2.0 * Bc * H * W * Co * 9 * Ci
