@@ -33,7 +33,7 @@ UNET_TFLOP_PER_SAMPLE = 0.803   # 401.6 GMAC @ 64x64 latents
 VAE_DEC_TFLOP = 2.515           # 1257 GMAC @ 512^2
 MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16
 # kernel classes timed live during the timed region; the one with the largest total is reported as the dominant kernel
-CANDIDATES = ["k_gemm8<", "k_attn"]
+CANDIDATES = ["k_gemm8<", "k_gemm4s<", "k_attn"]
 
 
 def fill_synthetic_on_device(module, seed):

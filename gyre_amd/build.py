@@ -15,8 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgyre_hip.so")
-SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_attn.hip", "model.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "gyre_hip.h")]
+SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_attn.hip", "model.hip"]
+HEADERS = ["common.h", "kernels.h", "gemm_shared.h", os.path.join("..", "..", "include", "gyre_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-Wno-unused-result", "-fno-gpu-rdc",
          # the fully unrolled MFMA epilogues (up to 40 fragments per wave) exceed clang's default pragma-unroll
@@ -32,8 +32,9 @@ PER_FILE_FLAGS = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # count in vmcnt and may be acknowledged before older loads, which would let the wait pass while a tile is still in
 # flight.  Every compile therefore records the register / scratch use of each kernel (clang remarks), and
 # tests/test_host_cpu.py::test_counted_vmcnt_kernels_do_not_spill checks it.  Kernels listed here drain with vmcnt(0).
-RESOURCE_FILES = ("kernels_attn.hip", "kernels_gemm.hip")
-SCRATCH_ALLOWED = ("k_attn3ILi80E",)
+RESOURCE_FILES = ("kernels_attn.hip", "kernels_gemm.hip", "kernels_gemm4s.hip")
+# k_gemm4s: its LDS-DMA requests are always retired with vmcnt(0); the 256x256 form spills in the epilogue only
+SCRATCH_ALLOWED = ("k_attn3ILi80E", "k_gemm4s")
 RESOURCES_JSON = os.path.join(HERE, "build", "kernel_resources.json")
 
 

@@ -24,12 +24,11 @@
 // Replaces cuBLAS/cuDNN (hipBLASLt/MIOpen) GEMM+conv reached through torch.nn.Linear /
 // torch.nn.Conv2d inside the third-party UNet/VAE the reference calls at
 // gyre/pipeline/unet/core.py:274 and gyre/pipeline/unified_pipeline.py:309,1531.
-#include "kernels.h"
+#include "gemm_shared.h"
 #include <cstdlib>
 #include <atomic>
 #include <utility>
 
-#define BK 64
 
 // Non-transposed epilogue shared by the 4-wave and 8-wave kernels.  Operands were issued swapped, so a
 // lane holds, per 16x16 fragment, output row m = m_base + 16*i + fr and 4 consecutive columns
@@ -95,14 +94,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
             }
         }
     }
-}
-
-// XCD-aware, bijective tile order: blocks b, b+8, ... run on the same XCD (private L2); give each XCD a
-// contiguous chunk of tile ids, tile id -> (tm, tn) with tn fastest so neighbours share the A rows.
-__device__ __forceinline__ int xcd_tile_id(int bid, int ntiles) {
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int xcd = bid & 7, loc = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
 // LDS-staged epilogue of the 8-wave kernel (bf16 row-major output).  The register layout after the swapped
@@ -217,8 +208,6 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
     }
 }
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 // ------------------------------------------------------------------------------------------------
 // 8-wave, LDS-DMA staged variant for the big problems (tiles BM x BN with BN = 320 or 256).
@@ -575,6 +564,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits)
     *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
 }
 
+int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits) {
+    const size_t nthreads = (size_t)p.M * (p.N / 4);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool TRANS>
 __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int tiles_n) {
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -806,7 +802,7 @@ static int launch_cfg(hipStream_t st, const GemmParams& p) {
 #include <mutex>
 #include <unordered_map>
 // 256-byte zero page per device: source of the zero padding for the LDS-DMA kernel (read-only after creation)
-static const bf16_t* zero_page_for_current_device() {
+const bf16_t* gemm_zero_page_for_current_device() {
     static std::mutex mu;
     static std::unordered_map<int, void*> pages;
     int dev = 0;
@@ -1270,6 +1266,14 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
         if (!p.geglu && p.N % 320 == 0) { big(4, 0.92, 256, 320); big(5, 0.88, 128, 320); }
         if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
+        // pipelined 32x32x16 kernel (kernels_gemm4s.hip), 8 waves on the 256x320 tile: better main loop (barrier off the
+        // critical path, requests issued from the MFMA gaps), heavier two-pass epilogue -> long reductions only.
+        // Measured in the UNet (tools/unet_layers.py, r02): 3x3 convs at 64x64 -3...-7 % time, K = 2560 linears -19 %, the
+        // K = 1280 / N = 320 linear +13 % (not taken).  The 4-wave one-wave-per-SIMD forms (configs 20-23) win isolated
+        // benchmarks (8192^3: 1325 vs 1048 TFLOP/s) but lose 4-15 % inside the UNet; they stay test / tuning configs.
+        const int nk_ = (p.K + BK - 1) / BK;
+        if (!(p.debug & 0x400) && p.N % 320 == 0 && (p.mode == GEMM_CONV3 ? nk_ >= 20 : nk_ >= 32) && gemm4s_supports(p, 24))
+            big(24, 1.00, 256, 320);
         // few output tiles but a long reduction (the 8x8 / 16x16 UNet levels: K = 9*Cin up to 23040): cut K into
         // slices so that tiles x slices covers the chip; fp32 slabs are reduced by k_splitk_reduce
         const int nk = (p.K + BK - 1) / BK;
@@ -1331,6 +1335,7 @@ static int plan_cfg(const GemmParams& p, int* splits) {
 
 GemmPlan gemm_plan(const GemmParams& p0) {
     GemmParams p = p0;
+    p.debug = g_gemm_debug;      // same planner inputs as launch_gemm
     GemmPlan pl{3, 1, 0};
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return pl;
     pl.cfg = plan_cfg(p, &pl.splits);
@@ -1378,7 +1383,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         if (p.geglu && cfg == 9) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
-        p.zero_page = zero_page_for_current_device();
+        p.zero_page = gemm_zero_page_for_current_device();
         if (!p.zero_page) GYRE_FAIL(-5, "gemm: cannot allocate the zero page");
     }
     switch (cfg) {
@@ -1400,6 +1405,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
                  return launch_conv8h<320>(st, p, KC_G8_CONV_256x320);
         case 17: if (!conv8h_eligible(p, 256)) GYRE_FAIL(-6, "gemm: halo conv kernel does not apply to this problem");
                  return launch_conv8h<256>(st, p, KC_G8_CONV_256x256);
+        case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
 }

@@ -61,6 +61,8 @@ static const char* kclass_name(int k) {
         "k_gemm<128, 128, 2, 2, 0", "k_gemm<256, 64, 4, 1, 0", "k_gemm<64, 64, 2, 2, 0",
         "k_gemm8<256, 320, 4, 2, 1", "k_gemm8<128, 320, 2, 4, 1", "k_gemm8<256, 256, 4, 2, 1", "k_gemm8<128, 256, 2, 4, 1",
         "k_gemm8<256, 320, 4, 2, 0", "k_gemm8<128, 320, 2, 4, 0", "k_gemm8<256, 256, 4, 2, 0", "k_gemm8<128, 256, 2, 4, 0",
+        "k_gemm4s<192, 320, 2, 2, 1", "k_gemm4s<192, 320, 2, 2, 0", "k_gemm4s<256, 256, 2, 2, 1", "k_gemm4s<256, 256, 2, 2, 0",
+        "k_gemm4s<128, 320, 2, 2, 1", "k_gemm4s<128, 320, 2, 2, 0", "k_gemm4s<128, 256, 2, 2, 1", "k_gemm4s<128, 256, 2, 2, 0", "k_gemm4s<256, 320, 4, 2, 1", "k_gemm4s<256, 320, 4, 2, 0",
         "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other"};
     return (k >= 0 && k < KC_COUNT) ? n[k] : "?";
 }
@@ -1102,10 +1104,12 @@ const char* gyre_prof_class_name(int k) { return kclass_name(k); }
 // The caller must have synchronised the stream.  Arrays have KC_COUNT entries.
 int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes) {
     for (int k = 0; k < KC_COUNT; ++k) { launches[k] = 0; ms[k] = 0; flops[k] = 0; bytes[k] = 0; }
+    static const bool dump = getenv("GYRE_PROF_DUMP") != nullptr;     // dev aid: one stderr line per timed launch
     for (auto& r : g_prof.recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             launches[r.kclass]++; ms[r.kclass] += t; flops[r.kclass] += r.flops; bytes[r.kclass] += r.bytes;
+            if (dump) fprintf(stderr, "GYRE_PROF %s | %.0f MFLOP | %.0f KB | %.2f us\n", kclass_name(r.kclass), r.flops / 1e6, r.bytes / 1e3, t * 1e3);
         }
         g_prof.pool.emplace_back(r.a, r.b);
     }

@@ -15,6 +15,13 @@ with s = scale * alpha / r (alpha absent -> 1).  Key formats as detected by refe
 Text-encoder entries (``lora_te_``) are ignored here (CLIP stays host PyTorch and keeps the reference's own path).
 
 The touched base weights are kept (CPU copies) so that removing / re-scaling restores them bit-exactly.
+
+Precision: the merge happens in fp32 and the merged fp32 tensor is what the native module uploads
+(``unet._weight_overrides``, consumed by modules._NativeModule._upload_source), so base + delta is rounded to bf16 once,
+inside the repack kernel.  Writing the sum back into a bf16 / fp16 master parameter first would round it against the
+master's grid: a delta element below half an ulp of W (|delta| < 0.2-0.4 % of |W|, typical for LoRA) would vanish,
+which the reference's activation-space hook never does.  The master parameter also receives the (rounded) merged value,
+for ``state_dict()`` consumers only.
 """
 from __future__ import annotations
 
@@ -117,8 +124,17 @@ def _rebuild(unet) -> None:
                 w = w + d * scale
         p = params[name]
         p.copy_(w.to(p.device, p.dtype))
+        if st["loras"] and p.dtype != torch.float32:
+            ov = getattr(unet, "_weight_overrides", None)
+            if ov is None:
+                ov = unet._weight_overrides = {}
+            ov[name] = w                      # fp32, uploaded instead of the rounded master
+        elif getattr(unet, "_weight_overrides", None):
+            unet._weight_overrides.pop(name, None)
     if not st["loras"]:
         st["base"].clear()
+        if getattr(unet, "_weight_overrides", None):
+            unet._weight_overrides.clear()
     if hasattr(unet, "_invalidate"):
         unet._invalidate()                       # the native copy is repacked from the merged weights at next use
 

@@ -118,7 +118,7 @@ class _NativeModule(nn.Module):
                 for key, p in self.state_dict().items():
                     if key not in native:
                         continue  # host-side parameters (e.g. SDXL add_embedding) stay in PyTorch
-                    t = p.detach()
+                    t = self._upload_source(key, p)
                     if t.device != device:
                         t = t.to(device)
                     t = t.contiguous()
@@ -129,6 +129,15 @@ class _NativeModule(nn.Module):
                 torch.cuda.current_stream(device).synchronize()  # load time only: temporaries may now be freed
                 self._dirty = False
         return self._handle
+
+    def _upload_source(self, key: str, p: torch.Tensor) -> torch.Tensor:
+        """The tensor handed to gyre_*_set_weight for `key`: the parameter, or an fp32 override of it (LoRA merges are
+        kept in fp32 so that base + delta is rounded to bf16 ONCE, by the repack kernel - a bf16 master would swallow
+        deltas below half an ulp of the weight, gyre_amd/lora.py)."""
+        ov = getattr(self, "_weight_overrides", None)
+        if ov and key in ov:
+            return ov[key].detach()
+        return p.detach()
 
     def _workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
         if nbytes == 0:

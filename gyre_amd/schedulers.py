@@ -898,8 +898,12 @@ class DiffusersScheduler:
         self.prediction_type = prediction_type
         self.sched.set_timesteps(num_inference_steps)
         if strength is not None:
-            init = min(int(num_inference_steps * strength), num_inference_steps)
-            self.start_offset = max(num_inference_steps - init, 0)
+            # common_scheduler.py:226-233: the scheduler config's steps_offset (1 for the SD DDIM / PNDM configs; the
+            # pinned DPMSolverMultistepScheduler has no such field -> 0) enters twice, which only shows once
+            # int(n * strength) reaches n: strength 1.0 then starts at timesteps[1], not timesteps[0]
+            offset = self.sched.steps_offset if self.sched.solver_order == 0 else 0
+            init = min(int(num_inference_steps * strength) + offset, num_inference_steps)
+            self.start_offset = max(num_inference_steps - init + offset, 0)
         else:
             self.start_offset = start_offset or 0
         self.unet = type("EvalCounter", (), {"evals": 0})()

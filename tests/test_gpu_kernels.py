@@ -557,3 +557,151 @@ def test_conv_halo_reuse_rejects_ineligible_shapes():
         assert L.gyre_op_conv3x3(st(), vp(x), 1, 24, 20, 320, vp(w), 320, None, None, 2, 0, 0, vp(y)) == -6   # stride 2
     finally:
         L.gyre_debug_force_gemm_cfg(old)
+
+
+# ---- pipelined 32x32x16 tile configs (kernels_gemm4s.hip): 4 waves 20 = 192x320, 21 = 256x256, 22 = 128x320, 23 = 128x256;
+# 8 waves 24 = 256x320 ----------
+def _ablation(bits):
+    return _lib.lib().gyre_debug_gemm_ablation(bits)
+
+
+@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 24])
+@pytest.mark.parametrize("M,K,N,bias,res", [(1000, 320, 640, True, True), (4096 + 37, 1280, 1280, True, False),
+                                            (513, 2560, 960, False, True), (192, 64, 320, True, False)])
+def test_linear_4s_tile_config(cfg, M, K, N, bias, res):
+    L = _lib.lib()
+    x = bf16_round(randn(M, K, seed=70))
+    w = bf16_round(randn(N, K, seed=71) / math.sqrt(K))
+    b = randn(N, seed=72) if bias else None
+    r = bf16_round(randn(M, N, seed=73)) if res else None
+    ref = F.linear(x, w, b)
+    if res:
+        ref = ref + r
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w)), N,
+                                    vp(b.to(DEV)) if bias else None, vp(to_dev_bf16(r)) if res else None, 0, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"linear 4s cfg{cfg} M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
+
+
+@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 24])
+def test_geglu_4s_tile_config(cfg):
+    L = _lib.lib()
+    M, K, F_ = 700, 320, 1280
+    x = bf16_round(randn(M, K, seed=44))
+    w = bf16_round(randn(2 * F_, K, seed=45) / math.sqrt(K))
+    b = randn(2 * F_, seed=46) * 0.5
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    try:
+        _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w, geglu=True)), F_,
+                                    vp(repack_bias(b, geglu=True)), None, 1, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+    report(f"geglu 4s cfg{cfg}", y.float().cpu(), ref, TOL)
+
+
+@pytest.mark.parametrize("zfill", [0, 1])
+@pytest.mark.parametrize("cfg", [20, 21, 22, 23, 24])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,asym,res", [
+    (2, 24, 20, 320, 640, 1, 0, 0, True), (1, 16, 16, 128, 1280, 1, 1, 0, False), (2, 18, 18, 128, 1280, 2, 0, 1, False),
+    (3, 8, 8, 64, 320, 1, 0, 0, False), (1, 19, 21, 192, 256, 1, 0, 0, True),
+])
+def test_conv_4s_tile_config(zfill, cfg, B, H, W, Cin, Cout, stride, ups, asym, res):
+    """zfill 0: conv zero padding through out-of-range raw-buffer LDS-DMA requests; 1: through zero-page pointers."""
+    L = _lib.lib()
+    x = bf16_round(randn(B, Cin, H, W, seed=47))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=48) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=49)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w, b, stride=stride, padding=0) if asym else F.conv2d(xi, w, b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = bf16_round(randn(B, Cout, Ho, Wo, seed=50)) if res else None
+    if res:
+        ref = ref + r
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(cfg)
+    olda = _ablation(0x200 if zfill else 0)
+    try:
+        _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+                                     vp(to_dev_bf16(nhwc(r))) if res else None, stride, ups, asym, vp(y)))
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+        _ablation(olda)
+    report(f"conv 4s cfg{cfg} zfill{zfill} {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+
+
+@pytest.mark.parametrize("cfg,splits", [(20, 3), (21, 4), (22, 8), (23, 5), (24, 6)])
+def test_conv_4s_split_k(cfg, splits):
+    L = _lib.lib()
+    B, H, W, Cin, Cout = 4, 16, 16, 640, 1280
+    x = bf16_round(randn(B, Cin, H, W, seed=51))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=52) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=53)
+    r = bf16_round(randn(B, Cout, H, W, seed=54))
+    ref = F.conv2d(x, w, b, padding=1) + r
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
+    old = L.gyre_debug_force_gemm_cfg(cfg | (splits << 8))
+    try:
+        args = (st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)), vp(to_dev_bf16(nhwc(r))), 1, 0, 0, vp(y))
+        _lib.check(L.gyre_op_conv3x3(*args))
+        y1 = y.clone()
+        _lib.check(L.gyre_op_conv3x3(*args))
+        assert torch.equal(y, y1)
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)
+        L.gyre_debug_set_splitk_workspace(None, 0)
+    report(f"conv 4s split-K cfg{cfg} x{splits}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+
+
+def test_4s_tile_configs_sum_in_the_same_order_as_the_others():
+    """32x32x16 fragments, four k16 sub-steps per 64-channel chunk: same bits as the 16x16x32 kernels."""
+    L = _lib.lib()
+    B, H, W, Cin, Cout = 2, 20, 24, 192, 1280
+    x = to_dev_bf16(nhwc(bf16_round(randn(B, Cin, H, W, seed=60))))
+    w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
+    b = randn(Cout, seed=62).to(DEV)
+    outs = {}
+    for cfg in (1, 4, 20, 21, 22, 23, 24):
+        y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        old = L.gyre_debug_force_gemm_cfg(cfg)
+        try:
+            _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, W, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
+        finally:
+            L.gyre_debug_force_gemm_cfg(old)
+        outs[cfg] = y
+    for cfg, y in outs.items():
+        assert torch.equal(y, outs[1]), f"conv: config {cfg} differs bitwise from config 1"
+    M, K, N = 777, 640, 1280
+    xl = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
+    wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
+    outs = {}
+    for cfg in (1, 4, 20, 21, 22, 23, 24):
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        old = L.gyre_debug_force_gemm_cfg(cfg)
+        try:
+            _lib.check(L.gyre_op_linear(st(), vp(xl), M, K, vp(wl), N, None, None, 0, vp(y)))
+        finally:
+            L.gyre_debug_force_gemm_cfg(old)
+        outs[cfg] = y
+    for cfg, y in outs.items():
+        assert torch.equal(y, outs[1]), f"linear: config {cfg} differs bitwise from config 1"
+
+
+def test_4s_rejects_unsupported_shapes():
+    L = _lib.lib()
+    x = to_dev_bf16(bf16_round(randn(256, 200, seed=1)))
+    w = repack_linear(bf16_round(randn(320, 200, seed=2)))
+    y = torch.empty(256, 320, dtype=torch.bfloat16, device=DEV)
+    old = L.gyre_debug_force_gemm_cfg(20)
+    try:
+        assert L.gyre_op_linear(st(), vp(x), 256, 200, vp(w), 320, None, None, 0, vp(y)) == -6   # K not in 64-channel steps
+    finally:
+        L.gyre_debug_force_gemm_cfg(old)

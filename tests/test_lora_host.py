@@ -103,3 +103,33 @@ def test_diffusers_format_and_errors():
         LR.apply_lora(net, {"lora_unet_nope.lora_down.weight": torch.zeros(1, 1), "lora_unet_nope.lora_up.weight": torch.zeros(1, 1)}, 1)
     with pytest.raises(NotImplementedError):
         LR.apply_lora(net, {"unet:0:up": torch.zeros(1)}, 2)
+
+
+def test_bf16_master_keeps_small_deltas():
+    """with a bf16 master, a delta of ~1e-3 |W| is below half an ulp of W and would round away if the merge were
+    written back into the master; the fp32 override that the native upload uses must carry it exactly."""
+    net = make_unet().to(torch.bfloat16)
+    name = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q"
+    w = dict(net.named_parameters())[name + ".weight"]
+    base = w.detach().clone()
+    g = torch.Generator().manual_seed(3)
+    r = 4
+    scale = 1e-3 * float(base.float().abs().mean())
+    lora = {"lora_unet_" + name.replace(".", "_") + ".lora_down.weight": torch.randn(r, w.shape[1], generator=g),
+            "lora_unet_" + name.replace(".", "_") + ".lora_up.weight": torch.randn(w.shape[0], r, generator=g) * scale / r ** 0.5,
+            "lora_unet_" + name.replace(".", "_") + ".alpha": torch.tensor(float(r))}
+    assert LR.apply_lora(net, lora, "a") == 1
+    delta = LR.lora_delta(lora["lora_unet_" + name.replace(".", "_") + ".lora_up.weight"],
+                          lora["lora_unet_" + name.replace(".", "_") + ".lora_down.weight"], torch.tensor(float(r)))
+    exact = base.float() + delta
+    # the rounded master lost most of it ...
+    lost = (w.float() - exact).norm() / delta.norm()
+    assert lost > 0.5
+    # ... the upload source did not
+    src = net._upload_source(name + ".weight", w)
+    assert src.dtype == torch.float32 and torch.equal(src, exact)
+    LR.set_lora_scale(net, "a", 0.5)
+    assert torch.equal(net._upload_source(name + ".weight", w), base.float() + delta * 0.5)
+    LR.remove_lora_from_model(net)
+    assert torch.equal(w, base) and net._upload_source(name + ".weight", w) is not None
+    assert not net._weight_overrides and net._upload_source(name + ".weight", w).dtype == torch.bfloat16

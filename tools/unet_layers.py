@@ -1,0 +1,39 @@
+"""Dev tool: per-launch (per layer shape) HIP-event times of one SD1.5 UNet forward, grouped by (class, flops, bytes).
+GYRE_PROF_DUMP=1 python tools/unet_layers.py 2>&1 | ... (the script sets the variable itself)."""
+import os, sys, subprocess, collections
+if os.environ.get("GYRE_PROF_DUMP") is None:
+    env = dict(os.environ, GYRE_PROF_DUMP="1")
+    out = subprocess.run([sys.executable, __file__] + sys.argv[1:], env=env, capture_output=True, text=True)
+    rows = collections.OrderedDict()
+    for line in out.stderr.splitlines():
+        if not line.startswith("GYRE_PROF "): continue
+        name, fl, by, us = [x.strip() for x in line[len("GYRE_PROF "):].split("|")]
+        key = (name, fl, by)
+        rows.setdefault(key, []).append(float(us.split()[0]))
+    tot = sum(sum(v) for v in rows.values())
+    print(out.stdout[-400:])
+    print(f"total timed {tot / 1e3:.2f} ms")
+    for (name, fl, by), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+        mf = float(fl.split()[0]); kb = float(by.split()[0]); t = sum(v) / len(v)
+        print(f"{name:30s} x{len(v):3d}  {sum(v):8.1f} us tot  {t:7.1f} us each  {mf / t / 1e0 / 1e6 * 1e6 / 1e6:7.0f} TF  {kb / t / 1e3:6.2f} TB/s  [{fl}, {by}]")
+    sys.exit(0)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gyre_amd import config as gcfg, _lib
+from gyre_amd.modules import GyreHipUNet
+B = int(os.environ.get("B", "16")); H = int(os.environ.get("LAT", "64")); dev = "cuda:0"; L = _lib.lib()
+net = GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(dev)
+g = torch.Generator(device=dev).manual_seed(0)
+with torch.no_grad():
+    for k, p in net.named_parameters():
+        if p.ndim > 1: p.copy_(torch.randn(p.shape, device=dev, generator=g, dtype=torch.float32) / p[0].numel() ** 0.5)
+        elif k.endswith("weight"): p.fill_(1.0)
+        else: p.zero_()
+net._invalidate()
+x = torch.randn(B, 4, H, H, device=dev); t = torch.full((B,), 500, device=dev); ctx = torch.randn(B, 77, 768, device=dev)
+L.gyre_debug_gemm_ablation(int(sys.argv[1], 0) if len(sys.argv) > 1 else 0)
+for _ in range(2): net(x, t, encoder_hidden_states=ctx)
+torch.cuda.synchronize(); _lib.prof_enable(None)
+net(x, t, encoder_hidden_states=ctx); torch.cuda.synchronize()
+_lib.prof_collect()
+print("done")
