@@ -1317,12 +1317,15 @@ static int pick_cfg_nosplit(const GemmParams& p) {
 // the mode on, the factor is planned for M' = rows-per-sample x canonical batch whatever the real batch is: any
 // split of a request over GPUs / sub-batches then gives bit-identical images (reference property
 // tests/batch_independance.py:15-27 made exact) at the price of a worse-filled chip when batch << canonical.
-static std::atomic<int> g_invariant_batch{0};
-int gemm_set_batch_invariant(int n) { return g_invariant_batch.exchange(n < 0 ? 0 : n); }
-int gemm_get_batch_invariant() { return g_invariant_batch.load(); }
+// Per calling thread, like the other planner knobs: the reference serves several device slots from threads of one
+// process (manager.py:2107-2139), and a process-wide switch flipped by one request between another thread's workspace
+// sizing and its forward would change that thread's split-K plan under its feet.
+static thread_local int g_invariant_batch = 0;
+int gemm_set_batch_invariant(int n) { const int old = g_invariant_batch; g_invariant_batch = n < 0 ? 0 : n; return old; }
+int gemm_get_batch_invariant() { return g_invariant_batch; }
 
 static int plan_cfg(const GemmParams& p, int* splits) {
-    const int inv = g_invariant_batch.load();
+    const int inv = g_invariant_batch;
     if (inv > 0 && p.samples > 0 && p.M % p.samples == 0) {
         GemmParams q = p;
         q.M = p.M / p.samples * inv;

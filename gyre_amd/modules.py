@@ -303,10 +303,14 @@ class GyreHipUNet(_NativeModule):
             # it once per request, unet/core.py:242-259); project it through the cross-attention K/V weights once.
             # Identity + version of a tensor we keep referenced => the storage cannot have been recycled.
             src = encoder_hidden_states
-            if not (self._ctx_src is src and self._ctx_ver == src._version and self._ctx_handle == h):
+            try:
+                ver = src._version
+            except RuntimeError:          # inference tensors carry no version counter: never trust the cache for them
+                ver = None
+            if ver is None or not (self._ctx_src is src and self._ctx_ver == ver and self._ctx_handle == h):
                 _lib.check(L.gyre_unet_set_context(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)),
                                                    C.c_void_p(ctx.data_ptr()), _lib.dtype_code(ctx), B, S))
-                self._ctx_src, self._ctx_ver, self._ctx_handle = src, src._version, h
+                self._ctx_src, self._ctx_ver, self._ctx_handle = src, ver, h
             need = L.gyre_unet_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
                 _lib.check(-1 if "unet:" in L.gyre_last_error().decode() else -4)

@@ -9,6 +9,7 @@ Host orchestration restating the reference's ``UnifiedPipeline.__call__``
   EnhancedRunwayInpaintMode   unified_pipeline.py:648-696 (9-channel UNet input assembly)
   strength >= 1 "shaped noise" fill (noise_mode 5)    unified_pipeline.py:402-417, 466-607
   Hires fix (mode tree of a natural-size and a full-size leaf)   unified_pipeline.py:1064-1200, 2100-2181
+  Grafted inpaint (inpaint_unet + unet blended by GraftUnets)    unified_pipeline.py:2071-2100, unet/graft.py:16-56
 
 Call stack per SURVEY.md 3.2/3.3: embeddings -> UNetWithEmbeddings -> (UnetWithExtraChannels)
 -> CFGUNet_Parallel -> KDiffusionUNetWrapper -> sampler loop -> vae.decode(latents / 0.18215)
@@ -114,8 +115,14 @@ class GyrePipeline:
     hires_oos_fraction = 0.6
     hires_image_oos_fraction = 1.0
 
-    def __init__(self, unet, vae, text_encoder: Optional[Callable] = None, device="cuda:0"):
+    def __init__(self, unet, vae, text_encoder: Optional[Callable] = None, device="cuda:0", inpaint_unet=None,
+                 grafted_inpaint=False):
+        """inpaint_unet: optional 9-channel (runway) UNet used whenever a mask is given (reference
+        unified_pipeline.py:1352,2058-2062).  grafted_inpaint: True or a blend dict {floor, start, end, easing}: masked
+        requests then run BOTH UNets and GraftUnets hands over from the inpaint UNet to `unet` (reference option
+        "grafted_inpaint", unified_pipeline.py:1543, 2082-2098)."""
         self.unet, self.vae, self.text_encoder = unet, vae, text_encoder
+        self.inpaint_unet, self.grafted_inpaint = inpaint_unet, grafted_inpaint
         self.device = torch.device(device)
         # the reference hard-codes SD1.x's 0.18215 (unified_pipeline.py:319,2488); SDXL's VAE uses 0.13025
         self.latent_scale = float(getattr(getattr(vae, "config", None), "scaling_factor", 0.18215))
@@ -175,42 +182,62 @@ class GyrePipeline:
         t = t[:, [0]]
         return 1 - t if inputIs0K1D else t
 
-    # -- one mode-tree leaf ---------------------------------------------------------------------------
-    def _build_leaf(self, *, height, width, image, mask_image, generators, text_embeddings, uncond_embeddings,
-                    guidance_scale, cfg_execution, B, fill_strength=None, added_cond=None, uncond_added_cond=None):
-        """Everything one resolution needs: the CFG-wrapped epsilon UNet with its conditioning bound, the clean
-        init latents (img2img / inpaint) and the inpaint blend data.  reference: a ModeTreeLeaf
-        (unified_pipeline.py:1173-1200) + the mode built for it (Txt2img/Img2img/EnhancedInpaint/RunwayInpaint)."""
-        dev = self.device
-        runway = self.unet.config.in_channels == 9
-        leaf = SimpleNamespace(height=height, width=width, lat_h=height // self.vae_scale_factor,
-                               lat_w=width // self.vae_scale_factor, extra=None, init_latents=None,
-                               blend_orig=None, blend_mask=None, noise=None)
-        if image is not None:
-            img = self.preprocess_image(image.to(torch.float32))
-            if img.shape[-2:] != (height, width):
-                raise ValueError(f"image is {tuple(img.shape[-2:])}, expected {(height, width)}")
-            if mask_image is not None:
-                mask = self.preprocess_mask(mask_image.to(torch.float32)).to(dev)      # 1 keep / 0 replace
-                high_mask = round_mask(mask, 0.001)
-                orig = self.image_to_latents(img, generators, high_mask)
-                latent_mask = torch.cat([mask_to_latent_mask(mask)] * B)
-                if runway:
-                    inpaint_mask = 1 - round_mask(latent_mask, 0.001)[:, [0]]           # 0 keep / 1 replace
-                    leaf.extra = torch.cat([inpaint_mask, orig], dim=1)
-                leaf.init_latents = self.image_to_latents(img, generators)
-                if fill_strength is not None:     # strength >= 1: re-seed the repaint area (unified_pipeline.py:603-607)
-                    leaf.init_latents = fill_with_shaped_noise(leaf.init_latents, latent_mask, generators, fill_strength)
-                if not runway:
-                    # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
-                    # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
-                    leaf.blend_orig, leaf.blend_mask = orig, latent_mask
-            else:
-                leaf.init_latents = self.image_to_latents(img, generators)
+    # -- mode tree -----------------------------------------------------------------------------------
+    # reference ModeTreeRoot / Node / Leaf (unified_pipeline.py:1064-1200): leaves are modes (one UNet stack each), inner
+    # nodes blend two sub-trees during sampling (GraftUnets, HiresUnetWrapper).  A tree here is a _Leaf or a
+    # (left, right, merger class, merger kwargs) tuple.
+    class _Leaf(SimpleNamespace):
+        pass
 
-        # UNet stack: embeddings -> extra channels -> CFG
+    @staticmethod
+    def _leaves(tree):
+        if isinstance(tree, tuple):
+            return GyrePipeline._leaves(tree[0]) + GyrePipeline._leaves(tree[1])
+        return [tree]
+
+    @staticmethod
+    def _map_leaves(tree, fn):
+        if isinstance(tree, tuple):
+            return (GyrePipeline._map_leaves(tree[0], fn), GyrePipeline._map_leaves(tree[1], fn), tree[2], tree[3])
+        return fn(tree)
+
+    def _construct_leaf(self, leaf, generators, B):
+        """Mode constructor (Img2imgMode / EnhancedInpaintMode / EnhancedRunwayInpaintMode __init__): preprocessing and,
+        for the inpaint modes, the posterior sample of the MASKED original (init_latents_orig, unified_pipeline.py:432-434).
+        Constructors of every leaf run before any leaf generates its start latents (build_mode, :1108-1116), which fixes
+        the order of the per-image generator draws."""
+        dev = self.device
+        leaf.lat_h, leaf.lat_w = leaf.height // self.vae_scale_factor, leaf.width // self.vae_scale_factor
+        leaf.extra = leaf.blend_orig = leaf.blend_mask = leaf.noise = leaf.latent_mask = leaf.img = None
+        runway = leaf.unet.config.in_channels == 9
+        if leaf.image is None:
+            if runway:
+                raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
+            return
+        img = self.preprocess_image(leaf.image.to(torch.float32))
+        if img.shape[-2:] != (leaf.height, leaf.width):
+            raise ValueError(f"image is {tuple(img.shape[-2:])}, expected {(leaf.height, leaf.width)}")
+        leaf.img = img
+        if leaf.mask_image is None:
+            if runway:
+                raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
+            return
+        mask = self.preprocess_mask(leaf.mask_image.to(torch.float32)).to(dev)      # 1 keep / 0 replace
+        orig = self.image_to_latents(img, generators, round_mask(mask, 0.001))
+        leaf.latent_mask = torch.cat([mask_to_latent_mask(mask)] * B)
+        if runway and not leaf.enhanced:
+            inpaint_mask = 1 - round_mask(leaf.latent_mask, 0.001)[:, [0]]            # 0 keep / 1 replace
+            leaf.extra = torch.cat([inpaint_mask, orig], dim=1)
+        else:
+            # EnhancedInpaintMode: keep the protected area pinned to the (masked) original by blending the
+            # denoised prediction with it while the blend mask exceeds the progress u (_blend, :620-625)
+            leaf.blend_orig, leaf.blend_mask = orig, leaf.latent_mask
+
+    def _bind_leaf(self, leaf, *, text_embeddings, uncond_embeddings, guidance_scale, cfg_execution, B, added_cond,
+                   uncond_added_cond, cfg_embeddings):
+        """UNet stack of one leaf: embeddings -> extra channels -> CFG (unified_pipeline.py:2235-2337, 2408-2430)."""
         def bind(emb, added=None):
-            u = S.UNetWithEmbeddings(self.unet, emb, added)
+            u = S.UNetWithEmbeddings(leaf.unet, emb, added)
             return S.UnetWithExtraChannels(u, leaf.extra) if leaf.extra is not None else u
 
         if guidance_scale > 1.0:
@@ -221,19 +248,26 @@ class GyrePipeline:
                 both = None
                 if added_cond is not None:
                     both = {k: torch.cat([uncond_added_cond[k], added_cond[k]]) for k in added_cond}
-                leaf.eps_unet = S.CFGUNet_Parallel(bind(torch.cat([uncond_embeddings, text_embeddings]), both), guidance_scale, B)
+                # ONE concatenated tensor for every leaf: the native UNet recognises the context it already projected by
+                # tensor identity, and the leaves of a hires / graft tree alternate on the same UNet every step
+                if cfg_embeddings.get("both") is None:
+                    cfg_embeddings["both"] = torch.cat([uncond_embeddings, text_embeddings])
+                leaf.eps_unet = S.CFGUNet_Parallel(bind(cfg_embeddings["both"], both), guidance_scale, B)
         else:
             leaf.eps_unet = bind(text_embeddings, added_cond)
-        return leaf
 
-    def _leaf_initial_latents(self, leaf, sched, generators):
+    def _generate_leaf_latents(self, leaf, sched, generators, fill_strength):
+        """Mode.generateLatents: txt2img noise, or (init sample, optional shaped-noise fill, noise) for an init image."""
         dev = self.device
-        if leaf.init_latents is None:
-            sample_size = getattr(self.unet.config, "sample_size", 64)
+        if leaf.img is None:
+            sample_size = getattr(leaf.unet.config, "sample_size", 64)
             latents = txt2img_latents(generators, 4, leaf.lat_h, leaf.lat_w, sample_size, dev)
             return sched.prepare_initial_latents(latents)
-        leaf.noise = S.batched_randn(leaf.init_latents.shape, generators, dev, torch.float32)
-        return sched.add_noise(leaf.init_latents, leaf.noise)
+        init = self.image_to_latents(leaf.img, generators)
+        if leaf.latent_mask is not None and fill_strength is not None:    # strength >= 1 (unified_pipeline.py:603-607)
+            init = fill_with_shaped_noise(init, leaf.latent_mask, generators, fill_strength)
+        leaf.noise = S.batched_randn(init.shape, generators, dev, torch.float32)
+        return sched.add_noise(init, leaf.noise)
 
     # -- the generation call ------------------------------------------------------------------------
     @torch.no_grad()
@@ -290,8 +324,6 @@ class GyrePipeline:
                     raise ValueError("added_cond tensors must have batch 1 or the number of seeds")
         else:
             added_cond = uncond_added_cond = None
-        if self.unet.config.in_channels == 9 and (image is None or mask_image is None):
-            raise ValueError("the 9-channel inpaint UNet needs image and mask_image")
         fill_strength = None
         if image is not None:
             if mask_image is not None:
@@ -308,7 +340,13 @@ class GyrePipeline:
         sched = S.make_scheduler(sampler, generators, dev, torch.float32)
         is_k = isinstance(sched, S.KDiffusionScheduler)
 
-        # ---- mode tree: one leaf, or natural-size + full-size leaves under the hires fix -----------------
+        # ---- mode tree (unified_pipeline.py:2054-2181) --------------------------------------------------------
+        main_unet = self.inpaint_unet if (mask_image is not None and self.inpaint_unet is not None) else self.unet
+        tree = self._Leaf(unet=main_unet, enhanced=False, height=height, width=width, image=image, mask_image=mask_image)
+        if main_unet is self.inpaint_unet and main_unet is not self.unet and self.grafted_inpaint:
+            blend = self.grafted_inpaint if isinstance(self.grafted_inpaint, dict) else None
+            top = self._Leaf(**{**tree.__dict__, "unet": self.unet, "enhanced": True})       # EnhancedInpaintMode on `unet`
+            tree = (tree, top, H.GraftUnets, {"blend": blend})
         # engine defaults: unified_pipeline.py:1368-1373 (on, threshold 3.33 %, oos 0.6, 1.0 with an init image)
         if hires_fix is None:
             hires_fix = self.hires_fix
@@ -323,54 +361,78 @@ class GyrePipeline:
         if use_hires and not is_k:
             raise ValueError("Can't use Diffuser schedulers with Hires fix. "
                              "Either use a K-Diffusion scheduler or disable Hires fix.")
-        common = dict(generators=generators, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
-                      guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, fill_strength=fill_strength,
-                      added_cond=added_cond, uncond_added_cond=uncond_added_cond)
-        leaves = []
         if use_hires:
             to_nat = lambda t: None if t is None else H.image_to_natural(natural_px, t if t.ndim == 4 else t[None],
                                                                          hires_oos_fraction)
-            leaves.append(self._build_leaf(height=natural_px, width=natural_px, image=to_nat(image),
-                                           mask_image=to_nat(mask_image), **common))
-        leaves.append(self._build_leaf(height=height, width=width, image=image, mask_image=mask_image, **common))
+            nat_image, nat_mask = to_nat(image), to_nat(mask_image)
+            natural = self._map_leaves(tree, lambda l: self._Leaf(**{**l.__dict__, "height": natural_px, "width": natural_px,
+                                                                     "image": nat_image, "mask_image": nat_mask}))
+            tree = (natural, tree, H.HiresUnetWrapper,
+                    {"natural_size": [sample_size, sample_size], "oos_fraction": hires_oos_fraction})
+        leaves = self._leaves(tree)
+        if not is_k and len(leaves) > 1 and use_hires:
+            raise ValueError("Can't use Diffuser schedulers with Hires fix.")
 
-        sched.set_eps_unets([l.eps_unet for l in leaves]) if is_k else sched.set_eps_unet(leaves[-1].eps_unet)
+        for leaf in leaves:                                     # build_mode: every constructor first
+            self._construct_leaf(leaf, generators, B)
+        shared = {}
+        for leaf in leaves:
+            self._bind_leaf(leaf, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
+                            guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, added_cond=added_cond,
+                            uncond_added_cond=uncond_added_cond, cfg_embeddings=shared)
+        sched.set_eps_unets([l.eps_unet for l in leaves])
         sched.set_timesteps(num_inference_steps, strength=strength if image is not None else None,
                             config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho, churn=churn, churn_tmin=churn_tmin,
                                                      churn_tmax=churn_tmax, sigma_min=sigma_min, sigma_max=sigma_max),
                             prediction_type=prediction_type)
-        for leaf in leaves:
-            leaf.latents = self._leaf_initial_latents(leaf, sched, generators)
 
         def _blend(mask, u, orig, nxt):
             it = mask.gt(u).to(nxt.dtype)
             return orig * it + nxt * (1 - it)
 
-        if is_k:
-            def k_unet(i, leaf):
-                inner = sched.unets[i]
+        # per-leaf scheduler-side UNets (Mode.wrap_k_unet / wrap_d_unet), then collapse the tree (:2462-2473)
+        for i, leaf in enumerate(leaves):
+            inner = sched.unets[i]
+            if is_k:
                 if leaf.blend_orig is None:
-                    return lambda x, sigma, u: inner(x, sigma)
-                return lambda x, sigma, u: _blend(leaf.blend_mask, u, leaf.blend_orig.to(x.dtype), inner(x, sigma))
-            ks = [k_unet(i, leaf) for i, leaf in enumerate(leaves)]
-            if use_hires:
-                model = H.HiresUnetWrapper(ks[0], ks[1], generators, [sample_size, sample_size], hires_oos_fraction)
-                latents = H.HiresUnetWrapper.merge_initial_latents(leaves[0].latents, leaves[1].latents)
+                    leaf.s_unet = (lambda inner: lambda x, sigma, u: inner(x, sigma))(inner)
+                else:
+                    leaf.s_unet = (lambda inner, leaf: lambda x, sigma, u:
+                                   _blend(leaf.blend_mask, u, leaf.blend_orig.to(x.dtype), inner(x, sigma)))(inner, leaf)
             else:
-                model, latents = ks[0], leaves[0].latents
-            plain = not use_hires and leaves[0].blend_orig is None
+                if leaf.blend_orig is None:
+                    leaf.s_unet = (lambda inner: lambda x, t, u: inner(x, t))(inner)
+                else:
+                    leaf.s_unet = (lambda inner, leaf: lambda x, t, u:
+                                   _blend(leaf.blend_mask, u, sched.add_noise_at(leaf.blend_orig, leaf.noise, t).to(x.dtype),
+                                          inner(x, t)))(inner, leaf)
+
+        def collapse(t):
+            if not isinstance(t, tuple):
+                return t.s_unet
+            kw = {k: v for k, v in t[3].items() if v is not None}
+            return t[2](collapse(t[0]), collapse(t[1]), generators, **kw)
+
+        def initial(t):                                       # every leaf generates (and draws), the merger picks
+            if not isinstance(t, tuple):
+                return self._generate_leaf_latents(t, sched, generators, fill_strength)
+            left, right = initial(t[0]), initial(t[1])
+            return t[2].merge_initial_latents(left, right)
+
+        def split(t, result):
+            if not isinstance(t, tuple):
+                return result
+            return t[2].split_result(split(t[0], result), split(t[1], result))
+
+        model = collapse(tree)
+        latents = initial(tree)
+        plain = len(leaves) == 1 and leaves[0].blend_orig is None
+        if is_k:
             latents = sched.loop(latents, callback=callback, k_model=None if plain else model)
-            if use_hires:
-                latents = H.HiresUnetWrapper.split_result(None, latents)
-            self.last_unet_evals = sum(u.evals for u in sched.unets)
         else:
-            leaf = leaves[0]
-            wrap = {}
-            if leaf.blend_orig is not None:
-                wrap["d_wrap"] = lambda xt, t, u: _blend(leaf.blend_mask, u,
-                                                         sched.add_noise_at(leaf.blend_orig, leaf.noise, t).to(xt.dtype), xt)
-            latents = sched.loop(leaf.latents, callback=callback, **wrap)
-            self.last_unet_evals = sched.unet.evals
+            latents = sched.loop(latents, callback=callback, d_model=None if plain else model)
+        latents = split(tree, latents)
+        self.last_unet_evals = sum(u.evals for u in sched.unets)
         if output_type == "latent":
             return latents
         result = self.vae_decode(latents)

@@ -13,7 +13,9 @@ algorithm (Shocher, "ResizeRight", 2021) - *parity unpinned*:
   boundary            taps outside the input are clamped to the edge sample (replicate padding)
 
 Without antialiasing the kernel is not stretched when downscaling (that is what the reference asks for).
-The separable resize is two small dense matrix products, which keeps it deterministic and batch independent.
+The separable resize is two small dense matrix products PER SAMPLE: a batched matmul may pick its kernel (and with it
+the fp32 summation order) by batch count, which would break the batch-independence property (reference
+tests/batch_independance.py:15-27) under the hires fix; one call per image has the same shape whatever the batch.
 """
 from __future__ import annotations
 
@@ -58,8 +60,14 @@ def resize_lanczos2(x: torch.Tensor, scale: float) -> torch.Tensor:
     h, w = x.shape[-2], x.shape[-1]
     mh = _weight_matrix(h, float(scale)).to(x.device, torch.float32)
     mw = _weight_matrix(w, float(scale)).to(x.device, torch.float32)
-    y = torch.matmul(mh, x.to(torch.float32))                                  # rows
-    y = torch.matmul(y, mw.t())                                                # columns
+    mwt = mw.t().contiguous()
+    xf = x.to(torch.float32)
+    if xf.ndim < 4:
+        return torch.matmul(torch.matmul(mh, xf), mwt).to(x.dtype)
+    lead = xf.shape[:-3]
+    xs = xf.reshape((-1,) + tuple(xf.shape[-3:]))
+    ys = [torch.matmul(torch.matmul(mh, s_), mwt) for s_ in xs]               # rows, then columns, one sample at a time
+    y = torch.stack(ys).reshape(lead + ys[0].shape)
     return y.to(x.dtype)
 
 

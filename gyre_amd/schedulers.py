@@ -883,16 +883,26 @@ class DiffusersScheduler:
     def __init__(self, kind: str, generators, device, dtype=torch.float32):
         self.sched = DiffusersLikeScheduler(kind)
         self.generators, self.device, self.dtype = generators, device, dtype
-        self.eps_unet, self.unet = None, None
+        self.eps_unet, self.eps_unets, self.unets, self.unet = None, [], [], None
         self.start_offset = 0
 
     def set_eps_unet(self, eps_unet):
-        self.eps_unet = eps_unet
+        self.set_eps_unets([eps_unet])
+
+    def set_eps_unets(self, eps_unets):
+        """One noise predictor per mode-tree leaf (common_scheduler.py set_eps_unets).  The step arithmetic of PLMS /
+        DPM-Solver++ is stateful, so only ONE leaf can be driven per loop (the reference shares one diffusers scheduler
+        object between the leaves of a graft, which steps its multistep history twice per timestep)."""
+        self.eps_unets = list(eps_unets)
+        self.eps_unet = self.eps_unets[-1] if self.eps_unets else None
 
     def set_timesteps(self, num_inference_steps: int, start_offset=None, strength=None, config=None,
                       prediction_type: str = "epsilon"):
         if self.eps_unet is None:
             raise ValueError("Epsilon unet needs to be set before timesteps")
+        if len(self.eps_unets) != 1:
+            raise ValueError("Diffusers-style samplers (ddim, plms, dpmsolverpp_*) drive a single UNet: use a k-diffusion "
+                             "sampler with grafted inpaint / hires fix")
         if prediction_type not in ("epsilon", "v_prediction"):
             raise NotImplementedError(f"prediction_type {prediction_type!r}")
         self.prediction_type = prediction_type
@@ -906,7 +916,24 @@ class DiffusersScheduler:
             self.start_offset = max(num_inference_steps - init + offset, 0)
         else:
             self.start_offset = start_offset or 0
-        self.unet = type("EvalCounter", (), {"evals": 0})()
+        outer = self
+
+        class _DUnet:
+            """wrap_unet (common_scheduler.py:261-283): x_t, t -> eps -> scheduler.step -> x_{t-1}"""
+            evals = 0
+
+            def __call__(self, x, t):
+                t = int(t)
+                eps = outer.eps_unet(x, t)
+                if outer.prediction_type == "v_prediction":
+                    # eps = sqrt(abar) v + sqrt(1 - abar) x   (x0 = sqrt(abar) x - sqrt(1 - abar) v)
+                    a = float(outer.sched.alphas_cumprod[t])
+                    eps = a ** 0.5 * eps + (1 - a) ** 0.5 * x
+                self.evals += 1
+                return outer.sched.step(eps, t, x)
+
+        self.unets = [_DUnet()]
+        self.unet = self.unets[0]
 
     def prepare_initial_latents(self, latents: Tensor) -> Tensor:
         return latents * self.sched.init_noise_sigma
@@ -916,30 +943,24 @@ class DiffusersScheduler:
         return a ** 0.5 * latents + (1 - a) ** 0.5 * noise
 
     def add_noise_at(self, latents: Tensor, noise: Tensor, t: int) -> Tensor:
-        a = float(self.sched.alphas_cumprod[t])
+        a = float(self.sched.alphas_cumprod[int(t)])
         return a ** 0.5 * latents + (1 - a) ** 0.5 * noise
 
-    def loop(self, latents: Tensor, callback=None, d_wrap=None) -> Tensor:
-        """d_wrap(xt, t, u) -> xt post-processes each new sample (reference Mode.wrap_d_unet)."""
+    def loop(self, latents: Tensor, callback=None, d_model=None) -> Tensor:
+        """d_model(x_t, t, u) -> x_{t-1} replaces the plain step (a mode's wrap_d_unet around self.unets[0]); u is the
+        progress value in [0, 0.999] (common_scheduler.py:285-301)."""
         x = latents
         ts = self.sched.timesteps[self.start_offset:]
         u_off = self.start_offset / max(len(self.sched.timesteps), 1)
         for i, t in enumerate(ts):
-            eps = self.eps_unet(x, int(t))
-            if getattr(self, "prediction_type", "epsilon") == "v_prediction":
-                # eps = sqrt(abar) v + sqrt(1 - abar) x   (x0 = sqrt(abar) x - sqrt(1 - abar) v)
-                a = float(self.sched.alphas_cumprod[int(t)])
-                eps = a ** 0.5 * eps + (1 - a) ** 0.5 * x
-            self.unet.evals += 1
-            x = self.sched.step(eps, int(t), x)
-            if d_wrap is not None:
+            if d_model is not None:
                 u = u_off + (1 - u_off) * i / max(len(ts), 1)
-                x = d_wrap(x, int(t), max(min(u, 0.999), 0))
+                x = d_model(x, int(t), max(min(u, 0.999), 0))
+            else:
+                x = self.unet(x, int(t))
             if callback is not None:
                 callback({"x": x, "i": i, "t": int(t)})
         return x
-
-
 
 
 def make_scheduler(sampler, generators, device, dtype=torch.float32):

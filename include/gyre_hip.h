@@ -191,7 +191,9 @@ int gyre_debug_gemm_ablation(int bits);
  * canonical_samples > 0 plans that factor as if every call held canonical_samples batch entries (16 = the
  * 8-images-with-CFG call of the headline configuration): results become bit-identical for ANY split of a batch
  * over GPUs or sub-batches, while calls much smaller than the canonical size fill the chip less well.
- * 0 (default) = plan for the actual batch.  Process-wide; returns the previous value. */
+ * 0 (default) = plan for the actual batch.  The setting belongs to the CALLING THREAD (one thread drives one device slot in
+ * the reference, manager.py:2107-2139): it affects the forwards and workspace queries that thread issues, nothing else.
+ * Returns the previous value. */
 int gyre_set_batch_invariant(int canonical_samples);
 int gyre_get_batch_invariant(void);
 

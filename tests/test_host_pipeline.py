@@ -581,3 +581,69 @@ def test_churn_semantics_and_pipeline_options(tiny):
     clipped = pipe(sigma_max=5.0, sigma_min=0.1, **kw)
     assert not torch.allclose(base, churned) and not torch.allclose(base, clipped)
     assert torch.equal(churned, pipe(churn=2.0, **kw))
+
+
+def test_pipeline_grafted_inpaint_tree(tiny):
+    """Grafted inpaint (reference unified_pipeline.py:2071-2100 + unet/graft.py:16-56): a masked request with an
+    inpaint_unet builds Graft(runway leaf on inpaint_unet, enhanced-inpaint leaf on unet); only the root runs before the
+    blend window, both inside it, only the top after it; with the hires fix the whole graft is duplicated at natural size."""
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    u9 = gcfg.tiny_unet(in_channels=9)
+    sd9 = weights.synthetic_state_dict(weights.unet_param_shapes(u9), 1)
+    calls = {"base": 0, "inpaint": 0}
+
+    class Counting:
+        def __init__(self, inner, name):
+            self.inner, self.name, self.config = inner, name, inner.config
+
+        def __call__(self, *a, **k):
+            calls[self.name] += 1
+            return self.inner(*a, **k)
+
+    base, inp = Counting(OracleUNet(usd, ucfg), "base"), Counting(OracleUNet(sd9, u9), "inpaint")
+    image = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 32:96, 32:96] = 1.0
+    kw = dict(seeds=[1, 2], text_embeddings=text, uncond_embeddings=unc, height=128, width=128, num_inference_steps=12,
+              sampler="euler", image=image, mask_image=mask, strength=1.0, output_type="latent")
+    pipe = GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp, grafted_inpaint=True)
+    out = pipe(**kw)
+    # u = i / 11: root only for i <= 1 (u <= 0.1), both for i = 2, 3, top only from i = 4 (u > 0.3)
+    assert (calls["inpaint"], calls["base"]) == (4, 10) and pipe.last_unet_evals == 14
+    assert out.shape == (2, 4, 16, 16) and bool(torch.isfinite(out).all())
+    # without the graft option the inpaint UNet does the whole request; without a mask the base UNet does
+    calls.update(base=0, inpaint=0)
+    GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp)(**kw)
+    assert (calls["inpaint"], calls["base"]) == (12, 0)
+    calls.update(base=0, inpaint=0)
+    GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp, grafted_inpaint=True)(**{**kw, "mask_image": None, "strength": 0.5})
+    assert (calls["inpaint"], calls["base"]) == (0, 6)
+    # diffusers-style samplers keep one multistep history: they refuse a multi-leaf tree
+    with pytest.raises(ValueError, match="single UNet"):
+        pipe(**{**kw, "sampler": "plms"})
+    # hires fix above the threshold: four leaves (natural + full size, each grafted)
+    calls.update(base=0, inpaint=0)
+    bmask = torch.zeros(1, 1, 192, 256)
+    bmask[:, :, 48:144, 64:192] = 1.0
+    big = dict(kw, height=192, width=256, image=torch.rand(1, 3, 192, 256), mask_image=bmask, num_inference_steps=6)
+    out = pipe(**big)
+    assert out.shape == (2, 4, 24, 32) and calls["inpaint"] > 0 and calls["base"] > 0
+
+
+def test_hires_init_image_draw_order_matches_reference_lifecycle(tiny):
+    """with hires fix + init image the reference constructs every leaf's mode first (masked-original posterior
+    samples: natural leaf, then full-size leaf) and only then generates start latents per leaf (init sample, noise).
+    The per-image generator therefore serves: orig(nat), orig(full), init(nat), noise(nat), init(full), noise(full)."""
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    order = []
+
+    class SpyVAE(OracleVAE):
+        def encode(self, x, **k):
+            order.append(("encode", tuple(x.shape[-2:])))
+            return super().encode(x, **k)
+
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), SpyVAE(vsd, vcfg), device="cpu")
+    pipe(seeds=[3], text_embeddings=text[:1], uncond_embeddings=unc[:1], height=192, width=256, num_inference_steps=3,
+         sampler="euler", image=torch.rand(1, 3, 192, 256), mask_image=torch.cat([torch.zeros(1, 1, 192, 128), torch.ones(1, 1, 192, 128)], 3),
+         strength=0.8, output_type="latent")
+    assert order == [("encode", (128, 128)), ("encode", (192, 256)), ("encode", (128, 128)), ("encode", (192, 256))]
