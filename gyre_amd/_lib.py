@@ -52,6 +52,7 @@ _SIGS = {
     "gyre_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_unet_set_context": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "gyre_unet_set_tome": (_i, [_vp, _i]),
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
@@ -85,6 +86,8 @@ _SIGS = {
     "gyre_op_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "gyre_op_qkv": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i]),
     "gyre_op_attention_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i]),
+    "gyre_op_tome_workspace": (_sz, [_i, _i, _i]),
+    "gyre_op_tome_merge": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
     "gyre_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gyre_op_copy_probe": (_i, [_vp, _vp, _vp, _sz]),
 }

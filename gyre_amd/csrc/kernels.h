@@ -72,6 +72,9 @@ struct GemmParams {
     int Hup = 0, Wup = 0;         // ups: logical size of the upsampled image (0 = 2*Hi x 2*Wi); < 2x crops the last row/col
     int samples = 0;              // batch entries folded into M (0 = unknown); used by the batch-invariant planner
     float* splitk_ws = nullptr; size_t splitk_ws_bytes = 0;  // fp32 partial slabs [splits][M][N] (see gemm_plan)
+    // batched form (4-wave kernels only): problem b uses A + b*bsA, W + b*bsW, out + b*bsC (element strides); no bias /
+    // residual / split-K.  Used for the per-sample token-similarity matrix of ToMe.
+    int batch = 1; size_t bsA = 0, bsW = 0, bsC = 0;
 };
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
@@ -89,3 +92,18 @@ struct AttnParams {
     int k_prescaled = 0;        // K already carries log2(e)/sqrt(D) (folded into the to_k weights at repack time)
 };
 int launch_attention(hipStream_t st, const AttnParams& p);
+
+// ---- ToMe: bipartite soft matching + merge of self-attention K / V tokens (kernels_tome.hip) ---------------------------
+struct TomeParams {
+    const bf16_t* k; int ldk;     // [B][N][ldk]  keys (row-major; any column offset already applied)
+    const bf16_t* v; int ldv;     // [B][N][ldv]  values (row-major)
+    int B, N, C, r;               // r tokens of the "a" half (even tokens) are merged into their best "b" (odd) match
+    bf16_t* k_out;                // [B][N - r][C]
+    bf16_t* vt_out; int ldvt;     // [B][C][ldvt]  merged values, transposed (what the attention kernel streams)
+    void* ws; size_t ws_bytes;    // tome_workspace_bytes(B, N, C)
+    int* order_out = nullptr;     // optional [B][N/2]: a-token indices by descending best-match score
+    int* node_idx_out = nullptr;  // optional [B][N/2]: best b match of every a token
+};
+size_t tome_workspace_bytes(int B, int N, int C);
+int tome_effective_r(int N, int r);       // min(r, N / 2), 0 when N < 2
+int launch_tome_merge(hipStream_t st, const TomeParams& p);

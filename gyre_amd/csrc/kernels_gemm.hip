@@ -581,6 +581,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
     uint4* lds = (uint4*)smem_raw;  // stage s: A at s*(BM+BN)*8, B right after A; 8 x uint4 per row
     constexpr int STAGE = (BM + BN) * 8;
 
+    if (p.batch > 1) {   // batched form: one problem per blockIdx.y
+        p.A += (size_t)blockIdx.y * p.bsA; p.A2 += (size_t)blockIdx.y * p.bsA; p.W += (size_t)blockIdx.y * p.bsW;
+        p.out = (bf16_t*)p.out + (size_t)blockIdx.y * p.bsC;
+    }
     // ---- XCD-aware, bijective tile order: tile id -> (tm, tn) with tn fastest -------------
     const int bid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
     const int tn = bid % tiles_n, tm = bid / tiles_n;
@@ -785,7 +789,7 @@ static int launch_cfg(hipStream_t st, const GemmParams& p) {
         static std::atomic<unsigned long long> attr_done{0};                                                                               \
         if (gyre_lds_attr_needed(attr_done))                                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n);                              \
+        hipLaunchKernelGGL(kern, dim3(grid, p.batch > 1 ? p.batch : 1), dim3(256), lds, st, p, tiles_m, tiles_n);       \
     } while (0)
     if (p.mode == GEMM_LINEAR) {
         if (trans) GYRE_GEMM_GO(GEMM_LINEAR, true, true); else GYRE_GEMM_GO(GEMM_LINEAR, true, false);
@@ -1260,7 +1264,7 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     consider(3, 0.30, 64, 64, 4);
     consider(1, 0.55, 128, 128, 2);
     consider(2, 0.50, 256, 64, 2);
-    if (!trans) {
+    if (!trans && p.batch <= 1) {
         // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the
         // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
         auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
@@ -1362,6 +1366,8 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.geglu && (p.N % 32)) GYRE_FAIL(-1, "gemm: GEGLU needs N % 32 == 0");
     if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
     if (p.out_mode == OUT_BF16_T && p.tokens_per_batch <= 0) GYRE_FAIL(-1, "gemm: tokens_per_batch required");
+    if (p.batch > 1 && (p.mode != GEMM_LINEAR || p.out_mode != OUT_BF16 || p.bias || p.residual || p.rowbias || p.geglu || p.vt_out))
+        GYRE_FAIL(-1, "gemm: the batched form is a plain bf16 matrix product");
     if (p.vt_out) {
         if (p.out_mode != OUT_BF16 || p.geglu || p.residual || p.tokens_per_batch <= 0 || p.tokens_per_batch % 8 || p.ldt % 8 ||
             p.vt_col0 <= 0 || p.vt_col0 >= p.N || p.N % 8)

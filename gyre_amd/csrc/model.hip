@@ -269,6 +269,7 @@ struct Exec {
     const std::vector<CtxKV>* ctx_cache = nullptr;
     size_t ctx_layer = 0;
     int batch = 0;   // samples in the current call (planner hint, see gemm_set_batch_invariant)
+    int tome_r = 0;  // ToMe: keys / values merged per self-attention (0 = off; reference option "tome", nonfree/tome_unet.py)
 
     bool dry() const { return arena.dry; }
     int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
@@ -383,7 +384,29 @@ struct Exec {
         const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
         Tn q, k, vt, ao;
         const bf16_t *qp, *kp, *vtp = nullptr; int ldq, ldk, Nk, ldvt;
-        if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
+        Tn km, vrow, tws;
+        const int tr = (!cross && tome_r > 0 && Nq % 16 == 0) ? tome_effective_r(Nq, tome_r) : 0;
+        if (!cross && tr > 0) {
+            // ToMe (nonfree/tome_unet.py:138-182): K and V of a self-attention are projected row-major, the r most
+            // redundant even-position keys are averaged into their best odd-position match (values follow the same
+            // assignment), and the attention runs against N - r keys.  Queries are untouched.
+            Nk = Nq - tr; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, 2 * C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
+            TRY(alloc(vrow, B, xq.H, xq.W, C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wv, C, w.bv, nullptr, 0, 0, vrow.p, C));
+            TRY(alloc(km, B, Nk, 1, C));
+            TRY(alloc(vt, B, C, 1, ldvt));
+            TRY(alloc_raw(tws, tome_workspace_bytes(B, Nq, C)));
+            if (!dry()) {
+                TomeParams tp;
+                tp.k = q.p + C; tp.ldk = 2 * C; tp.v = vrow.p; tp.ldv = C; tp.B = B; tp.N = Nq; tp.C = C; tp.r = tr;
+                tp.k_out = km.p; tp.vt_out = vt.p; tp.ldvt = ldvt; tp.ws = tws.p; tp.ws_bytes = tws.bytes;
+                TRY(launch_tome_merge(st, tp));
+            }
+            free(tws); free(vrow);
+            qp = q.p; kp = km.p; vtp = vt.p; ldq = 2 * C; ldk = C;
+        } else if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, 2 * C));
             TRY(alloc(vt, B, C, 1, ldvt));
@@ -431,7 +454,7 @@ struct Exec {
             a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = w.k_prescaled;
             TRY(launch_attention(st, a));
         }
-        free(q); free(k); free(vt);
+        free(q); free(k); free(vt); free(km);
         TRY(alloc(out, B, xq.H, xq.W, C));
         TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C));
         free(ao);
@@ -1026,6 +1049,23 @@ size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     }
     return peak;
 }
+int gyre_unet_set_tome(gyre_unet* h, int r) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null handle");
+    if (r < 0) GYRE_FAIL(GYRE_ERR_INVALID, "tome: r must be >= 0");
+    h->ex.tome_r = r;
+    return 0;
+}
+size_t gyre_op_tome_workspace(int B, int N, int C) { return tome_workspace_bytes(B, N, C); }
+int gyre_op_tome_merge(void* st, const void* k, int ldk, const void* v, int ldv, int B, int N, int C, int r, void* ws, size_t wsb,
+                       void* k_out, void* vt_out, int ldvt, int32_t* order_out, int32_t* node_idx_out) {
+    if (!k || !v || !ws || !k_out || !vt_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    TomeParams p;
+    p.k = (const bf16_t*)k; p.ldk = ldk; p.v = (const bf16_t*)v; p.ldv = ldv; p.B = B; p.N = N; p.C = C; p.r = r;
+    p.k_out = (bf16_t*)k_out; p.vt_out = (bf16_t*)vt_out; p.ldvt = ldvt; p.ws = ws; p.ws_bytes = wsb;
+    p.order_out = order_out; p.node_idx_out = node_idx_out;
+    return launch_tome_merge((hipStream_t)st, p);
+}
+
 int gyre_unet_set_context(gyre_unet* h, void* st, const void* ctx, int cdt, int B, int S) {
     if (!h || !ctx) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");

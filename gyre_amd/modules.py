@@ -245,6 +245,17 @@ class GyreHipUNet(_NativeModule):
         cfg.freq_shift = c.freq_shift
         return cfg
 
+    def set_tome(self, r: int) -> None:
+        """Token merging for the self-attentions (reference pipeline option ``tome: <r>``, unified_pipeline.py:1580-1588,
+        nonfree/tome_patcher.py:14-52): merge the r most redundant keys / values of every self-attention (clipped to half
+        the tokens of the layer).  0 switches it off."""
+        r = int(r)
+        if r < 0:
+            raise ValueError("tome r must be >= 0")
+        self._tome_r = r
+        if self._handle is not None:
+            _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(self._handle), r))
+
     def _aug_embedding(self, added_cond_kwargs, B: int, dev) -> Optional[torch.Tensor]:
         """SDXL text_time conditioning: tiny MLP on the host (PyTorch-ROCm), result handed to the native call."""
         if self.config.addition_embed_type != "text_time":
@@ -281,6 +292,9 @@ class GyreHipUNet(_NativeModule):
                              f"got {tuple(encoder_hidden_states.shape)}")
         dev = sample.device
         h = self._sync(dev)
+        if getattr(self, "_tome_applied", (None, None)) != (h, getattr(self, "_tome_r", 0)):
+            _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
+            self._tome_applied = (h, getattr(self, "_tome_r", 0))
         x = sample.contiguous()
         ctx = encoder_hidden_states.to(dev).contiguous()
         _lib.require_gpu_tensor(x, "latents")

@@ -129,6 +129,14 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
  * In the reference the same tensor is re-projected on every call (unet/core.py:253-259 binds it per wrapper). */
 int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_dtype, int B, int S);
 
+/* Token merging (ToMe) for the UNet's self-attentions - the reference's pipeline option "tome: <r>"
+ * (gyre/pipeline/unified_pipeline.py:1580-1588 -> nonfree/tome_patcher.py:14-52, nonfree/tome_unet.py:138-182,243):
+ * before each self-attention the r most redundant keys (even token positions, by cosine similarity to their best
+ * odd-position match - bipartite soft matching) are averaged into that match, values follow, and the attention runs
+ * against N - r keys; r is clipped to N / 2 per layer as ToMe does.  0 switches it off (default).  The matching
+ * algorithm lives in the un-vendored facebookresearch/ToMe submodule; restated from the paper, parity unpinned. */
+int gyre_unet_set_tome(gyre_unet* h, int r);
+
 /* Parity tests only: the next forward copies the named intermediate activation (f32, NCHW) into out.  Names follow
  * the oracle's taps: "down<i>" (end of down level i, after its downsampler), "mid", "up<i>" (end of up level i, after
  * its upsampler).  Taps are cleared by that forward. */
@@ -232,6 +240,13 @@ int gyre_op_qkv(void* stream, const void* x, int M, int C, const void* w_qkv, in
  * fp32 before their bf16 rounding), which lets the kernel take exp2 of the matrix-core output directly. */
 int gyre_op_attention_ex(void* stream, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt,
                          int B, int heads, int Nq, int Nk, int D, void* o, int ldo, int k_prescaled);
+/* ToMe merge of one self-attention's keys / values: k[B,N,ldk], v[B,N,ldv] (bf16 rows of C channels) ->
+ * k_out[B,N-r,C], vt_out[B,C,ldvt] (values transposed, columns >= N-r zero); optional order_out / node_idx_out [B,N/2]
+ * (int32, dev) receive the a-token ranking and every a token's best match.  r is clipped to N / 2. */
+size_t gyre_op_tome_workspace(int B, int N, int C);
+int gyre_op_tome_merge(void* stream, const void* k, int ldk, const void* v, int ldv, int B, int N, int C, int r,
+                       void* workspace, size_t workspace_bytes, void* k_out, void* vt_out, int ldvt,
+                       int32_t* order_out, int32_t* node_idx_out);
 int gyre_op_nchw_to_nhwc(void* stream, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y_bf16);
 /* Device-side memcpy-rate probe used by bench.py to calibrate the HBM roofline on the box. */
 int gyre_op_copy_probe(void* stream, const void* src, void* dst, size_t bytes);

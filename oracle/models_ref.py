@@ -119,12 +119,16 @@ def attention(q: Tensor, k: Tensor, v: Tensor, heads: int) -> Tensor:
     return out.reshape(B, heads, Nq, d).permute(0, 2, 1, 3).reshape(B, Nq, C)
 
 
-def basic_transformer_block(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int) -> Tensor:
-    """BasicTransformerBlock [3P]: LN+self-attn, LN+cross-attn, LN+GEGLU-FF (erf gelu)."""
+def basic_transformer_block(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int, tome_r: int = 0) -> Tensor:
+    """BasicTransformerBlock [3P]: LN+self-attn, LN+cross-attn, LN+GEGLU-FF (erf gelu).
+    tome_r > 0: ToMe on the self-attention's keys / values (reference nonfree/tome_unet.py:138-182; oracle/tome_ref.py)."""
     C = x.shape[-1]
     h = F.layer_norm(x, (C,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
-    a = attention(_lin(h, sd, p + ".attn1.to_q"), _lin(h, sd, p + ".attn1.to_k"),
-                  _lin(h, sd, p + ".attn1.to_v"), heads)
+    k1, v1 = _lin(h, sd, p + ".attn1.to_k"), _lin(h, sd, p + ".attn1.to_v")
+    if tome_r > 0 and h.shape[1] % 16 == 0:           # the native path merges when the token count is a multiple of 16
+        from . import tome_ref
+        k1, v1 = tome_ref.tome_merge_kv(k1, v1, tome_r)
+    a = attention(_lin(h, sd, p + ".attn1.to_q"), k1, v1, heads)
     x = x + _lin(a, sd, p + ".attn1.to_out.0")
     h = F.layer_norm(x, (C,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
     a = attention(_lin(h, sd, p + ".attn2.to_q"), _lin(ctx, sd, p + ".attn2.to_k"),
@@ -139,7 +143,7 @@ def basic_transformer_block(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int) 
 
 
 def transformer_2d(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int, groups: int, depth: int,
-                   linear_proj: bool) -> Tensor:
+                   linear_proj: bool, tome_r: int = 0) -> Tensor:
     """Transformer2DModel [3P]: GN(eps 1e-6), proj_in, blocks, proj_out, + residual."""
     B, C, H, W = x.shape
     res = x
@@ -151,7 +155,7 @@ def transformer_2d(x: Tensor, ctx: Tensor, sd: SD, p: str, heads: int, groups: i
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = _lin(h, sd, p + ".proj_in")
     for d in range(depth):
-        h = basic_transformer_block(h, ctx, sd, f"{p}.transformer_blocks.{d}", heads)
+        h = basic_transformer_block(h, ctx, sd, f"{p}.transformer_blocks.{d}", heads, tome_r)
     if not linear_proj:
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = _conv(h, sd, p + ".proj_out", padding=0)
@@ -175,7 +179,7 @@ def added_cond_embedding(sd: SD, cfg, text_embeds: Tensor, time_ids: Tensor) -> 
 
 
 def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder_hidden_states: Tensor,
-                 taps: Optional[dict] = None, added_cond: Optional[dict] = None) -> Tensor:
+                 taps: Optional[dict] = None, added_cond: Optional[dict] = None, tome_r: int = 0) -> Tensor:
     """eps = unet(latents[NCHW], t[int64 N], ctx[N,S,D]).  ``taps`` (optional dict)
     receives named intermediate activations for block-level parity tests."""
     g, eps = cfg.norm_num_groups, 1e-5
@@ -198,7 +202,7 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
             h = resnet_block(h, temb, sd, f"down_blocks.{i}.resnets.{j}", g, eps)
             if cfg.attn_levels[i]:
                 h = transformer_2d(h, encoder_hidden_states, sd, f"down_blocks.{i}.attentions.{j}",
-                                   cfg.num_heads[i], g, cfg.transformer_depth[i], cfg.use_linear_projection)
+                                   cfg.num_heads[i], g, cfg.transformer_depth[i], cfg.use_linear_projection, tome_r)
             skips.append(h)
         if i < nlev - 1:
             h = _conv(h, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
@@ -208,7 +212,7 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
 
     h = resnet_block(h, temb, sd, "mid_block.resnets.0", g, eps)
     h = transformer_2d(h, encoder_hidden_states, sd, "mid_block.attentions.0", cfg.num_heads[-1], g,
-                       cfg.transformer_depth[-1], cfg.use_linear_projection)
+                       cfg.transformer_depth[-1], cfg.use_linear_projection, tome_r)
     h = resnet_block(h, temb, sd, "mid_block.resnets.1", g, eps)
     if taps is not None:
         taps["mid"] = h
@@ -220,7 +224,7 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
             h = resnet_block(h, temb, sd, f"up_blocks.{i}.resnets.{j}", g, eps)
             if cfg.attn_levels[lvl]:
                 h = transformer_2d(h, encoder_hidden_states, sd, f"up_blocks.{i}.attentions.{j}",
-                                   cfg.num_heads[lvl], g, cfg.transformer_depth[lvl], cfg.use_linear_projection)
+                                   cfg.num_heads[lvl], g, cfg.transformer_depth[lvl], cfg.use_linear_projection, tome_r)
         if i < nlev - 1:
             # diffusers resizes to the next skip connection's size (forward_upsample_size) - 2x unless a level is odd
             h = F.interpolate(h, size=skips[-1].shape[-2:], mode="nearest")

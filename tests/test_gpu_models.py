@@ -229,3 +229,51 @@ def test_unet_per_level_parity(full):
     _lib.check(L.gyre_unet_debug_tap(C.c_void_p(net._handle), b"mid", C.c_void_p(small.data_ptr()), 16))
     with pytest.raises(ValueError):
         net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))
+
+
+@pytest.mark.parametrize("r", [8, 40, 1000])
+def test_tiny_unet_tome_parity(r):
+    """ToMe in the native UNet (reference option "tome: r", nonfree/tome_unet.py:138-182) vs the oracle UNet with the
+    restated algorithm (oracle/tome_ref.py, same tie rules and roundings).  r = 1000 exceeds every level's N / 2 and is
+    clipped per layer; the result must differ from the unmerged UNet (the feature is really on)."""
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x, t, ctx = randn(2, 4, 16, 16, seed=61), torch.tensor([500, 40]), randn(2, 77, cfg.cross_attention_dim, seed=62)
+    base = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+    net.set_tome(r)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+    ref = M.unet_forward(sd, cfg, x, t, ctx, tome_r=r)
+    report(f"tiny unet + ToMe r={r}", got, ref, 3e-2)
+    assert float((got - base).norm() / base.norm()) > 1e-3
+    net.set_tome(0)
+    assert torch.equal(net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu(), base)
+
+
+def test_sd15_unet_tome_full_size_properties():
+    """BASELINE config 5 shape (SD1.5, batch 16 = 8 images x CFG, 64x64 latents) with ToMe r = 1024: finite, deterministic,
+    close to the unmerged prediction (merging redundant keys is an approximation of the same attention), and faster
+    attention is reported by tools/, not asserted here."""
+    import gpu_util
+    cfg = gcfg.sd15_unet()
+    net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.ndim > 1:
+                p.copy_(torch.randn(p.shape, device=DEV, generator=g, dtype=torch.float32) / p[0].numel() ** 0.5)
+            elif "norm" in k and k.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    net._invalidate()
+    x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
+    ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
+    t = torch.full((16,), 500, device=DEV)
+    base = net(x, t, encoder_hidden_states=ctx).sample
+    net.set_tome(1024)
+    a = net(x, t, encoder_hidden_states=ctx).sample
+    b = net(x, t, encoder_hidden_states=ctx).sample
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    rel = float((a - base).norm() / base.norm())
+    print(f"[property] SD1.5 UNet with ToMe r=1024 vs without: rel-L2 {rel:.3e}")
+    assert 1e-4 < rel < 0.5
