@@ -1,0 +1,275 @@
+"""Engine-level drop-in: the reference's ``UnifiedPipeline`` call contract over the native pipeline.
+
+An existing Gyre server selects it in engines.yaml:
+
+    - id: "stable-diffusion-v1-5-mi355x"
+      class: "gyre_amd.engine.GyreUnifiedPipeline"
+      model: "@sd15"
+      overrides:
+        unet: {class: "gyre_amd.modules.GyreHipUNet"}
+        vae:  {class: "gyre_amd.modules.GyreHipVAE"}
+
+and everything above it stays the reference's own code: ``EngineManager`` builds the object from the loaded modules
+(manager.py:1712-1783: ``Class(**modules)``), wraps it in ``DiffusionPipelineWrapper`` (pipeline_wrapper.py:164-397), the
+gRPC servicer (services/generate.py:992-1152) calls the wrapper with the request's kwargs and turns the returned tensors
+into PNG artifacts.  What this class has to honour is therefore exactly what the wrapper touches:
+
+  * constructor keywords = module names (vae, text_encoder, tokenizer, unet, scheduler, inpaint_unet, ...);
+    ``pipeline_modules()`` so that ``PipelineWrapper.activate(device)`` can swap in per-device clones (:96-131)
+  * ``scheduler`` attribute: the wrapper injects the sampler chosen by the request (:255-267) - a k-diffusion sampler
+    callable or a diffusers scheduler object; it is mapped back to the native sampler of the same name
+  * ``progress_bar`` attribute: wrapped around the step iterable, raises ``ProgressBarAbort`` on cancellation (:26-47)
+  * ``__call__`` keywords of ``UnifiedPipeline.__call__`` (unified_pipeline.py:1722-1790) - the wrapper filters its
+    kwargs by this signature (:269-286) - returning ``(images [B,3,H,W] in 0..1, nsfw flags)`` for
+    ``output_type="tensor", return_dict=False`` (:2512-2534)
+  * ``set_options`` with the reference's option names (unified_pipeline.py:1538-1629)
+  * no-op memory knobs (attention / VAE slicing, xformers): 288 GB of HBM3E, the whole batch stays resident.
+
+Features outside the native hot path raise NotImplementedError (-> gRPC UNIMPLEMENTED, services/exception_to_grpc.py):
+CLIP guidance, depth / hint images (ControlNet, T2I), textual-inversion token embeddings, tiling.
+"""
+from __future__ import annotations
+
+import functools
+from typing import Any, Callable, List, Optional
+
+import torch
+
+from . import lora as LR
+from .pipeline import GyrePipeline
+from .text import LPWTextEmbedder
+
+# sampler callables (k-diffusion function names, reference samplers.py:47-67) / diffusers scheduler classes (:24-45)
+_K_NAMES = {"sample_lms": "lms", "sample_euler": "euler", "sample_euler_ancestral": "euler_a", "sample_dpm_2": "dpm_2",
+            "sample_dpm_2_ancestral": "dpm_2_a", "sample_heun": "heun", "sample_dpm_fast": "dpm_fast",
+            "sample_dpm_adaptive": "dpm_adaptive", "sample_dpmpp_2s_ancestral": "dpmpp_2s_a", "sample_dpmpp_sde": "dpmpp_sde",
+            "sample_dpmpp_2m": "dpmpp_2m"}
+_D_NAMES = {"DDIMScheduler": "ddim", "PNDMScheduler": "plms", "LMSDiscreteScheduler": "lms", "EulerDiscreteScheduler": "euler",
+            "EulerAncestralDiscreteScheduler": "euler_a", "DPM2DiscreteScheduler": "dpm_2",
+            "DPM2AncestralDiscreteScheduler": "dpm_2_a", "HeunDiscreteScheduler": "heun"}
+
+
+def sampler_name(scheduler: Any) -> str:
+    """The native sampler for what the reference's wrapper injected as ``pipeline.scheduler``."""
+    if isinstance(scheduler, str):
+        return scheduler
+    fn = scheduler
+    while isinstance(fn, functools.partial):
+        fn = fn.func
+    name = getattr(fn, "__name__", None)
+    if name in _K_NAMES:
+        return _K_NAMES[name]
+    cls = type(scheduler).__name__
+    if cls == "DPMSolverMultistepScheduler":
+        cfg = getattr(scheduler, "config", None)
+        order = cfg.get("solver_order", 2) if isinstance(cfg, dict) else getattr(cfg, "solver_order", 2)
+        return f"dpmsolverpp_{int(order) if isinstance(order, int) else 2}"
+    if cls in _D_NAMES:
+        return _D_NAMES[cls]
+    raise NotImplementedError(f"Scheduler not implemented: {scheduler!r}")
+
+
+class GyreUnifiedPipeline:
+    # reference UnifiedPipeline._meta (unified_pipeline.py:1265): both sampler families; weights stay resident (no offload)
+    _meta = {"diffusers_capable": True, "kdiffusion_capable": True, "offload_capable": False}
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler=None, safety_checker=None, feature_extractor=None,
+                 clip_model=None, clip_tokenizer=None, inpaint_unet=None, inpaint_text_encoder=None, depth_unet=None,
+                 depth_text_encoder=None, hintset_manager=None, **_unused):
+        self.vae, self.text_encoder, self.tokenizer, self.unet = vae, text_encoder, tokenizer, unet
+        self.scheduler, self.inpaint_unet = scheduler, inpaint_unet
+        self.safety_checker, self.feature_extractor = safety_checker, feature_extractor
+        self.clip_model, self.clip_tokenizer = clip_model, clip_tokenizer
+        self.hintset_manager = hintset_manager
+        self.progress_bar: Optional[Callable] = None
+        self._grafted_inpaint: Any = False
+        self._hires_fix, self._hires_threshold_fraction = True, 0.0333
+        self._hires_oos_fraction, self._hires_image_oos_fraction = 0.6, 1.0
+        self._text_embedding_layer = "final"
+        self._tome = 0
+
+    # ---- what PipelineWrapper / DiffusionPipelineWrapper touch -----------------------------------------------------------
+    def pipeline_modules(self):
+        for name in ("vae", "text_encoder", "unet", "inpaint_unet"):
+            m = getattr(self, name, None)
+            if isinstance(m, torch.nn.Module):
+                yield name, m
+
+    @property
+    def execution_device(self) -> torch.device:
+        return next(self.unet.parameters()).device
+
+    device = execution_device
+
+    def to(self, device):
+        for name, m in list(self.pipeline_modules()):
+            setattr(self, name, m.to(device))
+        return self
+
+    def enable_attention_slicing(self, *_a, **_k): pass
+    def disable_attention_slicing(self, *_a, **_k): pass
+    def enable_vae_slicing(self): pass
+    def disable_vae_slicing(self): pass
+    def enable_xformers_memory_efficient_attention(self, *_a, **_k): pass
+    def disable_xformers_memory_efficient_attention(self): pass
+
+    def set_options(self, options: dict) -> None:
+        """Engine ``options:`` of engines.yaml (reference unified_pipeline.py:1538-1629)."""
+        for key, value in options.items():
+            if key == "hires":
+                if isinstance(value, bool):
+                    self._hires_fix = value
+                else:
+                    for sk, sv in value.items():
+                        if sk == "enable":
+                            self._hires_fix = bool(sv)
+                        elif sk == "oos_fraction":
+                            self._hires_oos_fraction = float(sv)
+                        elif sk == "image_oos_fraction":
+                            self._hires_image_oos_fraction = float(sv)
+                        elif sk == "threshold_fraction":
+                            self._hires_threshold_fraction = float(sv)
+                        else:
+                            raise ValueError(f"Unknown option {sk}: {sv} passed as part of hires settings")
+            elif key == "grafted_inpaint":
+                self._grafted_inpaint = value if isinstance(value, dict) else bool(value)
+            elif key == "tome":
+                self._tome = int(value) if value else 0
+            elif key == "clip_skip":
+                self._text_embedding_layer = "penultimate" if value else "final"
+            elif key in ("xformers", "vae_tiling", "structured_diffusion"):
+                pass                                       # memory knobs / deprecated: accepted, nothing to do
+            elif key in ("grafted_depth", "clip"):
+                if value:
+                    raise NotImplementedError(f"option {key!r} is outside the native hot path")
+            else:
+                raise ValueError(f"Unknown option {key}: {value} passed to UnifiedPipeline")
+
+    # ---- text -------------------------------------------------------------------------------------------------------------
+    def _embed(self, prompt, negative_prompt, B, num_images_per_prompt, do_cfg, max_embeddings_multiples):
+        def frags(p):                                       # str | Prompt | list | PromptBatch -> list of [(text, weight)] / str
+            if p is None:
+                return None
+            if hasattr(p, "as_tokens") and hasattr(p, "prompts"):
+                return p.as_tokens()
+            if hasattr(p, "as_tokens"):
+                return [p.as_tokens()]
+            if isinstance(p, (list, tuple)):
+                return [q.as_tokens() if hasattr(q, "as_tokens") else q for q in p]
+            return [p]
+        pos = frags(prompt)
+        neg = frags(negative_prompt) or [""] * len(pos)
+        if len(neg) == 1 and len(pos) > 1:
+            neg = neg * len(pos)
+        te, dev = self.text_encoder, self.execution_device
+        layer = self._text_embedding_layer
+
+        def encode(ids):
+            final = layer == "final"
+            out = te(input_ids=ids.to(dev), output_hidden_states=not final, return_dict=True)
+            if final:
+                return out.last_hidden_state.float()
+            tower = getattr(te, "text_model", te)
+            return tower.final_layer_norm(out.hidden_states[-2]).float()
+        encode.device = dev
+        tok = self.tokenizer
+
+        def tokenize(text):
+            return tok(text, add_special_tokens=False)["input_ids"] if callable(tok) else tok.encode(text)[1:-1]
+        emb = LPWTextEmbedder(encode, tokenize, max_embeddings_multiples)
+        cond, unc = emb.get_embeddings(pos, neg if do_cfg else None)
+        rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
+        return rep(cond), rep(unc)
+
+    # ---- the generation call (keywords of reference UnifiedPipeline.__call__, unified_pipeline.py:1722-1790) ---------------
+    @torch.no_grad()
+    def __call__(self, prompt, height: int = 512, width: int = 512, image=None, mask_image=None, outmask_image=None,
+                 depth_map=None, hint_images=None, strength: Optional[float] = None, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: int = 1,
+                 prediction_type: Optional[str] = "epsilon", eta: Optional[float] = None, churn: Optional[float] = None,
+                 churn_tmin: Optional[float] = None, churn_tmax: Optional[float] = None, sigma_min: Optional[float] = None,
+                 sigma_max: Optional[float] = None, karras_rho: Optional[float] = None, scheduler_noise_type: str = "normal",
+                 generator=None, latents=None, max_embeddings_multiples: int = 3, output_type: str = "pil",
+                 return_dict: bool = True, callback=None, callback_steps: int = 1, clip_guidance_scale: Optional[float] = None,
+                 clip_guidance_base: Optional[str] = None, clip_prompt=None, lora=None, token_embeddings=None,
+                 hires_fix=None, hires_oos_fraction=None, tiling=False, debug_latent_tags=None, debug_latent_prefix="",
+                 cfg_execution: str = "parallel"):
+        if clip_guidance_scale:
+            raise NotImplementedError("CLIP guidance needs backward kernels: outside the native hot path")
+        if depth_map is not None or hint_images:
+            raise NotImplementedError("depth / hint conditioning (ControlNet, T2I adapters) is outside the native hot path")
+        if token_embeddings:
+            raise NotImplementedError("textual-inversion token embeddings are outside the native hot path")
+        if tiling:
+            raise NotImplementedError("tiling mode is not implemented natively")
+        if scheduler_noise_type not in (None, "normal"):
+            raise NotImplementedError("only normal sampler noise is implemented (brownian needs torchsde)")
+        if latents is not None:
+            raise NotImplementedError("caller-supplied start latents")
+        if self.scheduler is None:
+            raise ValueError("no scheduler injected")
+        n_prompts = len(prompt.prompts) if hasattr(prompt, "prompts") else (len(prompt) if isinstance(prompt, (list, tuple)) else 1)
+        B = n_prompts * num_images_per_prompt
+        if generator is None:
+            generators = [torch.Generator("cpu").manual_seed(torch.seed() % (2 ** 31)) for _ in range(B)]
+        else:
+            generators = list(generator) if isinstance(generator, (list, tuple)) else [generator]
+            if len(generators) != B:
+                if len(generators) == 1 and B > 1:
+                    raise ValueError("one torch.Generator per image is required for batch-independent results")
+                raise ValueError(f"Generator passed as a list, but list length does not match batch size {B}")
+        do_cfg = guidance_scale > 1.0
+        cond, unc = self._embed(prompt, negative_prompt, B, num_images_per_prompt, do_cfg, max_embeddings_multiples)
+        if strength is None:
+            strength = 0.8
+        dev = self.execution_device
+        pipe = GyrePipeline(self.unet, self.vae, None, device=dev, inpaint_unet=self.inpaint_unet,
+                            grafted_inpaint=self._grafted_inpaint)
+        pipe.hires_fix, pipe.hires_threshold_fraction = self._hires_fix, self._hires_threshold_fraction
+        pipe.hires_oos_fraction, pipe.hires_image_oos_fraction = self._hires_oos_fraction, self._hires_image_oos_fraction
+        for u in (self.unet, self.inpaint_unet):
+            if u is None:
+                continue
+            LR.remove_lora_from_model(u)                    # the reference strips leftovers on every call (:2190-2200)
+            if hasattr(u, "set_tome"):
+                u.set_tome(self._tome)
+        if lora:
+            for i, spec in enumerate(lora if isinstance(lora, (list, tuple)) else [lora]):
+                tensors, weights = (spec if isinstance(spec, (list, tuple)) else (spec, {}))
+                scale = (weights or {}).get("unet", 1.0) if isinstance(weights, dict) else 1.0
+                LR.apply_lora(self.unet, tensors, f"request-{i}", scale)
+        steps_seen = []
+
+        def cb(info):
+            steps_seen.append(info.get("i", len(steps_seen)))
+            if callback is not None and len(steps_seen) % max(callback_steps, 1) == 0:
+                callback(len(steps_seen) - 1, info.get("t"), info.get("x"))
+        if self.progress_bar is not None:
+            # the wrapper's tqdm object polls the stop event on every update (ProgressBarWrapper, pipeline_wrapper.py:26-47)
+            bar = self.progress_bar(total=num_inference_steps)
+            cb_inner = cb
+
+            def cb(info, _b=bar):
+                cb_inner(info)
+                if hasattr(_b, "update"):
+                    _b.update(1)
+        to_dev = lambda t: None if t is None else t.to(dev)
+        images = pipe(generators=generators, text_embeddings=cond, uncond_embeddings=unc, height=height, width=width,
+                      num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                      sampler=sampler_name(self.scheduler), image=to_dev(image), mask_image=to_dev(mask_image),
+                      strength=strength, karras_rho=karras_rho, eta=eta, cfg_execution=cfg_execution, callback=cb,
+                      hires_fix=hires_fix, hires_oos_fraction=hires_oos_fraction, outmask_image=to_dev(outmask_image),
+                      prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
+                      churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
+                      sigma_max=sigma_max)
+        images = images.float().cpu()                       # reference: result_image.cpu() ... BCHW 0..1 (:2512-2531)
+        nsfw: List[bool] = [False] * images.shape[0]       # tests / engines run with nsfw_behaviour "ignore"
+        if output_type == "pil":
+            from PIL import Image
+            images = [Image.fromarray((im.permute(1, 2, 0).numpy() * 255).round().astype("uint8")) for im in images]
+        elif output_type not in ("tensor", "pt"):
+            raise ValueError(f"output_type {output_type!r}")
+        if not return_dict:
+            return images, nsfw
+        from types import SimpleNamespace
+        return SimpleNamespace(images=images, nsfw_content_detected=nsfw)

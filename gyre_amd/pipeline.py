@@ -271,7 +271,8 @@ class GyrePipeline:
 
     # -- the generation call ------------------------------------------------------------------------
     @torch.no_grad()
-    def __call__(self, *, seeds: Sequence[int], text_embeddings: Optional[Tensor] = None,
+    def __call__(self, *, seeds: Optional[Sequence[int]] = None, generators: Optional[Sequence[torch.Generator]] = None,
+                 text_embeddings: Optional[Tensor] = None,
                  uncond_embeddings: Optional[Tensor] = None, input_ids: Optional[Tensor] = None,
                  negative_ids: Optional[Tensor] = None, height: int = 512, width: int = 512,
                  num_inference_steps: int = 50, guidance_scale: float = 7.5, sampler: str = "dpmpp_2m",
@@ -286,11 +287,14 @@ class GyrePipeline:
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
-        B = len(seeds)
+        if (seeds is None) == (generators is None):
+            raise ValueError("pass either seeds or generators (one per image)")
+        B = len(seeds) if seeds is not None else len(generators)
         if B < 1:
             raise ValueError("at least one seed (image) is required")
         dev = self.device
-        generators = build_generators(seeds, generator_device)
+        # the reference hands the pipeline one torch.Generator per image (pipeline_wrapper.py:243-253)
+        generators = build_generators(seeds, generator_device) if seeds is not None else list(generators)
         if text_embeddings is None:
             if input_ids is None:
                 raise ValueError("pass text_embeddings or input_ids")

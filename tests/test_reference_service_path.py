@@ -1,0 +1,44 @@
+"""the Stability-API request path stays the REFERENCE's own code and runs over the native engine class.
+
+north_star: "the gRPC/REST Stability-API surface, engines_yaml config and manager.py model loading remain drop-in".  Nothing
+of that surface is rebuilt here; instead tests/golden/ref_service_probe.py EXECUTES it from /root/reference (absent
+third-party roots stubbed, PNG codec swapped for PIL) on top of gyre_amd.engine.GyreUnifiedPipeline:
+
+  level 1  DiffusionPipelineWrapper.__call__   gyre/pipeline/pipeline_wrapper.py:288-397 (seed -> generators :243-253,
+           sampler enum -> injected scheduler :255-267, kwargs filtered by the pipeline signature :269-286,
+           ProgressBarWrapper cancellation :26-47)
+  level 2  GenerationServiceServicer.Generate  gyre/services/generate.py:1174-1185 -> generate_request :992-1152
+           (ParameterExtractor :393-935, batched_seeds :959-990, image_to_artifact :50-85): a generation_pb2.Request in,
+           Answer artifacts (PNG, per-image seed) out
+
+with oracle UNet / VAE arithmetic on the CPU (this container has no GPU; the native modules satisfy the same module
+contract, tests/test_reference_manager_loading.py).  Build container only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+
+
+def test_reference_wrapper_and_grpc_servicer_run_over_the_native_engine_class():
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "ref_service_probe.py")], env=env,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if "PROBE_JSON " in l]
+    assert r.returncode == 0 and line, (r.stdout + r.stderr)[-3000:]
+    out = json.loads(line[0].split("PROBE_JSON ", 1)[1])
+    # level 1: the reference's pipeline wrapper
+    assert out["samplers"] >= 17                                         # every sampler enum of the reference is on offer
+    assert out["l1_shape"] == [2, 3, 128, 128] and out["l1_range_ok"] and out["l1_nsfw"] == [False, False]
+    assert out["l1_sampler_seen"] == "dpmpp_2m"                          # SAMPLER_K_DPMPP_2M -> the in-tree sample_dpmpp_2m partial
+    assert out["l1_equals_direct"]                                       # same tensors as calling the host pipeline directly
+    assert out["l1_ddim_img2img"] == [[2, 3, 128, 128], "ddim"]
+    assert out["l1_cancelled"] and out["l1_clip_guidance"] == "NotImplementedError"
+    # level 2: the reference's gRPC servicer
+    assert "l2_error" not in out, out.get("l2_trace")
+    assert out["l2_artifacts"] == 2 and out["l2_png"] and out["l2_seeds"] == [420420420, 420420421]
