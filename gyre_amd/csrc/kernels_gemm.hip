@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
 // 128 B), so the XOR swizzle is applied to the per-lane SOURCE address and mirrored on the ds_read
 // (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, int NST = 2>
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -333,140 +333,12 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int kc0 = split * nk_per;
     const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr int LPW = AR + BR;   // DMA instructions per wave per K step
-    if constexpr (NST == 4) {
-        // ---- phased schedule ("8-phase" form of the CDNA4 guide, cdna_hip_programming.md 5 / T3-T5) -----------------
-        // A K step is cut into NP = NI/2 phases of 16 MFMAs (all MI row fragments x two column fragments x K = 64).
-        // Each phase: ds_read the register sub-tile it needs | issue a share of the NEXT K step's LDS-DMA granules |
-        // counted vmcnt | barrier | MFMA cluster at raised priority | barrier.  The two halves of the workgroup
-        // (waves 0-3 / 4-7 = the two waves of each SIMD) run one barrier apart, so one half's MFMA cluster always
-        // covers the other half's ds_read / DMA-issue section; DMA loads stay in flight across barriers (vmcnt is
-        // never drained inside the loop), which removes the per-K-step stage+wait+barrier stall of the 2-phase loop.
-        // MEASURED (tools/square_gemm.py, cfg_compare.py, geglu_compare.py; config 13 vs 6): bit-identical results;
-        // 8192^3 1142 vs 1085 TFLOP/s, long-K linears +5-10 %, K = 320 layers -7 %, 3x3 convs -4 % (per-granule address
-        // regeneration); the stagger itself is worth only ~2 % here because the 2-phase loop already runs two waves per
-        // SIMD that cover each other.  Not selected by the planner; kept as a tested experiment.
-        // Granule g (64 rows x 128 B, one DMA instruction per thread): A0..A3, then B0..B(BR-1).  Issue order and
-        // the wait counts below are derived in DESIGN.md (a granule is read one phase after the wait that retires
-        // it on every wave, and re-staged at least two phases after its last read).
-        static_assert(WM == 4 && WN == 2 && NI % 2 == 0 && AR == 4 && (BR == 5 || BR == 4), "phased schedule: 256 x {320,256}");
-        constexpr int NP = NI / 2;
-        auto issue_gran = [&](int kc, int s, int g) {      // g is a compile-time constant after unrolling
-            char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
-            const int k = kc * BK + kvs * 8;
-            const bool kok = k < p.K && kc < nk;             // past the last K step: zero page (keeps vmcnt counts fixed)
-            if (g < AR) {
-                const int i = g;
-                const bf16_t* src = zero;
-                if (MODE == GEMM_LINEAR) {
-                    if (kok && a_base[i] >= 0)
-                        src = k < p.C1 ? p.A + (size_t)a_base[i] * p.lda + k : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
-                } else {
-                    int tap, c;
-                    if (UNIFORM_TAP) { const int chunk = kc / 9; tap = kc - chunk * 9; c = chunk * BK + kvs * 8; }
-                    else { tap = k / p.Cin; c = k - tap * p.Cin; }
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
-                    if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
-                        if (p.ups) { iy >>= 1; ix >>= 1; }
-                        size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
-                        src = c < p.C1 ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
-                    }
-                }
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 8192), 16, 0, 0);
-            } else {
-                const int i = g - AR;
-                int kw = k;
-                if (MODE == GEMM_CONV3 && UNIFORM_TAP) { const int chunk = kc / 9, tap = kc - chunk * 9; kw = tap * p.Cin + chunk * BK + kvs * 8; }
-                const int n = n0 + r0 + 64 * i;
-                const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int g = 0; g < LPW; ++g) issue_gran(kc0, 0, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int gsel = (p.debug >> 4) & 3;                 // tuning: which waves form the late half
-        const bool late_half = gsel == 0 ? wave >= 4 : gsel == 1 ? (wave & 1) : gsel == 2 ? ((wave >> 1) & 1) : false;
-        if (late_half) __builtin_amdgcn_s_barrier();         // stagger: this half runs one barrier behind
-        bf16x8_t af[MI][2];
-        for (int kc = kc0; kc < nk; ++kc) {
-            const int cur = (kc - kc0) & 1;
-            const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
-            const uint4* b = a + BM * 8;
-#pragma unroll
-            for (int ph = 0; ph < NP; ++ph) {
-                if (ph == 0) {
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) {
-                            const int r = wm * TM + i * 16 + fr;
-                            af[i][ks] = __builtin_bit_cast(bf16x8_t, a[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
-                        }
-                }
-                bf16x8_t bfr[2][2];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int r = wn * TN + (2 * ph + jj) * 16 + fr;
-                        bfr[jj][ks] = __builtin_bit_cast(bf16x8_t, b[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
-                    }
-                // next K step's granules for this phase + the counted wait that retires what phase ph+1 will read
-                if constexpr (BR == 5) {
-                    if (ph == 0) { issue_gran(kc + 1, cur ^ 1, 0); issue_gran(kc + 1, cur ^ 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                    if (ph == 1) { issue_gran(kc + 1, cur ^ 1, 2); issue_gran(kc + 1, cur ^ 1, 3); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-                    if (ph == 2) { issue_gran(kc + 1, cur ^ 1, AR + 0); issue_gran(kc + 1, cur ^ 1, AR + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-                    if (ph == 3) { issue_gran(kc + 1, cur ^ 1, AR + 3); issue_gran(kc + 1, cur ^ 1, AR + 1); }
-                    if (ph == 4) { issue_gran(kc + 1, cur ^ 1, AR + 4); asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-                } else {
-                    if (ph == 0) { issue_gran(kc + 1, cur ^ 1, 0); issue_gran(kc + 1, cur ^ 1, 1); }
-                    if (ph == 1) { issue_gran(kc + 1, cur ^ 1, 2); issue_gran(kc + 1, cur ^ 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                    if (ph == 2) { issue_gran(kc + 1, cur ^ 1, AR + 0); issue_gran(kc + 1, cur ^ 1, AR + 2); }
-                    if (ph == 3) { issue_gran(kc + 1, cur ^ 1, AR + 1); issue_gran(kc + 1, cur ^ 1, AR + 3); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int i = 0; i < MI; ++i)
-                            acc[i][2 * ph + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj][ks], af[i][ks], acc[i][2 * ph + jj], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the past-the-end zero-page granules
-        if (!late_half) __builtin_amdgcn_s_barrier();        // re-align the two halves
-        __syncthreads();
-    } else {
     issue_stage(kc0, 0);
-    if (NST == 3 && kc0 + 1 < nk) issue_stage(kc0 + 1, 1);
-    if (NST == 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int kc = kc0; kc < nk; ++kc) {
-        const int cur = NST == 3 ? (kc - kc0) % 3 : (kc - kc0) & 1;
-        if (NST == 3) {
-            // 3-deep ring, two K steps in flight: the refill target was read in step kc-1 (barrier B below protects it)
-            if (kc + 2 < nk && !(p.debug & 1)) issue_stage(kc + 2, (kc + 2 - kc0) % 3);
-            const int ahead = min(2, nk - 1 - kc);
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // barrier A: stage `cur` complete for every wave
-        } else {
-            if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
-        }
+        const int cur = (kc - kc0) & 1;
+        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
         const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
         const uint4* b = a + BM * 8;
         if (!(p.debug & 2))
@@ -489,15 +361,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
             }
         }
-        if (NST == 3) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // barrier B: every wave finished reading stage `cur`
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-    if (NST == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (splits > 1) {
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
@@ -822,11 +687,11 @@ const bf16_t* gemm_zero_page_for_current_device() {
     return (const bf16_t*)p;
 }
 
-template <int BM, int BN, int WM, int WN, int NST = 2>
+template <int BM, int BN, int WM, int WN>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    const size_t lds = (size_t)(NST == 4 ? 2 : NST) * (BM + BN) * 128;   // NST == 4: phased schedule on a double buffer
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
@@ -835,7 +700,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
                         a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
 #define GYRE_GEMM8_GO(MODE_, UNI_)                                                                                  \
     do {                                                                                                            \
-        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_, NST>;                                                        \
+        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_>;                                                             \
         static std::atomic<unsigned long long> attr_done{0};                                                                               \
         if (gyre_lds_attr_needed(attr_done))                                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
@@ -854,394 +719,6 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
         hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
         GYRE_LAUNCH_CHECK();
     }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// 4-wave LDS-DMA variant, K step 32, sized so that TWO independent workgroups share a CU (57 KB LDS, 256 VGPRs).
-// Same tile math as k_gemm8 (wave tile 64 x 160 for the 128x320 tile), but the two co-resident workgroups are not
-// tied by a common barrier: they drift apart, so one's DMA-issue / barrier / epilogue phases run under the
-// other's MFMA phase (with one 8-wave workgroup per CU all waves hit those phases together and the matrix pipe
-// idles; its epilogue store drain cannot overlap anything - see the persistent-kernel note above).
-// LDS rows are 64 B (32 bf16): one DMA wave-instruction fills 16 rows; 16-byte slots are XOR-swizzled with
-// (row >> 2) & 3 on the source address and on the ds_read_b128 (conflict-free: 16 rows x same k-slot hit 16 slots).
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
-__global__ __launch_bounds__(256, 2) void k_gemm4d(GemmParams p, int tiles_m, int tiles_n, int splits) {
-    constexpr int BKS = 32;
-    constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int AR = BM / 64, BR = BN / 64;      // DMA instructions per wave per K step (16 rows each, 4 waves)
-    constexpr int STAGE_BYTES = (BM + BN) * 64;
-    static_assert(WM * WN == 4 && BM % 64 == 0 && BN % 64 == 0, "4 waves, 64-row staging granules");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-
-    const int ntiles = tiles_m * tiles_n;
-    const int split = blockIdx.x / ntiles;
-    const int bid = xcd_tile_id(blockIdx.x - split * ntiles, ntiles);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int rl = lane >> 2;                       // row inside a 16-row DMA granule
-    const int kvs = (lane & 3) ^ ((lane >> 4) & 3); // global k-granule fetched into LDS slot (lane & 3): swizzle (row>>2)&3
-    const int fr = lane & 15, fq = lane >> 4;
-
-    // rows staged by this lane: A rows 16*(wave + 4*i) + rl (i < AR), B rows 16*(wave + 4*i) + rl (i < BR)
-    int a_base[AR], a_y0[AR], a_x0[AR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        int row = m0 + 16 * (wave + 4 * i) + rl;
-        bool ok = row < p.M;
-        if (MODE == GEMM_LINEAR) {
-            a_base[i] = ok ? row : -1;
-            a_y0[i] = 0; a_x0[i] = 0;
-        } else {
-            int hw = p.Ho * p.Wo;
-            int n = row / hw, rem = row - n * hw;
-            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_base[i] = ok ? n * p.Hi * p.Wi : -1;
-            a_y0[i] = oy * p.stride - p.pad;
-            a_x0[i] = ox * p.stride - p.pad;
-        }
-    }
-    const int Hlim = p.ups ? (p.Hup ? p.Hup : 2 * p.Hi) : p.Hi, Wlim = p.ups ? (p.Wup ? p.Wup : 2 * p.Wi) : p.Wi;
-    const bf16_t* zero = p.zero_page;
-
-    auto issue_stage = [&](int kc, int s) {
-        char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
-        const int k = kc * BKS + kvs * 8;
-        const bool kok = k < p.K;
-        if (MODE == GEMM_LINEAR) {
-            const bool first = k < p.C1;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const bf16_t* src = zero;
-                if (kok && a_base[i] >= 0)
-                    src = first ? p.A + (size_t)a_base[i] * p.lda + k : p.A2 + (size_t)a_base[i] * p.lda2 + (k - p.C1);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 4096), 16, 0, 0);
-            }
-        } else {
-            int tap, c;
-            if (UNIFORM_TAP) {  // channel chunk (32 wide) outer, tap inner
-                const int chunk = kc / 9;
-                tap = kc - chunk * 9;
-                c = chunk * BKS + kvs * 8;
-            } else {
-                tap = k / p.Cin;
-                c = k - tap * p.Cin;
-            }
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const bool first = c < p.C1;
-#pragma unroll
-            for (int i = 0; i < AR; ++i) {
-                const bf16_t* src = zero;
-                int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
-                if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
-                    if (p.ups) { iy >>= 1; ix >>= 1; }
-                    size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
-                    src = first ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
-                }
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + i * 4096), 16, 0, 0);
-            }
-        }
-        int kw = k;
-        if (MODE == GEMM_CONV3 && UNIFORM_TAP) {
-            const int chunk = kc / 9, tap = kc - chunk * 9;
-            kw = tap * p.Cin + chunk * BKS + kvs * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int n = n0 + 16 * (wave + 4 * i) + rl;
-            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 64 + i * 4096), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nk_all = (p.K + BKS - 1) / BKS;
-    const int nk_per = (nk_all + splits - 1) / splits;
-    const int kc0 = split * nk_per;
-    const int nk = min(nk_all, kc0 + nk_per);
-    issue_stage(kc0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kc = kc0; kc < nk; ++kc) {
-        const int cur = (kc - kc0) & 1;
-        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
-        const char* a = smem_raw + cur * STAGE_BYTES;
-        const char* b = a + BM * 64;
-        if (!(p.debug & 2)) {
-            bf16x8_t af[MI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                int r = wm * TM + i * 16 + fr;
-                af[i] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(a + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                int r = wn * TN + j * 16 + fr;
-                bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(b + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    if (splits > 1) {
-        float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * TM + i * 16 + fr;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * TN + j * 16 + 4 * fq;
-                if (n < p.N) *(float4*)(slab + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            }
-        }
-        return;
-    }
-    const int n_out = p.geglu ? p.N / 2 : p.N;
-    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
-        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
-        float* my = (float*)smem_raw + wave * (16 * (TN + 4));
-        if constexpr (NI % 2 == 0) {
-            if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my); return; }
-        }
-        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
-        return;
-    }
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg4d(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int grid = tiles_m * tiles_n * splits;
-    constexpr int STAGE = (BM + BN) * 64;
-    constexpr int ESIZE = 4 * 16 * (BN / WN + 4) * 4;
-    const int lds = 2 * STAGE > ESIZE ? 2 * STAGE : ESIZE;
-    const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
-    const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
-    const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
-                                                : (double)p.M * p.K * 2.0;
-    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
-                        a_bytes + (double)p.N * p.K * 2.0 + (double)p.M * n_out * 2.0 * (p.residual ? 2.0 : 1.0));
-#define GYRE_GEMM4D_GO(MODE_, UNI_)                                                                                 \
-    do {                                                                                                            \
-        auto kern = k_gemm4d<BM, BN, WM, WN, MODE_, UNI_>;                                                          \
-        static std::atomic<unsigned long long> attr_done{0};                                                        \
-        if (gyre_lds_attr_needed(attr_done))                                                                        \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);          \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p, tiles_m, tiles_n, splits);                      \
-    } while (0)
-    if (p.mode == GEMM_LINEAR) {
-        GYRE_GEMM4D_GO(GEMM_LINEAR, true);
-    } else {
-        const bool uni = (p.Cin % 32 == 0) && (p.C1 % 32 == 0);
-        if (uni) GYRE_GEMM4D_GO(GEMM_CONV3, true); else GYRE_GEMM4D_GO(GEMM_CONV3, false);
-    }
-#undef GYRE_GEMM4D_GO
-    GYRE_LAUNCH_CHECK();
-    if (splits > 1) {
-        const size_t nthreads = (size_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
-        GYRE_LAUNCH_CHECK();
-    }
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// 3x3 conv with HALO REUSE (stride 1, pad 1, whole image rows per tile).  The implicit-GEMM kernels above fetch the A
-// tile of every tap from L2 again (nine shifted copies of nearly the same pixels); here the input window of a tile -
-// its R = BM / W image rows plus one halo row above / below and one zero column left / right - is brought into LDS
-// ONCE per 32-channel chunk and the nine taps read it at shifted row offsets.  Per chunk the L2->LDS traffic drops
-// from 9 x (A + B) to A_window + 9 x B  (256x320 tile at 64x64: 324 KB -> 205 KB, -37 %), on the path that limits
-// the other kernels.  K order: 32-channel chunk outer, tap inner (so not bit-identical to the 64-channel-chunk
-// kernels; the planner picks it from per-sample shape only, see pick_cfg).
-// LDS: window [ (R+2) x (W+2) rows ][ 64 B ] double-buffered per chunk + weight tiles [BN][64 B] of two taps,
-// double-buffered per barrier step; 16-byte slots XOR-swizzled with (row >> 2) & 3 on the DMA source and on the ds_read_b128.
-// ------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(512) void k_conv8h(GemmParams p, int tiles_m, int tiles_n) {
-    constexpr int BM = 256, WM = 4, WN = 2, BKS = 32;
-    constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int BI = (BN / 16 + 7) / 8;            // weight-tile DMA instructions per wave (16 rows each, 8 waves)
-    constexpr int BBYTES = BN * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-
-    const int ntiles = tiles_m * tiles_n;
-    const int bid = xcd_tile_id(blockIdx.x, ntiles);
-    const int tn = bid % tiles_n, tm = bid / tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int rl = lane >> 2;
-    const int gsrc = (lane & 3) ^ ((lane >> 4) & 3);   // k-granule this lane fetches into slot (lane & 3)
-
-    const int W = p.Wi, H = p.Hi, W2 = W + 2;
-    const int R = BM / W;                              // image rows per tile (host guarantees BM % W == 0, H % R == 0)
-    const int wrows = (R + 2) * W2;
-    const int wbytes = (wrows * 64 + 1023) & ~1023;    // window buffer, whole DMA instructions
-    const int nwi = wbytes / 1024;                     // wave-instructions per window
-    const int hw = H * W;
-    const int ns = m0 / hw, y0 = (m0 - ns * hw) / W;   // sample and first image row of this tile
-    char* wbuf0 = smem_raw;
-    char* bbuf0 = smem_raw + 2 * wbytes;
-    const bf16_t* zero = p.zero_page;
-
-    // window rows staged by this lane: instruction q = wave + 8*i covers rows 16q .. 16q+15
-    constexpr int WI_MAX = 5;                          // up to (R+2)(W+2) <= 640 rows  (W >= 16)
-    int wpix[WI_MAX];
-#pragma unroll
-    for (int i = 0; i < WI_MAX; ++i) {
-        const int q = wave + 8 * i;
-        const int wr = q * 16 + rl;
-        int pix = -1;
-        if (q < nwi && wr < wrows) {
-            const int ry = wr / W2, cx = wr - ry * W2;
-            const int y = y0 - 1 + ry, x = cx - 1;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) pix = ns * hw + y * W + x;
-        }
-        wpix[i] = pix;
-    }
-    auto issue_window = [&](int chunk, int s) {
-        char* dst = wbuf0 + s * wbytes;
-        const int c = chunk * BKS + gsrc * 8;
-        const bool first = c < p.C1;
-#pragma unroll
-        for (int i = 0; i < WI_MAX; ++i) {
-            const int q = wave + 8 * i;
-            if (q < nwi) {                              // wave-uniform
-                const bf16_t* src = zero;
-                if (wpix[i] >= 0) src = first ? p.A + (size_t)wpix[i] * p.lda + c : p.A2 + (size_t)wpix[i] * p.lda2 + (c - p.C1);
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + q * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto issue_weights_to = [&](int chunk, int tap, char* dst) {
-        const int kw = tap * p.Cin + chunk * BKS + gsrc * 8;
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int q = wave + 8 * i;
-            if (q * 16 < BN) {                          // wave-uniform
-                const int n = n0 + q * 16 + rl;
-                const bf16_t* src = n < p.N ? p.W + (size_t)n * p.K + kw : zero;
-                __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + q * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    // window row of (output row r, tap 0): (ty + 0) * (W+2) + (tx + 0)
-    int abase[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int r = wm * TM + i * 16 + fr;
-        const int ty = r / W, tx = r - ty * W;
-        abase[i] = ty * W2 + tx;
-    }
-    f32x4_t acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // Taps are a flat stream g = chunk * 9 + tap; one barrier step handles TWO of them (80 MFMAs per wave between
-    // barriers, like the BK = 64 kernels), pairs may straddle a chunk boundary - both windows are resident.
-    const int nchunks = p.Cin / BKS;
-    const int G = 9 * nchunks;
-    auto issue_pair = [&](int g, int s) {        // weight tiles of taps g, g+1 into pair buffer s
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (g + h < G) { const int c = (g + h) / 9; issue_weights_to(c, g + h - 9 * c, bbuf0 + (2 * s + h) * BBYTES); }
-    };
-    issue_window(0, 0);
-    issue_pair(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int next_win = 1;
-    for (int g0 = 0, st = 0; g0 < G; g0 += 2, ++st) {
-        const int cur = st & 1;
-        const int c_lo = g0 / 9;
-        // window next_win goes into the buffer chunk next_win - 2 used: free once every tap below 9 * (next_win - 1) is done
-        if (next_win < nchunks && next_win - 1 <= c_lo) { issue_window(next_win, next_win & 1); ++next_win; }
-        issue_pair(g0 + 2, cur ^ 1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int g = g0 + h;
-            if (g < G) {                                              // wave-uniform
-                const int chunk = g / 9, tap = g - 9 * chunk;
-                const char* wb = wbuf0 + (chunk & 1) * wbytes;
-                const char* bb = bbuf0 + (2 * cur + h) * BBYTES;
-                const int toff = (tap / 3) * W2 + (tap % 3);
-                bf16x8_t af[MI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int wr = abase[i] + toff;
-                    af[i] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(wb + wr * 64 + ((fq ^ ((wr >> 2) & 3)) << 4)));
-                }
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int r = wn * TN + j * 16 + fr;
-                    bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(bb + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4)));
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const int n_out = p.N;
-    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
-        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
-        float* my = (float*)smem_raw + wave * (16 * (TN + 4));
-        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
-        return;
-    }
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
-}
-
-// can the halo kernel run this problem?  (per-sample shape only - the batch size never enters)
-static bool conv8h_eligible(const GemmParams& p, int BN) {
-    if (p.mode != GEMM_CONV3 || p.stride != 1 || p.pad != 1 || p.ups || p.geglu || p.out_mode != OUT_BF16) return false;
-    if (p.Cin % 32 || p.C1 % 32 || p.N % BN) return false;
-    const int W = p.Wi, H = p.Hi;
-    if (W < 16 || 256 % W) return false;
-    const int R = 256 / W;
-    if (R > H || H % R) return false;
-    if ((R + 2) * (W + 2) > 5 * 8 * 16) return false;                     // WI_MAX instructions per lane
-    const size_t lds = 2 * (size_t)((((R + 2) * (W + 2) * 64) + 1023) & ~1023) + 4 * (size_t)BN * 64;
-    return lds <= 160 * 1024 && (size_t)8 * 16 * (BN / 2 + 4) * 4 <= lds;   // staged epilogue reuses the operand LDS
-}
-template <int BN>
-static int launch_conv8h(hipStream_t st, const GemmParams& p, int kcls) {
-    const int tiles_m = p.M / 256, tiles_n = p.N / BN;
-    const int W = p.Wi, R = 256 / W;
-    const size_t lds = 2 * (size_t)((((R + 2) * (W + 2) * 64) + 1023) & ~1023) + 4 * (size_t)BN * 64;
-    GyreProfScope prof_(kcls, st, 2.0 * p.M * (double)p.N * p.K,
-                        (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0 + (double)p.N * p.K * 2.0 +
-                            (double)p.M * p.N * 2.0 * (p.residual ? 2.0 : 1.0));
-    auto kern = k_conv8h<BN>;
-    static std::atomic<unsigned long long> attr_done{0};
-    if (gyre_lds_attr_needed(attr_done))
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, p, tiles_m, tiles_n);
-    GYRE_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1388,8 +865,6 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
     if (cfg >= 4) {
-        if (p.geglu && cfg == 11) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
-        if (p.geglu && cfg == 9) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         p.zero_page = gemm_zero_page_for_current_device();
@@ -1403,17 +878,6 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
-        case 8: return launch_cfg8<128, 256, 2, 4, 3>(st, p, KC_G8_CONV_128x256, splits);  // experiment: 3-deep ring
-        case 9: return launch_cfg4d<128, 320, 2, 2>(st, p, KC_G8_CONV_128x320, splits);     // 2 workgroups / CU
-        case 10: return launch_cfg4d<128, 256, 2, 2>(st, p, KC_G8_CONV_128x256, splits);
-        case 11: return launch_cfg8<256, 320, 2, 4>(st, p, KC_G8_CONV_256x320, splits);    // experiment: 128x80 wave tiles
-        // experiment: phased ("8-phase") K loop, see the NST == 4 branch of k_gemm8.  Only the 256x256 tile is built: the
-        // 256x320 form needs > 256 registers and a counted-vmcnt kernel must not spill.
-        case 13: return launch_cfg8<256, 256, 4, 2, 4>(st, p, KC_G8_CONV_256x256, splits);
-        case 16: if (!conv8h_eligible(p, 320)) GYRE_FAIL(-6, "gemm: halo conv kernel does not apply to this problem");
-                 return launch_conv8h<320>(st, p, KC_G8_CONV_256x320);
-        case 17: if (!conv8h_eligible(p, 256)) GYRE_FAIL(-6, "gemm: halo conv kernel does not apply to this problem");
-                 return launch_conv8h<256>(st, p, KC_G8_CONV_256x256);
         case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }

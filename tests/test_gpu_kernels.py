@@ -254,7 +254,7 @@ def test_error_paths():
 
 
 # ---- every GEMM tile configuration, forced, on shapes with M / N / K tails -------------------------
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,K,N,bias,res", [(1000, 320, 640, True, True), (4096 + 37, 200, 1280, True, False),
                                             (513, 1280, 320 * 4, False, True)])
 def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
@@ -276,7 +276,7 @@ def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
     report(f"linear cfg{cfg} M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7, 8, 10, 13])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 6, 7])
 def test_geglu_forced_tile_config(cfg):
     L = _lib.lib()
     M, K, F_ = 700, 320, 1280
@@ -295,7 +295,7 @@ def test_geglu_forced_tile_config(cfg):
     report(f"geglu cfg{cfg}", y.float().cpu(), ref, TOL)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,asym,res", [
     (2, 24, 20, 320, 640, 1, 0, 0, True), (1, 16, 16, 72, 1280, 1, 1, 0, False), (2, 18, 18, 128, 1280, 2, 0, 1, False),
 ])
@@ -374,8 +374,7 @@ def test_attention_variants(variant, B, heads, Nq, Nk, D):
 
 def test_all_tile_configs_sum_in_the_same_order():
     """Every production tile config (4-wave 128x128 / 256x64 / 64x64, 8-wave 256x320 / 128x320 / 256x256 / 128x256)
-    gives BIT-identical output for the same problem: the planner may pick by problem size without changing results.
-    (Configs 9/10, the BK=32 experiment, sum in 32-channel chunks and are excluded.)"""
+    gives BIT-identical output for the same problem: the planner may pick by problem size without changing results."""
     L = _lib.lib()
     # 3x3 conv, uniform taps, dual-source-free; Cout multiple of 320 and 256 so that all configs are legal
     B, H, W, Cin, Cout = 2, 20, 24, 192, 1280
@@ -383,7 +382,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
     b = randn(Cout, seed=62).to(DEV)
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7, 11, 13):
+    for cfg in (1, 2, 3, 4, 5, 6, 7):
         y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
@@ -398,7 +397,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     xl = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
     wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7, 11, 13):
+    for cfg in (1, 2, 3, 4, 5, 6, 7):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
@@ -522,41 +521,6 @@ def test_fused_qkv_rejects_unaligned_configs():
     assert rc == -6
     assert L.gyre_op_qkv(st(), vp(x), 256, 320, vp(w), 100, vp(qk), vp(vt), 256) == -1   # tokens must divide M
 
-
-@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,res", [(16, 2, 32, 32, 320, 640, True), (16, 1, 64, 64, 64, 320, False), (17, 2, 16, 16, 128, 1280, True),
-                                                    (16, 3, 16, 16, 96, 320, False), (17, 1, 32, 32, 32, 256, True), (16, 1, 128, 128, 32, 320, False)])
-def test_conv_halo_reuse_kernel(cfg, B, H, W, Cin, Cout, res):
-    """3x3 conv with the input window staged once per 32-channel chunk (k_conv8h): vs fp32 conv2d, incl. image borders,
-    several samples per launch, bias and residual."""
-    L = _lib.lib()
-    x = bf16_round(randn(B, Cin, H, W, seed=90))
-    w = bf16_round(randn(Cout, Cin, 3, 3, seed=91) / math.sqrt(9 * Cin))
-    b = randn(Cout, seed=92)
-    ref = F.conv2d(x, w, b, padding=1)
-    r = bf16_round(randn(B, Cout, H, W, seed=93)) if res else None
-    if res:
-        ref = ref + r
-    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
-    old = L.gyre_debug_force_gemm_cfg(cfg)
-    try:
-        _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
-                                     vp(to_dev_bf16(nhwc(r))) if res else None, 1, 0, 0, vp(y)))
-    finally:
-        L.gyre_debug_force_gemm_cfg(old)
-    report(f"halo conv cfg{cfg} {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
-
-
-def test_conv_halo_reuse_rejects_ineligible_shapes():
-    L = _lib.lib()
-    x = torch.zeros(1, 24, 20, 320, dtype=torch.bfloat16, device=DEV)      # W = 20 does not divide 256
-    w = torch.zeros(320, 9 * 320, dtype=torch.bfloat16, device=DEV)
-    y = torch.empty(1, 24, 20, 320, dtype=torch.bfloat16, device=DEV)
-    old = L.gyre_debug_force_gemm_cfg(16)
-    try:
-        assert L.gyre_op_conv3x3(st(), vp(x), 1, 24, 20, 320, vp(w), 320, None, None, 1, 0, 0, vp(y)) == -6
-        assert L.gyre_op_conv3x3(st(), vp(x), 1, 24, 20, 320, vp(w), 320, None, None, 2, 0, 0, vp(y)) == -6   # stride 2
-    finally:
-        L.gyre_debug_force_gemm_cfg(old)
 
 
 # ---- pipelined 32x32x16 tile configs (kernels_gemm4s.hip): 4 waves 20 = 192x320, 21 = 256x256, 22 = 128x320, 23 = 128x256;

@@ -8,6 +8,8 @@ vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 rnd = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
 kind = sys.argv[1]
+if os.environ.get("FORCE_CFG"): L.gyre_debug_force_gemm_cfg(int(os.environ["FORCE_CFG"], 0))      # tile config under test
+if os.environ.get("GEMM_ABL"): L.gyre_debug_gemm_ablation(int(os.environ["GEMM_ABL"], 0))
 if kind == "conv":
     B, H, W, Ci, Co = map(int, sys.argv[2:7])
     x, w, b = rnd(B, H, W, Ci), rnd(Co, 9 * Ci), torch.zeros(Co, device=DEV)

@@ -8,11 +8,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.log
+    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-class-table > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --inference-steps 3 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.log
+    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --inference-steps 3 --no-cpu-baseline --no-class-table > $OUT/bench_fetch.json 2> $OUT/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --inference-steps 3 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.log
+    python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --inference-steps 3 --no-cpu-baseline --no-class-table > $OUT/bench_write.json 2> $OUT/write.log
 ls -R $OUT | head -40
 # keep only the small files (the merged directory is capped at 64 MiB)
 find $OUT -name "*.csv" -size +30M -print -exec sh -c 'head -c 30000000 "$1" > "$1.head"; rm "$1"' _ {} \;

@@ -63,7 +63,7 @@ for it in range(N_GEMM):
         mk = lambda: torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         desc = ("linear", M, K, N)
     ref = None
-    for cfg in (1, 4, 5, 6, 7, 13, 0):
+    for cfg in (1, 4, 5, 6, 7, 20, 21, 22, 23, 24, 0):
         L.gyre_debug_force_gemm_cfg(cfg)
         for r in range(REPS if cfg else 2):
             y = mk(); background()
