@@ -55,6 +55,8 @@ _SIGS = {
     "gyre_unet_set_tome": (_i, [_vp, _i]),
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
+    "gyre_unet_vjp_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "gyre_unet_vjp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i, _vp]),
     "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
     "gyre_vae_destroy": (None, [_vp]),
     "gyre_vae_num_params": (_i, [_vp]),
@@ -64,6 +66,8 @@ _SIGS = {
     "gyre_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_vae_encode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
+    "gyre_vae_decode_vjp_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "gyre_vae_decode_vjp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i]),
     "gyre_prof_set_mask": (_i, [C.c_uint]),
     "gyre_prof_num_classes": (_i, []),
     "gyre_prof_class_name": (C.c_char_p, [_i]),
@@ -86,6 +90,13 @@ _SIGS = {
     "gyre_op_attention": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "gyre_op_qkv": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i]),
     "gyre_op_attention_ex": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i]),
+    "gyre_op_groupnorm_bwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "gyre_op_groupnorm_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "gyre_op_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _f, _vp, _vp]),
+    "gyre_op_geglu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "gyre_op_attention_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "gyre_op_attention_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz,
+                                   _vp, _i, _vp, _i, _vp, _i]),
     "gyre_op_tome_workspace": (_sz, [_i, _i, _i]),
     "gyre_op_tome_merge": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
     "gyre_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

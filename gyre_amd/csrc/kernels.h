@@ -22,6 +22,7 @@ struct GnParams {
     float* scale_shift;  // [B][2][C]   (a = rstd*gamma, b = beta - mean*a)
     int nchunks;
     bf16_t* y;           // [B][HW][C]
+    float* mean_rstd = nullptr;  // optional [B][G][2] (backward pass)
 };
 size_t gn_workspace_bytes(int B, int HW, int C, int G);
 int gn_pick_chunks(int B, int HW, int C);
@@ -92,6 +93,48 @@ struct AttnParams {
     int k_prescaled = 0;        // K already carries log2(e)/sqrt(D) (folded into the to_k weights at repack time)
 };
 int launch_attention(hipStream_t st, const AttnParams& p);
+
+// ---- input-gradient kernels of the CLIP-guided mode (kernels_bwd.hip) ---------------------------------------------
+struct GnBwdParams {
+    const bf16_t* x; const bf16_t* x2; int C1;       // forward input (x2 = second source of the skip concat, or null)
+    int B, HW, C, G;
+    const float* gamma; const float* beta; float eps; int silu;
+    const bf16_t* dy;                                // [B][HW][C]
+    const bf16_t* addend;                            // optional [B][HW][C1], added to dx (identity-shortcut gradient)
+    bf16_t* dx; bf16_t* dx2;                         // [B][HW][C1], [B][HW][C - C1]
+    // filled in by launch_groupnorm_bwd from its workspace
+    float* partial = nullptr; float* coef = nullptr; float* mean_rstd = nullptr; float* scale_shift = nullptr; int nchunks = 0;
+};
+size_t gn_bwd_workspace_bytes(int B, int HW, int C, int G);
+int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws);
+int launch_layernorm_bwd(hipStream_t st, const bf16_t* x, const bf16_t* dy, int M, int C, const float* gamma, float eps,
+                         const bf16_t* addend, bf16_t* dx);
+// pre: [M][2F] GEGLU pre-activation in the interleaved column order of the packed weight; dy: [M][F]; dpre: [M][2F]
+int launch_geglu_bwd(hipStream_t st, const bf16_t* pre, const bf16_t* dy, size_t M, int F, bf16_t* dpre);
+int launch_pool2_sum(hipStream_t st, const bf16_t* du, int B, int H, int W, int Hu, int Wu, int C, bf16_t* dx);
+int launch_zero_stuff2(hipStream_t st, const bf16_t* dy, int B, int Ho, int Wo, int H, int W, int C, bf16_t* dz);
+int launch_add_bf16(hipStream_t st, bf16_t* y, const bf16_t* x, size_t n);
+int launch_conv_weight_t(hipStream_t st, const bf16_t* w, int O, int I, bf16_t* wt);   // [O][9][I] -> [I][9][O], window rotated
+int launch_transpose(hipStream_t st, const bf16_t* in, int ld_in, int R, int C, bf16_t* out, int ld_out, int batch,
+                     size_t bs_in, size_t bs_out);
+struct AttnBwdParams {
+    const bf16_t* q; int ldq;      // [B][Nq][ldq], head h at column h*D
+    const bf16_t* k; int ldk;      // [B][Nk][ldk]
+    const bf16_t* v; int ldv;      // [B][Nk][ldv]  (row-major, unlike the forward kernel's V^T)
+    const bf16_t* o; int ldo;      // forward output [B][Nq][ldo]
+    const bf16_t* d_o; int lddo;   // its gradient
+    const bf16_t* kt; int ldkt;    // K transposed [B][H*D][ldkt], ldkt >= Nk rounded up to 32, pad columns zero
+    const bf16_t* qt; const bf16_t* d_ot; int ldqt;   // Q^T, dO^T [B][H*D][ldqt] (only read when dk != null)
+    bf16_t* dq; int lddq;
+    bf16_t* dk; int lddk; bf16_t* dv; int lddv;       // dk == null: queries only (cross-attention: the context gets no gradient)
+    void* stats;                   // attn_bwd_stats_bytes(B, H, Nq)
+    int B, H, Nq, Nk, D;
+    int k_prescaled;               // K carries log2(e)/sqrt(D) (see AttnParams)
+    // filled in by launch_attention_bwd
+    float* lse = nullptr; float* delta = nullptr; int NqPad = 0; float alpha = 0.f, beta = 0.f;
+};
+size_t attn_bwd_stats_bytes(int B, int H, int Nq);
+int launch_attention_bwd(hipStream_t st, AttnBwdParams p);
 
 // ---- ToMe: bipartite soft matching + merge of self-attention K / V tokens (kernels_tome.hip) ---------------------------
 struct TomeParams {

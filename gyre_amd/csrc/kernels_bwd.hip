@@ -1,0 +1,656 @@
+// Input-gradient (vector-Jacobian product) kernels for the CLIP-guided denoising mode.
+//
+// The reference's ClipGuidedMode (gyre/pipeline/unet/clipguided.py:301-338,420) asks autograd for
+// d loss / d latents through the guided UNet evaluation and the VAE decoder; weights never receive gradients.
+// These are the transposes of the forward kernels for that one direction:
+//   k_gn_bwd_partial / k_gn_bwd_finalize / k_gn_bwd_apply   GroupNorm(+SiLU), concat-aware like the forward
+//   k_ln_bwd                                                 LayerNorm (+ the residual branch's gradient)
+//   k_geglu_bwd                                              GEGLU on the 16-value / 16-gate interleaved columns
+//   k_attn_bwd_delta / k_attn_bwd_dq / k_attn_bwd_dkv        flash-style attention backward on v_mfma_f32_32x32x16_bf16:
+//                                                            probabilities are recomputed from Q, K and a row
+//                                                            log-sum-exp, never stored
+//   k_pool2_sum / k_zero_stuff2                              adjoints of nearest 2x upsampling / stride-2 sampling
+//   k_conv_weight_t / k_transpose                            W^T operands of the data-gradient GEMMs / convs
+// Gradients are NHWC bf16 like the activations; every reduction accumulates in fp32 in a fixed order.
+#include "kernels.h"
+#include "gemm_shared.h"
+
+// ------------------------------------------------------------------------------
+// GroupNorm (+SiLU) backward.  With u = a*x + b (a = rstd*gamma, b = beta - mean*a, from the forward statistics
+// kernels), g = dy * silu'(u) * gamma and xh = (x - mean) * rstd:
+//     dx = rstd * (g - mean_grp(g) - xh * mean_grp(g * xh))
+// Stage 1 sums g and g*xh per (sample, pixel chunk, group); stage 2 reduces the chunks in a fixed order; stage 3 applies.
+// ------------------------------------------------------------------------------
+#define GNB_MAXV 4
+__device__ __forceinline__ float silu_grad_f(float u) {
+    const float s = 1.0f / (1.0f + __expf(-u));
+    return s * fmaf(u, 1.0f - s, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, int PY, int pix_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;  // [PY][C][2]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int CV = p.C / 8, C2 = p.C - p.C1, cpg = p.C / p.G;
+    const int p0 = chunk * pix_per_chunk, p1 = min(p.HW, p0 + pix_per_chunk);
+    float s[GNB_MAXV][8], ss[GNB_MAXV][8];
+#pragma unroll
+    for (int v = 0; v < GNB_MAXV; ++v)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[v][j] = 0.f; ss[v][j] = 0.f; }
+    if (ty < PY) {
+        for (int pix = p0 + ty; pix < p1; pix += PY) {
+            const size_t gp = (size_t)n * p.HW + pix;
+#pragma unroll
+            for (int v = 0; v < GNB_MAXV; ++v) {
+                const int cv = tx + v * TX;
+                if (cv < CV) {
+                    const int c = cv * 8;
+                    const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
+                    float f[8], d[8];
+                    unpack8(*(const uint4*)src, f);
+                    unpack8(*(const uint4*)(p.dy + gp * p.C + c), d);
+                    const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float* mr = p.mean_rstd + ((size_t)n * p.G + (c + j) / cpg) * 2;
+                        const float u = fmaf(sc[j], f[j], sc[p.C + j]);
+                        const float g = d[j] * (p.silu ? silu_grad_f(u) : 1.0f) * p.gamma[c + j];
+                        s[v][j] += g;
+                        ss[v][j] = fmaf(g, (f[j] - mr[0]) * mr[1], ss[v][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < GNB_MAXV; ++v) {
+            const int cv = tx + v * TX;
+            if (cv < CV) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[((size_t)ty * p.C + cv * 8 + j) * 2 + 0] = s[v][j];
+                    red[((size_t)ty * p.C + cv * 8 + j) * 2 + 1] = ss[v][j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int y = 0; y < PY; ++y)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                a += red[((size_t)y * p.C + c) * 2 + 0];
+                b += red[((size_t)y * p.C + c) * 2 + 1];
+            }
+        float* dst = p.partial + (((size_t)n * p.nchunks + chunk) * p.G + g) * 2;
+        dst[0] = a; dst[1] = b;
+    }
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_finalize(GnBwdParams p) {
+    const int n = blockIdx.x;
+    const float cnt = (float)p.HW * (float)(p.C / p.G);
+    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+            a += src[0]; b += src[1];
+        }
+        p.coef[((size_t)n * p.G + g) * 2 + 0] = a / cnt;
+        p.coef[((size_t)n * p.G + g) * 2 + 1] = b / cnt;
+    }
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdParams p, size_t total_vec) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_vec) return;
+    const int CV = p.C / 8, C2 = p.C - p.C1, cpg = p.C / p.G;
+    const size_t gp = idx / CV;
+    const int c = (int)(idx % CV) * 8;
+    const int n = (int)(gp / p.HW);
+    const bool first = c < p.C1;
+    const bf16_t* src = first ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
+    float f[8], d[8], o[8], ad[8];
+    unpack8(*(const uint4*)src, f);
+    unpack8(*(const uint4*)(p.dy + gp * p.C + c), d);
+    const bool has_add = first && p.addend;
+    if (has_add) unpack8(*(const uint4*)(p.addend + gp * p.C1 + c), ad);
+    const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (c + j) / cpg;
+        const float* mr = p.mean_rstd + ((size_t)n * p.G + grp) * 2;
+        const float* cf = p.coef + ((size_t)n * p.G + grp) * 2;
+        const float u = fmaf(sc[j], f[j], sc[p.C + j]);
+        const float g = d[j] * (p.silu ? silu_grad_f(u) : 1.0f) * p.gamma[c + j];
+        const float xh = (f[j] - mr[0]) * mr[1];
+        o[j] = mr[1] * (g - cf[0] - xh * cf[1]) + (has_add ? ad[j] : 0.f);
+    }
+    bf16_t* dst = first ? p.dx + gp * p.C1 + c : p.dx2 + gp * C2 + (c - p.C1);
+    *(uint4*)dst = pack8(o);
+}
+size_t gn_bwd_workspace_bytes(int B, int HW, int C, int G) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int nch = gn_pick_chunks(B, HW, C);
+    return gn_workspace_bytes(B, HW, C, G) + al((size_t)B * nch * G * 2 * 4) + 2 * al((size_t)B * G * 2 * 4);
+}
+int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
+    if (p.C % 8 || p.C1 % 8 || p.C % p.G || p.G > 256) GYRE_FAIL(-1, "groupnorm_bwd: C, C1 multiples of 8, C of groups (<= 256)");
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // forward statistics (same kernels, same summation order as the forward pass)
+    GnParams f;
+    f.x = p.x; f.x2 = p.x2 ? p.x2 : p.x; f.C1 = p.C1; f.B = p.B; f.HW = p.HW; f.C = p.C; f.G = p.G;
+    f.gamma = p.gamma; f.beta = p.beta; f.eps = p.eps; f.silu = p.silu; f.y = nullptr;
+    f.nchunks = gn_pick_chunks(p.B, p.HW, p.C);
+    char* w = (char*)ws;
+    f.partial = (float*)w;
+    f.scale_shift = (float*)(w + al((size_t)p.B * f.nchunks * p.G * 2 * 4));
+    w += gn_workspace_bytes(p.B, p.HW, p.C, p.G);
+    p.partial = (float*)w; w += al((size_t)p.B * f.nchunks * p.G * 2 * 4);
+    p.coef = (float*)w; w += al((size_t)p.B * p.G * 2 * 4);
+    f.mean_rstd = (float*)w;
+    p.mean_rstd = f.mean_rstd; p.scale_shift = f.scale_shift; p.nchunks = f.nchunks;
+    if (!p.x2) p.x2 = p.x;
+    int rc = launch_groupnorm_stats(st, f);
+    if (rc) return rc;
+    const int CV = p.C / 8;
+    const int TX = CV < 256 ? CV : 256;
+    if ((CV + TX - 1) / TX > GNB_MAXV) GYRE_FAIL(-6, "groupnorm_bwd: C too large");
+    int PY = 256 / TX; if (PY < 1) PY = 1;
+    const int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
+    const size_t lds = (size_t)PY * p.C * 2 * sizeof(float);
+    if (lds > 160 * 1024) GYRE_FAIL(-6, "groupnorm_bwd: LDS budget exceeded");
+    hipLaunchKernelGGL(k_gn_bwd_partial, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    GYRE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(p.B), dim3(256), 0, st, p);
+    GYRE_LAUNCH_CHECK();
+    const size_t total = (size_t)p.B * p.HW * CV;
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row:  g = dy*gamma, dx = rstd*(g - mean(g) - xh*mean(g*xh)) (+ addend)
+// ------------------------------------------------------------------------------
+#define LNB_MAXV 4
+__global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int M, int C,
+                                                const float* __restrict__ gamma, float eps,
+                                                const bf16_t* __restrict__ addend, bf16_t* __restrict__ dx) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + wave;
+    if (row >= (size_t)M) return;
+    const int CV = C / 8;
+    float f[LNB_MAXV][8], g[LNB_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < LNB_MAXV; ++v) {
+        const int cv = lane + v * 64;
+        if (cv < CV) {
+            unpack8(*(const uint4*)(x + row * C + cv * 8), f[v]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[v][j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < LNB_MAXV; ++v) {
+        const int cv = lane + v * 64;
+        if (cv < CV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[v][j] - mean; q = fmaf(d, d, q); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < LNB_MAXV; ++v) {
+        const int cv = lane + v * 64;
+        if (cv < CV) {
+            float d[8];
+            unpack8(*(const uint4*)(dy + row * C + cv * 8), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f[v][j] = (f[v][j] - mean) * rstd;
+                g[v][j] = d[j] * gamma[cv * 8 + j];
+                s1 += g[v][j];
+                s2 = fmaf(g[v][j], f[v][j], s2);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+    for (int v = 0; v < LNB_MAXV; ++v) {
+        const int cv = lane + v * 64;
+        if (cv < CV) {
+            float o[8], ad[8];
+            if (addend) unpack8(*(const uint4*)(addend + row * C + cv * 8), ad);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rstd * (g[v][j] - m1 - f[v][j] * m2) + (addend ? ad[j] : 0.f);
+            *(uint4*)(dx + row * C + cv * 8) = pack8(o);
+        }
+    }
+}
+int launch_layernorm_bwd(hipStream_t st, const bf16_t* x, const bf16_t* dy, int M, int C, const float* gamma, float eps,
+                         const bf16_t* addend, bf16_t* dx) {
+    if (C % 8 || C > 8 * 64 * LNB_MAXV) GYRE_FAIL(-6, "layernorm_bwd: C must be a multiple of 8 and <= 2048");
+    hipLaunchKernelGGL(k_ln_bwd, dim3((M + 3) / 4), dim3(256), 0, st, x, dy, M, C, gamma, eps, addend, dx);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// GEGLU backward on the interleaved pre-activation: columns 32p..32p+15 hold the values, 32p+16..32p+31 the gates of
+// output columns 16p..16p+15 (launch_repack_linear).  out = val * gelu(gate):
+//   d val = dy * gelu(gate),   d gate = dy * val * (Phi(gate) + gate * phi(gate))
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_geglu_bwd(const bf16_t* __restrict__ pre, const bf16_t* __restrict__ dy, size_t M,
+                                                   int F, bf16_t* __restrict__ dpre) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int FV = F / 8;
+    if (idx >= M * FV) return;
+    const size_t row = idx / FV;
+    const int c = (int)(idx % FV) * 8;                       // output column of this 8-vector
+    const size_t base = row * (size_t)(2 * F) + (size_t)(c >> 4) * 32 + (c & 15);
+    float v[8], gt[8], d[8], dv[8], dg[8];
+    unpack8(*(const uint4*)(pre + base), v);
+    unpack8(*(const uint4*)(pre + base + 16), gt);
+    unpack8(*(const uint4*)(dy + row * F + c), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = gt[j];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        dv[j] = d[j] * x * cdf;
+        dg[j] = d[j] * v[j] * fmaf(x, pdf, cdf);
+    }
+    *(uint4*)(dpre + base) = pack8(dv);
+    *(uint4*)(dpre + base + 16) = pack8(dg);
+}
+int launch_geglu_bwd(hipStream_t st, const bf16_t* pre, const bf16_t* dy, size_t M, int F, bf16_t* dpre) {
+    if (F % 16) GYRE_FAIL(-1, "geglu_bwd: F must be a multiple of 16");
+    const size_t total = M * (size_t)(F / 8);
+    hipLaunchKernelGGL(k_geglu_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pre, dy, M, F, dpre);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// resampling adjoints, elementwise add, operand transposes
+// ------------------------------------------------------------------------------
+// nearest upsampling to (Hu, Wu) <= (2H, 2W) duplicated source pixels; the adjoint sums the (up to 4) copies
+__global__ __launch_bounds__(256) void k_pool2_sum(const bf16_t* __restrict__ du, int B, int H, int W, int Hu, int Wu, int C,
+                                                   bf16_t* __restrict__ dx, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int CV = C / 8;
+    const int c = (int)(idx % CV) * 8;
+    size_t r = idx / CV;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int yy = 2 * y + a, xx = 2 * x + b;
+            if (yy < Hu && xx < Wu) {
+                float f[8];
+                unpack8(*(const uint4*)(du + (((size_t)n * Hu + yy) * Wu + xx) * C + c), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        }
+    *(uint4*)(dx + (((size_t)n * H + y) * W + x) * C + c) = pack8(acc);
+}
+int launch_pool2_sum(hipStream_t st, const bf16_t* du, int B, int H, int W, int Hu, int Wu, int C, bf16_t* dx) {
+    if (C % 8) GYRE_FAIL(-1, "pool2_sum: C must be a multiple of 8");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(k_pool2_sum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, du, B, H, W, Hu, Wu, C, dx, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+// stride-2 sampling picked input pixel (2oy + ky - pad, ...): its adjoint is a stride-1 convolution with the flipped
+// kernel over dy spread onto the even positions of an (H, W) grid
+__global__ __launch_bounds__(256) void k_zero_stuff2(const bf16_t* __restrict__ dy, int B, int Ho, int Wo, int H, int W, int C,
+                                                     bf16_t* __restrict__ dz, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int CV = C / 8;
+    const int c = (int)(idx % CV) * 8;
+    size_t r = idx / CV;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+        v = *(const uint4*)(dy + (((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c);
+    *(uint4*)(dz + (((size_t)n * H + y) * W + x) * C + c) = v;
+}
+int launch_zero_stuff2(hipStream_t st, const bf16_t* dy, int B, int Ho, int Wo, int H, int W, int C, bf16_t* dz) {
+    if (C % 8) GYRE_FAIL(-1, "zero_stuff2: C must be a multiple of 8");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(k_zero_stuff2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, Ho, Wo, H, W, C, dz, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+__global__ __launch_bounds__(256) void k_add_bf16(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    float a[8], b[8];
+    unpack8(((const uint4*)y)[i], a);
+    unpack8(((const uint4*)x)[i], b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    ((uint4*)y)[i] = pack8(a);
+}
+int launch_add_bf16(hipStream_t st, bf16_t* y, const bf16_t* x, size_t n) {
+    if (n % 8) GYRE_FAIL(-1, "add_bf16: n must be a multiple of 8");
+    hipLaunchKernelGGL(k_add_bf16, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, y, x, n / 8);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+// conv weight [O][3][3][I] -> [I][3][3][O] with the window rotated by 180 degrees (the data-gradient convolution)
+__global__ __launch_bounds__(256) void k_conv_weight_t(const bf16_t* __restrict__ w, int O, int I, bf16_t* __restrict__ wt,
+                                                       size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int o = (int)(idx % O);
+    const int t = (int)((idx / O) % 9);
+    const int i = (int)(idx / ((size_t)O * 9));
+    wt[idx] = w[((size_t)o * 9 + (8 - t)) * I + i];
+}
+int launch_conv_weight_t(hipStream_t st, const bf16_t* w, int O, int I, bf16_t* wt) {
+    const size_t total = (size_t)O * 9 * I;
+    hipLaunchKernelGGL(k_conv_weight_t, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, O, I, wt, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+// out[b][c][r] = in[b][r][c] for r < R (zeros for R <= r < ld_out): batched 2-D transpose through LDS
+__global__ __launch_bounds__(256) void k_transpose(const bf16_t* __restrict__ in, int ld_in, int R, int C, bf16_t* __restrict__ out,
+                                                   int ld_out, size_t bs_in, size_t bs_out) {
+    __shared__ bf16_t tile[64][66];
+    const bf16_t* src = in + blockIdx.z * bs_in;
+    bf16_t* dst = out + blockIdx.z * bs_out;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * ld_in + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < ld_out) dst[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+int launch_transpose(hipStream_t st, const bf16_t* in, int ld_in, int R, int C, bf16_t* out, int ld_out, int batch,
+                     size_t bs_in, size_t bs_out) {
+    if (ld_out < R) GYRE_FAIL(-1, "transpose: ld_out < rows");
+    hipLaunchKernelGGL(k_transpose, dim3((ld_out + 63) / 64, (C + 63) / 64, batch), dim3(256), 0, st, in, ld_in, R, C, out,
+                       ld_out, bs_in, bs_out);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
+// Attention backward.  Per (sample, head):  S = Q K^T,  P = softmax(S * scale),  O = P V.  Given dO:
+//   delta_i = sum_d dO_id O_id,   dP = dO V^T,   dS = P o (dP - delta),
+//   dQ = dS K * scale,   dK = dS^T Q * scale,   dV = P^T dO.
+// v_mfma_f32_32x32x16_bf16 register layouts (wave64): A / B operand lane l = row / column l & 31, eight consecutive k at
+// 8 * (l >> 5); result lane l = column l & 31, register r = row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+//   k_attn_bwd_dq   (wave = 32 queries) builds S^T = K Q^T so a lane owns ONE query and 16 keys per tile: the softmax
+//                   statistics, P^T and dS^T are lane-local, and dS^T is directly the B operand of dQ^T += K^T dS^T.
+//   k_attn_bwd_dkv  (wave = 32 keys) builds S = Q K^T so a lane owns ONE key and 16 queries per tile: P and dS are directly
+//                   the A operands of dV += P^T dO and dK += dS^T Q.
+// In both, the contraction index of the second product is the set of rows a lane holds, i.e. a fixed permutation of the
+// tile's 32 rows; the other operand is read in the same permuted order from a transposed copy ([C][tokens]) of K / Q / dO.
+// The first pass of k_attn_bwd_dq produces the row log-sum-exp (base 2) both kernels recompute P from.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_bwd_delta(AttnBwdParams p) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * Nq * H
+    if (idx >= (size_t)p.B * p.Nq * p.H) return;
+    const int h = (int)(idx % p.H);
+    const size_t row = idx / p.H;          // b * Nq + q
+    const int b = (int)(row / p.Nq), q = (int)(row % p.Nq);
+    const bf16_t* o = p.o + row * p.ldo + h * p.D;
+    const bf16_t* d = p.d_o + row * p.lddo + h * p.D;
+    float s = 0.f;
+    for (int v = 0; v < p.D; v += 8) {
+        float a[8], c[8];
+        unpack8(*(const uint4*)(o + v), a);
+        unpack8(*(const uint4*)(d + v), c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(a[j], c[j], s);
+    }
+    p.delta[((size_t)b * p.H + h) * p.NqPad + q] = s;
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* base, int ld, int row, int nrows, int k, int kmax) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nrows && k < kmax) v = *(const uint4*)(base + (size_t)row * ld + k);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+// eight values of one row of a transposed operand in the permuted order of MFMA step m: tokens t0 + 16m + 4hi + {0..3, 8..11}
+__device__ __forceinline__ bf16x8_t ld_frag_t(const bf16_t* rowp, bool row_ok, int t) {
+    uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
+    if (row_ok) { a = *(const uint2*)(rowp + t); b = *(const uint2*)(rowp + t + 8); }
+    return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& v, int m) {
+    return __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(v[8 * m + 0], v[8 * m + 1]), pack_bf16x2(v[8 * m + 2], v[8 * m + 3]),
+                                                   pack_bf16x2(v[8 * m + 4], v[8 * m + 5]), pack_bf16x2(v[8 * m + 6], v[8 * m + 7])));
+}
+
+template <int NDB>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunks) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const int qblk = blockIdx.x / dchunks, dchunk = blockIdx.x % dchunks;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (qblk * 4 + wave) * 32;
+    if (q0 >= p.Nq) return;
+    const int D = p.D;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    const bf16_t* KT = p.kt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldkt;
+    const int q = q0 + col;
+    const size_t stat = ((size_t)b * p.H + h) * p.NqPad + q;
+    const int nkb = (p.Nk + 31) / 32;
+    const float NEG = -1e30f;
+
+    // pass 1: row maximum and sum of 2^(s - max) over all keys (lane-local over its 16 keys per tile, halves merged last)
+    float lse2;
+    {
+        float mx = NEG, sum = 0.f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16_t s = {};
+            for (int d0 = 0; d0 < D; d0 += 16)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D),
+                                                            ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D), s, 0, 0, 0);
+            float tmx = NEG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s[r] = key < p.Nk ? s[r] * p.alpha : NEG;
+                tmx = fmaxf(tmx, s[r]);
+            }
+            const float nm = fmaxf(mx, tmx);
+            float ts = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ts += __builtin_amdgcn_exp2f(s[r] - nm);
+            sum = sum * __builtin_amdgcn_exp2f(mx - nm) + ts;
+            mx = nm;
+        }
+        const float omx = __shfl_xor(mx, 32), osum = __shfl_xor(sum, 32);
+        const float nm = fmaxf(mx, omx);
+        sum = sum * __builtin_amdgcn_exp2f(mx - nm) + osum * __builtin_amdgcn_exp2f(omx - nm);
+        lse2 = nm + __builtin_amdgcn_logf(sum);     // v_log_f32 is log2
+        if (dchunk == 0 && hi == 0 && q < p.Nq) p.lse[stat] = lse2;
+    }
+    const float delta = q < p.Nq ? p.delta[stat] : 0.f;
+
+    // pass 2: dQ^T[d][q] += K^T[d][keys] dS^T[keys][q]
+    f32x16_t acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) acc[i] = f32x16_t{};
+    const int dbase = dchunk * NDB * 32;
+    for (int kb = 0; kb < nkb; ++kb) {
+        f32x16_t s = {}, dp = {};
+        for (int d0 = 0; d0 < D; d0 += 16) {
+            const bf16x8_t qf = ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D);
+            const bf16x8_t dof = ld_frag(DO, p.lddo, q, p.Nq, d0 + 8 * hi, D);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D), qf, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, d0 + 8 * hi, D), dof, dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(s[r] * p.alpha - lse2) : 0.f;
+            s[r] = pr * (dp[r] - delta);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const bf16x8_t dsf = pack_frag(s, m);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) {
+                const int d = dbase + i * 32 + col;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_t(KT + (size_t)d * p.ldkt, d < D, kb * 32 + 16 * m + 4 * hi),
+                                                                 dsf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    if (q >= p.Nq) return;
+    bf16_t* out = p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dbase + i * 32 + 8 * g + 4 * hi;
+            if (d < D)
+                *(uint2*)(out + d) = make_uint2(pack_bf16x2(acc[i][4 * g] * p.beta, acc[i][4 * g + 1] * p.beta),
+                                                pack_bf16x2(acc[i][4 * g + 2] * p.beta, acc[i][4 * g + 3] * p.beta));
+        }
+}
+
+template <int NDB>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchunks) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
+    const int kblk = blockIdx.x / dchunks, dchunk = blockIdx.x % dchunks;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = (kblk * 4 + wave) * 32;
+    if (k0 >= p.Nk) return;
+    const int D = p.D;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    const bf16_t* QT = p.qt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldqt;
+    const bf16_t* DOT = p.d_ot + ((size_t)b * p.H * D + (size_t)h * D) * p.ldqt;
+    const float* LSE = p.lse + ((size_t)b * p.H + h) * p.NqPad;
+    const float* DEL = p.delta + ((size_t)b * p.H + h) * p.NqPad;
+    const int key = k0 + col;
+    const int nqb = (p.Nq + 31) / 32;
+    f32x16_t dk[NDB], dv[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) { dk[i] = f32x16_t{}; dv[i] = f32x16_t{}; }
+    const int dbase = dchunk * NDB * 32;
+    for (int qb = 0; qb < nqb; ++qb) {
+        f32x16_t s = {}, dp = {};
+        for (int d0 = 0; d0 < D; d0 += 16) {
+            const bf16x8_t kf = ld_frag(K, p.ldk, key, p.Nk, d0 + 8 * hi, D);
+            const bf16x8_t vf = ld_frag(V, p.ldv, key, p.Nk, d0 + 8 * hi, D);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, d0 + 8 * hi, D), kf, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, d0 + 8 * hi, D), vf, dp, 0, 0, 0);
+        }
+        // lane: key fixed, queries qb*32 + 8g + 4hi + {0..3}; NqPad is a multiple of 32 so the statistics reads stay in range
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int qq = qb * 32 + 8 * g + 4 * hi;
+            const float4 l4 = *(const float4*)(LSE + qq), d4 = *(const float4*)(DEL + qq);
+            const float l[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (qq + r) < p.Nq && key < p.Nk;
+                const float pr = ok ? __builtin_amdgcn_exp2f(s[4 * g + r] * p.alpha - l[r]) : 0.f;
+                s[4 * g + r] = pr;
+                dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const bf16x8_t pf = pack_frag(s, m), dsf = pack_frag(dp, m);
+            const int t = qb * 32 + 16 * m + 4 * hi;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) {
+                const int d = dbase + i * 32 + col;
+                dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ld_frag_t(DOT + (size_t)d * p.ldqt, d < D, t), dv[i], 0, 0, 0);
+                dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, ld_frag_t(QT + (size_t)d * p.ldqt, d < D, t), dk[i], 0, 0, 0);
+            }
+        }
+    }
+    // result lane: column = d, register r = key (r & 3) + 8 (r >> 2) + 4 hi
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) {
+        const int d = dbase + i * 32 + col;
+        if (d >= D) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (kk < p.Nk) {
+                p.dk[((size_t)b * p.Nk + kk) * p.lddk + h * D + d] = f32_to_bf16(dk[i][r] * p.beta);
+                p.dv[((size_t)b * p.Nk + kk) * p.lddv + h * D + d] = f32_to_bf16(dv[i][r]);
+            }
+        }
+    }
+}
+
+size_t attn_bwd_stats_bytes(int B, int H, int Nq) {
+    const size_t npad = (size_t)(Nq + 31) / 32 * 32;
+    return 2 * (((size_t)B * H * npad * 4 + 255) & ~(size_t)255);
+}
+int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
+    if (p.D % 8 || p.ldq % 8 || p.ldk % 8 || p.ldv % 8 || p.lddo % 8 || p.ldo % 8 || p.lddq % 4 || p.ldkt % 4 || p.ldqt % 4)
+        GYRE_FAIL(-1, "attention_bwd: head dim and row strides must be multiples of 8 elements");
+    if (p.B < 1 || p.H < 1 || p.Nq < 1 || p.Nk < 1) GYRE_FAIL(-1, "attention_bwd: empty problem");
+    if (p.ldkt < (p.Nk + 31) / 32 * 32 || (p.dk && p.ldqt < (p.Nq + 31) / 32 * 32))
+        GYRE_FAIL(-1, "attention_bwd: transposed operands need token strides padded to a multiple of 32");
+    p.NqPad = (p.Nq + 31) / 32 * 32;
+    const size_t half = ((size_t)p.B * p.H * p.NqPad * 4 + 255) & ~(size_t)255;
+    p.lse = (float*)p.stats; p.delta = (float*)((char*)p.stats + half);
+    const float sc = 1.0f / sqrtf((float)p.D);
+    // K prescaled by log2(e) / sqrt(D) (UNet to_k weights): logits are already base-2; d logit / d (Q K'^T) = ln 2
+    p.alpha = p.k_prescaled ? 1.0f : sc * 1.4426950408889634f;
+    p.beta = p.k_prescaled ? 0.6931471805599453f : sc;
+    GYRE_HIP_CHECK(hipMemsetAsync(p.stats, 0, 2 * half, st));
+    const size_t nd = (size_t)p.B * p.Nq * p.H;
+    hipLaunchKernelGGL(k_attn_bwd_delta, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, p);
+    GYRE_LAUNCH_CHECK();
+    const int ndb_total = (p.D + 31) / 32;
+    const int ndb = ndb_total <= 2 ? 2 : (ndb_total <= 3 ? 3 : (ndb_total <= 5 ? 5 : 4));
+    const int dchunks = (ndb_total + ndb - 1) / ndb;
+    const dim3 gq((unsigned)((p.Nq + 127) / 128 * dchunks), p.H, p.B), gk((unsigned)((p.Nk + 127) / 128 * dchunks), p.H, p.B);
+    switch (ndb) {
+        case 2: hipLaunchKernelGGL(k_attn_bwd_dq<2>, gq, dim3(256), 0, st, p, dchunks); break;
+        case 3: hipLaunchKernelGGL(k_attn_bwd_dq<3>, gq, dim3(256), 0, st, p, dchunks); break;
+        case 5: hipLaunchKernelGGL(k_attn_bwd_dq<5>, gq, dim3(256), 0, st, p, dchunks); break;
+        default: hipLaunchKernelGGL(k_attn_bwd_dq<4>, gq, dim3(256), 0, st, p, dchunks); break;
+    }
+    GYRE_LAUNCH_CHECK();
+    if (!p.dk) return 0;
+    switch (ndb) {
+        case 2: hipLaunchKernelGGL(k_attn_bwd_dkv<2>, gk, dim3(256), 0, st, p, dchunks); break;
+        case 3: hipLaunchKernelGGL(k_attn_bwd_dkv<3>, gk, dim3(256), 0, st, p, dchunks); break;
+        case 5: hipLaunchKernelGGL(k_attn_bwd_dkv<5>, gk, dim3(256), 0, st, p, dchunks); break;
+        default: hipLaunchKernelGGL(k_attn_bwd_dkv<4>, gk, dim3(256), 0, st, p, dchunks); break;
+    }
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}

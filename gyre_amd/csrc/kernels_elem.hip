@@ -233,6 +233,10 @@ __global__ __launch_bounds__(256) void k_gn_finalize(GnParams p) {
         float var = fmaxf(sb / cnt - mean * mean, 0.f);
         mean_s[g] = mean;
         rstd_s[g] = rsqrtf(var + p.eps);
+        if (p.mean_rstd) {
+            p.mean_rstd[((size_t)n * p.G + g) * 2 + 0] = mean;
+            p.mean_rstd[((size_t)n * p.G + g) * 2 + 1] = rstd_s[g];
+        }
     }
     __syncthreads();
     float* sc = p.scale_shift + (size_t)n * 2 * p.C;

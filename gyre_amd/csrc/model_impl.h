@@ -1,0 +1,974 @@
+// Model runtime internals shared by model.hip (forward graphs + C ABI) and model_vjp.hip (input-gradient graphs):
+// workspace arena, weight store, per-layer weight records, the op executor and the UNet / VAE graph objects.
+#pragma once
+#include "../../include/gyre_hip.h"
+#include "kernels.h"
+#include <cstdlib>
+#include <cmath>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int pad8(int c) { return (c + 7) / 8 * 8; }
+
+// ------------------------------------------------------------------------------------------
+// workspace arena: first-fit free list over a caller-provided buffer.  The same call sequence
+// gives the same offsets, so a dry run (no launches) yields the exact peak requirement.
+// ------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, peak = 0;
+    bool dry = false;
+    std::map<size_t, size_t> free_;  // offset -> size
+    void reset(char* b, size_t c, bool d) {
+        base = b; cap = c; dry = d; peak = 0;
+        free_.clear();
+        free_[0] = d ? ((size_t)1 << 60) : c;
+    }
+    // returns offset or (size_t)-1
+    size_t alloc(size_t bytes) {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            if (it->second >= bytes) {
+                size_t off = it->first, rem = it->second - bytes;
+                free_.erase(it);
+                if (rem) free_[off + bytes] = rem;
+                peak = std::max(peak, off + bytes);
+                return off;
+            }
+        }
+        return (size_t)-1;
+    }
+    void release(size_t off, size_t bytes) {
+        bytes = align_up(bytes ? bytes : 1, 256);
+        auto it = free_.emplace(off, bytes).first;
+        auto nx = std::next(it);
+        if (nx != free_.end() && it->first + it->second == nx->first) { it->second += nx->second; free_.erase(nx); }
+        if (it != free_.begin()) {
+            auto pv = std::prev(it);
+            if (pv->first + pv->second == it->first) { pv->second += it->second; free_.erase(it); }
+        }
+    }
+};
+
+struct Tn {  // NHWC bf16 activation (or a raw byte buffer when C == 0)
+    bf16_t* p = nullptr; size_t off = (size_t)-1, bytes = 0;
+    int B = 0, H = 0, W = 0, C = 0;
+    int rows() const { return B * H * W; }
+    bool valid() const { return off != (size_t)-1; }
+};
+
+// ------------------------------------------------------------------------------------------
+// weight store
+// ------------------------------------------------------------------------------------------
+enum ParamKind { PK_CONV3 = 0, PK_MAT = 1, PK_VEC = 2, PK_MAT_GEGLU = 3, PK_VEC_GEGLU = 4 };
+struct Param {
+    std::string key;
+    std::vector<int64_t> shape;  // PyTorch shape expected from the caller
+    int kind = PK_VEC;
+    int o_pad = 0, i_pad = 0;    // padded out / in channels of the repacked matrix
+    void* dev = nullptr;         // destination (inside `owner` allocation)
+    float scale = 1.f;           // folded into the values in fp32 before the bf16 rounding (attention K scale)
+    bool set = false;
+};
+
+struct Store {
+    int device = 0;
+    std::vector<std::unique_ptr<Param>> params;
+    std::unordered_map<std::string, Param*> by_key;
+    std::vector<void*> allocs;
+    ~Store() { for (void* a : allocs) (void)hipFree(a); }
+    void* dmalloc(size_t bytes, bool zero) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        if (zero) (void)hipMemset(p, 0, bytes);
+        allocs.push_back(p);
+        return p;
+    }
+    Param* add(const std::string& key, std::vector<int64_t> shape, int kind, void* dev, int o_pad = 0, int i_pad = 0) {
+        auto p = std::make_unique<Param>();
+        p->key = key; p->shape = std::move(shape); p->kind = kind; p->dev = dev; p->o_pad = o_pad; p->i_pad = i_pad;
+        Param* raw = p.get();
+        by_key[key] = raw;
+        params.push_back(std::move(p));
+        return raw;
+    }
+    // --- convenience creators: allocate + register -------------------------------------------------
+    bf16_t* conv3(const std::string& pfx, int O, int I, float** bias) {
+        int ip = pad8(I), op = pad8(O);  // zero rows up to a multiple of 8: the consumer's C % 8 == 0
+        bf16_t* w = (bf16_t*)dmalloc((size_t)op * 9 * ip * 2, true);
+        add(pfx + ".weight", {O, I, 3, 3}, PK_CONV3, w, op, ip);
+        float* b = (float*)dmalloc((size_t)pad8(O) * 4, true);
+        add(pfx + ".bias", {O}, PK_VEC, b);
+        *bias = b;
+        return w;
+    }
+    // linear or 1x1 conv; rows padded to a multiple of 8 with zeros so the output tensor can feed
+    // kernels that need C % 8 == 0
+    bf16_t* mat(const std::string& pfx, int O, int I, bool conv1x1, bool has_bias, float** bias, int kind = PK_MAT) {
+        int ip = pad8(I), op = pad8(O);
+        bf16_t* w = (bf16_t*)dmalloc((size_t)op * ip * 2, true);
+        std::vector<int64_t> shp = conv1x1 ? std::vector<int64_t>{O, I, 1, 1} : std::vector<int64_t>{O, I};
+        add(pfx + ".weight", shp, kind, w, op, ip);
+        if (bias) *bias = nullptr;
+        if (has_bias) {
+            float* b = (float*)dmalloc((size_t)op * 4, true);
+            add(pfx + ".bias", {O}, kind == PK_MAT_GEGLU ? PK_VEC_GEGLU : PK_VEC, b);
+            *bias = b;
+        }
+        return w;
+    }
+    void vec(const std::string& key, int n, float** out) {
+        float* b = (float*)dmalloc((size_t)n * 4, true);
+        add(key, {n}, PK_VEC, b);
+        *out = b;
+    }
+    int set_weight(const char* key, const void* src, int dtype, const int64_t* shape, int ndim, hipStream_t st) {
+        auto it = by_key.find(key);
+        if (it == by_key.end()) GYRE_FAIL(GYRE_ERR_KEY, std::string("unknown weight key: ") + key);
+        Param& p = *it->second;
+        if (dtype < 0 || dtype > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+        bool ok = (int)p.shape.size() == ndim;
+        for (int i = 0; ok && i < ndim; ++i) ok = p.shape[i] == shape[i];
+        if (!ok) {
+            std::string m = std::string("shape mismatch for ") + key + ": expected [";
+            for (auto d : p.shape) m += std::to_string(d) + ",";
+            m += "] got [";
+            for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + ",";
+            GYRE_FAIL(GYRE_ERR_KEY, m + "]");
+        }
+        int O = (int)p.shape[0];
+        switch (p.kind) {
+            case PK_CONV3: TRY(launch_repack_conv(st, src, dtype, O, (int)p.shape[1], 3, 3, p.i_pad, (bf16_t*)p.dev)); break;
+            case PK_MAT: case PK_MAT_GEGLU: {
+                int I = (int)p.shape[1];
+                // [O][I] -> [O][i_pad] (reuse the conv repack with a 1x1 window for the padding case)
+                if (p.i_pad != I || p.kind == PK_MAT) {
+                    if (p.kind == PK_MAT_GEGLU) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "geglu weight with padded K");
+                    TRY(launch_repack_conv(st, src, dtype, O, I, 1, 1, p.i_pad, (bf16_t*)p.dev, p.scale));
+                } else {
+                    TRY(launch_repack_linear(st, src, dtype, O, I, 1, (bf16_t*)p.dev));
+                }
+                break;
+            }
+            case PK_VEC: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 0, (float*)p.dev, p.scale)); break;
+            case PK_VEC_GEGLU: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 1, (float*)p.dev)); break;
+        }
+        p.set = true;
+        return 0;
+    }
+    int finalize() {
+        for (auto& p : params)
+            if (!p->set) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "weight not set: " + p->key);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// layer weights
+// ------------------------------------------------------------------------------------------
+struct ResW {
+    int cin = 0, cout = 0;
+    float *n1g, *n1b, *n2g, *n2b;
+    bf16_t *c1w, *c2w, *scw = nullptr;
+    float *c1b, *c2b, *scb = nullptr;
+    int temb_off = -1;  // column offset into the batched time_emb_proj output
+};
+struct AttnW {
+    int c = 0, heads = 1, kv_dim = 0;
+    bf16_t *wqk = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    int k_prescaled = 0;         // to_k weights carry the softmax scale (UNet attention; not the VAE block)
+    bool qkv_fused = false;      // wqk holds [3C][C] = Q | K | V rows (UNet self-attention)
+    float *bqk = nullptr, *bq = nullptr, *bk = nullptr, *bv = nullptr, *bo = nullptr;
+};
+struct TBlockW {
+    float *ln1g, *ln1b, *ln2g, *ln2b, *ln3g, *ln3b;
+    AttnW a1, a2;
+    bf16_t *ff1, *ff2;
+    float *ff1b, *ff2b;
+};
+struct TransW {
+    int c = 0, heads = 1;
+    float *ng, *nb;
+    bf16_t *pin, *pout;
+    float *pinb, *poutb;
+    std::vector<TBlockW> blocks;
+};
+struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; };
+
+// ------------------------------------------------------------------------------------------
+// execution context: arena + stream + dry-run switch; every op allocates its output
+// ------------------------------------------------------------------------------------------
+struct CtxKV { bf16_t* k; bf16_t* vt; };
+// Activations a forward pass keeps for the input-gradient pass (model_vjp.hip) instead of returning them to the arena
+struct MhaSave { Tn ao; };                                   // attention output before the out projection
+struct ResSave { Tn h1; };                                   // conv1 output (input of the second GroupNorm)
+struct TBlockSave { Tn h0, n1, h1, n2, h2, n3; MhaSave a1, a2; };   // block input, LN outputs, residual stream after each attention
+struct TransSave { std::vector<TBlockSave> blocks; Tn hlast; };     // hlast: residual stream entering proj_out
+struct Exec {
+    Arena arena;
+    hipStream_t st = nullptr;
+    int groups = 32;
+    std::string fail;
+    // cross-attention K / V^T of the current text context, projected once per request (gyre_unet_set_context)
+    const std::vector<CtxKV>* ctx_cache = nullptr;
+    size_t ctx_layer = 0;
+    int batch = 0;   // samples in the current call (planner hint, see gemm_set_batch_invariant)
+    int tome_r = 0;  // ToMe: keys / values merged per self-attention (0 = off; reference option "tome", nonfree/tome_unet.py)
+
+    bool dry() const { return arena.dry; }
+    int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        t.bytes = (size_t)B * H * W * C * elt;
+        t.off = arena.alloc(t.bytes);
+        if (t.off == (size_t)-1 || (!arena.dry && t.off + t.bytes > arena.cap))
+            GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small: need " + std::to_string(t.bytes) + " B at offset " +
+                      std::to_string((long long)t.off) + ", capacity " + std::to_string(arena.cap) + " B (tensor " +
+                      std::to_string(B) + "x" + std::to_string(H) + "x" + std::to_string(W) + "x" + std::to_string(C) + ")");
+        t.p = arena.dry ? nullptr : (bf16_t*)(arena.base + t.off);
+        return 0;
+    }
+    int alloc_raw(Tn& t, size_t bytes) { return alloc(t, 1, 1, 1, (int)((bytes + 1) / 2)); }
+    void free(Tn& t) { if (t.valid()) { arena.release(t.off, t.bytes); t.off = (size_t)-1; t.p = nullptr; } }
+
+    // GroupNorm (+SiLU) of x (optionally concatenated with x2 along C)
+    int groupnorm(const Tn& x, const Tn* x2, const float* g, const float* b, float eps, int silu, Tn& y) {
+        int C = x.C + (x2 ? x2->C : 0);
+        int HW = x.H * x.W;
+        Tn ws;
+        TRY(alloc_raw(ws, gn_workspace_bytes(x.B, HW, C, groups)));
+        TRY(alloc(y, x.B, x.H, x.W, C));
+        if (!dry()) {
+            GnParams p;
+            p.x = x.p; p.x2 = x2 ? x2->p : x.p; p.C1 = x.C; p.B = x.B; p.HW = HW; p.C = C; p.G = groups;
+            p.gamma = g; p.beta = b; p.eps = eps; p.silu = silu;
+            p.nchunks = gn_pick_chunks(x.B, HW, C);
+            p.partial = (float*)ws.p;
+            p.scale_shift = (float*)((char*)ws.p + align_up((size_t)x.B * p.nchunks * groups * 2 * sizeof(float), 256));
+            p.y = y.p;
+            if (gn_use_small(HW, C, x.C, groups)) {
+                TRY(launch_groupnorm_small(st, p));
+            } else {
+                TRY(launch_groupnorm_stats(st, p));
+                TRY(launch_groupnorm_apply(st, p));
+            }
+        }
+        free(ws);
+        return 0;
+    }
+    // runs one GEMM launch, giving it split-K slab space from the arena when the planner wants it
+    int run_gemm(GemmParams& p) {
+        if (!p.samples) p.samples = batch;
+        GemmPlan pl = gemm_plan(p);
+        Tn ws;
+        if (pl.ws_bytes) {
+            TRY(alloc_raw(ws, pl.ws_bytes));
+            p.splitk_ws = (float*)ws.p; p.splitk_ws_bytes = pl.ws_bytes;
+        }
+        int rc = dry() ? 0 : launch_gemm(st, p);
+        free(ws);
+        return rc;
+    }
+    // 3x3 conv; x2 = second channel source (skip concat), rowbias = per-sample channel bias (temb)
+    // ups: nearest-neighbour upsampling fused into the gather.  (Hup, Wup) = size of the upsampled image, by default
+    // 2x; diffusers resizes to the skip connection's size when the latent is not a multiple of 2^levels
+    // (UNet2DConditionModel forward_upsample_size), which for sizes 2H-1 is the 2x image minus its last row / column.
+    int conv3(const Tn& x, const ConvW& w, int stride, int pad, int ups, const float* rowbias, int ld_rowbias,
+              const Tn* residual, Tn& y, int Hup = 0, int Wup = 0) {
+        if (ups && ((Hup && (Hup > 2 * x.H || Hup < 2 * x.H - 1)) || (Wup && (Wup > 2 * x.W || Wup < 2 * x.W - 1))))
+            GYRE_FAIL(GYRE_ERR_INVALID, "upsample target must be 2x or 2x-1 of the input");
+        int Hin = ups ? (Hup ? Hup : 2 * x.H) : x.H, Win = ups ? (Wup ? Wup : 2 * x.W) : x.W;
+        int Ho = (Hin + (pad ? 2 : 1) - 3) / stride + 1, Wo = (Win + (pad ? 2 : 1) - 3) / stride + 1;
+        TRY(alloc(y, x.B, Ho, Wo, pad8(w.cout)));
+        GemmParams p;
+        p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
+        p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad; p.ups = ups;
+        p.Hup = ups ? Hin : 0; p.Wup = ups ? Win : 0;
+        p.W = w.w; p.K = 9 * x.C; p.N = pad8(w.cout); p.M = x.B * Ho * Wo;
+        p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
+        if (residual) { p.residual = residual->p; p.ldr = residual->C; }
+        p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
+        return run_gemm(p);
+    }
+    // final 3x3 conv straight to the caller's NCHW buffer
+    int conv3_nchw(const Tn& x, const ConvW& w, void* out, int out_dtype) {
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
+        p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = x.H; p.Wo = x.W; p.stride = 1; p.pad = 1;
+        p.W = w.w; p.K = 9 * x.C; p.N = w.cout; p.M = x.rows();
+        p.bias = w.b; p.rows_per_sample = x.H * x.W;
+        p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = out_dtype;
+        return launch_gemm(st, p);
+    }
+    // y[M][N] = x[M][K] (|| x2) @ w^T + bias (+ residual); geglu halves N
+    int linear(const bf16_t* x, int lda, const bf16_t* x2, int lda2, int C1, int M, int K, const bf16_t* w, int N,
+               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc) {
+        GemmParams p;
+        p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
+        p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
+        p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
+        return run_gemm(p);
+    }
+    int linear_t(const bf16_t* x, int lda, int M, int K, const bf16_t* w, int N, const float* bias, int tokens, int ldt,
+                 bf16_t* y) {
+        if (dry()) return 0;
+        GemmParams p;
+        p.A = x; p.lda = lda; p.mode = GEMM_LINEAR; p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias;
+        p.out = y; p.out_mode = OUT_BF16_T; p.tokens_per_batch = tokens; p.ldt = ldt;
+        return launch_gemm(st, p);
+    }
+    int layernorm(const Tn& x, const float* g, const float* b, Tn& y) {
+        TRY(alloc(y, x.B, x.H, x.W, x.C));
+        if (dry()) return 0;
+        return launch_layernorm(st, x.p, x.rows(), x.C, g, b, 1e-5f, y.p);
+    }
+    // multi-head attention of tokens x against kv source (self: kv == nullptr); out = proj(attn) + residual
+    int mha(const Tn& xq, bool cross, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w,
+            const Tn& residual, Tn& out, MhaSave* sv = nullptr) {
+        const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
+        Tn q, k, vt, ao;
+        const bf16_t *qp, *kp, *vtp = nullptr; int ldq, ldk, Nk, ldvt;
+        Tn km, vrow, tws;
+        const int tr = (!cross && tome_r > 0 && Nq % 16 == 0) ? tome_effective_r(Nq, tome_r) : 0;
+        if (!cross && tr > 0) {
+            // ToMe (nonfree/tome_unet.py:138-182): K and V of a self-attention are projected row-major, the r most
+            // redundant even-position keys are averaged into their best odd-position match (values follow the same
+            // assignment), and the attention runs against N - r keys.  Queries are untouched.
+            Nk = Nq - tr; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, 2 * C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
+            TRY(alloc(vrow, B, xq.H, xq.W, C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wv, C, w.bv, nullptr, 0, 0, vrow.p, C));
+            TRY(alloc(km, B, Nk, 1, C));
+            TRY(alloc(vt, B, C, 1, ldvt));
+            TRY(alloc_raw(tws, tome_workspace_bytes(B, Nq, C)));
+            if (!dry()) {
+                TomeParams tp;
+                tp.k = q.p + C; tp.ldk = 2 * C; tp.v = vrow.p; tp.ldv = C; tp.B = B; tp.N = Nq; tp.C = C; tp.r = tr;
+                tp.k_out = km.p; tp.vt_out = vt.p; tp.ldvt = ldvt; tp.ws = tws.p; tp.ws_bytes = tws.bytes;
+                TRY(launch_tome_merge(st, tp));
+            }
+            free(tws); free(vrow);
+            qp = q.p; kp = km.p; vtp = vt.p; ldq = 2 * C; ldk = C;
+        } else if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
+            Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, 2 * C));
+            TRY(alloc(vt, B, C, 1, ldvt));
+            bool fused = false;
+            if (w.qkv_fused && !w.bqk && !w.bv && Nq % 8 == 0) {
+                // Q | K | V in one launch: the V tiles write V^T through the transposing epilogue (needs an 8-wave
+                // tile config whose wave tiles line up with the V columns; else two launches as before)
+                GemmParams p;
+                p.A = xq.p; p.lda = C; p.mode = GEMM_LINEAR; p.W = w.wqk; p.K = C; p.N = 3 * C; p.M = B * Nq; p.samples = B;
+                p.out = q.p; p.ldc = 2 * C; p.out_mode = OUT_BF16;
+                p.vt_out = vt.p; p.vt_col0 = 2 * C; p.tokens_per_batch = Nq; p.ldt = ldvt;
+                GemmPlan pl = gemm_plan(p);
+                const int tn = pl.cfg == 4 ? 160 : pl.cfg == 5 ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
+                if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
+                    fused = true;
+                    if (!dry()) TRY(launch_gemm(st, p));
+                }
+            }
+            if (!fused) {
+                TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
+                TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
+            }
+            qp = q.p; kp = dry() ? nullptr : q.p + C; vtp = vt.p; ldq = ldk = 2 * C;
+        } else {
+            Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
+            TRY(alloc(q, B, xq.H, xq.W, C));
+            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wq, C, w.bq, nullptr, 0, 0, q.p, C));
+            if (ctx_cache) {  // K / V^T of this layer were projected when the context was set
+                if (ctx_layer >= ctx_cache->size()) GYRE_FAIL(GYRE_ERR_INVALID, "internal: context cache layer overflow");
+                kp = (*ctx_cache)[ctx_layer].k; vtp = (*ctx_cache)[ctx_layer].vt;
+                ++ctx_layer;
+            } else {
+                TRY(alloc(k, B, Nk, 1, C));
+                TRY(linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wk, C, w.bk, nullptr, 0, 0, k.p, C));
+                TRY(alloc(vt, B, C, 1, ldvt));
+                TRY(linear_t(kvsrc, kv_dim, B * Nk, kv_dim, w.wv, C, w.bv, Nk, ldvt, vt.p));
+                kp = k.p; vtp = vt.p;
+            }
+            qp = q.p; ldq = ldk = C;
+        }
+        TRY(alloc(ao, B, xq.H, xq.W, C));
+        if (!dry()) {
+            AttnParams a;
+            a.q = qp; a.ldq = ldq; a.k = kp; a.ldk = ldk; a.vt = vtp; a.ldvt = ldvt; a.o = ao.p; a.ldo = C;
+            a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = w.k_prescaled;
+            TRY(launch_attention(st, a));
+        }
+        free(q); free(k); free(vt); free(km);
+        TRY(alloc(out, B, xq.H, xq.W, C));
+        TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C));
+        if (sv) sv->ao = ao; else free(ao);
+        return 0;
+    }
+    int resnet(const Tn& x, const Tn* skip, const ResW& w, const float* tproj, int ld_tproj, float eps, Tn& out,
+               ResSave* sv = nullptr) {
+        Tn a, h1, b, sc;
+        TRY(groupnorm(x, skip, w.n1g, w.n1b, eps, 1, a));
+        ConvW c1{w.c1w, w.c1b, w.cin, w.cout};
+        TRY(conv3(a, c1, 1, 1, 0, (tproj && w.temb_off >= 0) ? tproj + w.temb_off : nullptr, ld_tproj, nullptr, h1));
+        free(a);
+        TRY(groupnorm(h1, nullptr, w.n2g, w.n2b, eps, 1, b));
+        if (sv) sv->h1 = h1; else free(h1);
+        const Tn* res = &x;
+        if (w.scw) {
+            TRY(alloc(sc, x.B, x.H, x.W, w.cout));
+            TRY(linear(x.p, x.C, skip ? skip->p : nullptr, skip ? skip->C : 0, x.C, x.rows(), w.cin, w.scw, w.cout,
+                       w.scb, nullptr, 0, 0, sc.p, w.cout));
+            res = &sc;
+        } else if (skip) {
+            GYRE_FAIL(GYRE_ERR_INVALID, "resnet: concat input needs a shortcut conv");
+        }
+        ConvW c2{w.c2w, w.c2b, w.cout, w.cout};
+        TRY(conv3(b, c2, 1, 1, 0, nullptr, 0, res, out));
+        free(b); free(sc);
+        return 0;
+    }
+    int transformer(const Tn& x, const Tn& ctx, int S, int ctx_dim, const TransW& w, Tn& out, TransSave* sv = nullptr) {
+        const int B = x.B, M = x.rows(), C = w.c;
+        Tn a, h;
+        TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
+        TRY(alloc(h, B, x.H, x.W, C));
+        TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C));
+        free(a);
+        if (sv) sv->blocks.assign(w.blocks.size(), TBlockSave());
+        for (size_t bi = 0; bi < w.blocks.size(); ++bi) {
+            const TBlockW& bw = w.blocks[bi];
+            TBlockSave* bs = sv ? &sv->blocks[bi] : nullptr;
+            Tn n, h2, ff;
+            TRY(layernorm(h, bw.ln1g, bw.ln1b, n));
+            TRY(mha(n, false, nullptr, 0, 0, bw.a1, h, h2, bs ? &bs->a1 : nullptr));
+            if (bs) { bs->h0 = h; bs->n1 = n; } else { free(n); free(h); }
+            h = h2;
+            TRY(layernorm(h, bw.ln2g, bw.ln2b, n));
+            TRY(mha(n, true, ctx.p, S, ctx_dim, bw.a2, h, h2, bs ? &bs->a2 : nullptr));
+            if (bs) { bs->h1 = h; bs->n2 = n; } else { free(n); free(h); }
+            h = h2;
+            TRY(layernorm(h, bw.ln3g, bw.ln3b, n));
+            TRY(alloc(ff, B, x.H, x.W, 4 * C));
+            TRY(linear(n.p, C, nullptr, 0, 0, M, C, bw.ff1, 8 * C, bw.ff1b, nullptr, 0, 1, ff.p, 4 * C));
+            if (bs) bs->n3 = n; else free(n);
+            TRY(alloc(h2, B, x.H, x.W, C));
+            TRY(linear(ff.p, 4 * C, nullptr, 0, 0, M, 4 * C, bw.ff2, C, bw.ff2b, h.p, C, 0, h2.p, C));
+            free(ff);
+            if (bs) bs->h2 = h; else free(h);
+            h = h2;
+        }
+        TRY(alloc(out, B, x.H, x.W, C));
+        TRY(linear(h.p, C, nullptr, 0, 0, M, C, w.pout, C, w.poutb, x.p, C, 0, out.p, C));
+        if (sv) sv->hlast = h; else free(h);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// weight registration helpers
+// ------------------------------------------------------------------------------------------
+static void reg_resnet(Store& s, const std::string& p, int cin, int cout, bool temb, bf16_t* temb_w, float* temb_b,
+                       int temb_dim, int& temb_cols, ResW& w) {
+    w.cin = cin; w.cout = cout;
+    s.vec(p + ".norm1.weight", cin, &w.n1g); s.vec(p + ".norm1.bias", cin, &w.n1b);
+    w.c1w = s.conv3(p + ".conv1", cout, cin, &w.c1b);
+    if (temb) {
+        w.temb_off = temb_cols;
+        s.add(p + ".time_emb_proj.weight", {cout, temb_dim}, PK_MAT, temb_w + (size_t)temb_cols * temb_dim, cout, temb_dim);
+        s.add(p + ".time_emb_proj.bias", {cout}, PK_VEC, temb_b + temb_cols);
+        temb_cols += cout;
+    }
+    s.vec(p + ".norm2.weight", cout, &w.n2g); s.vec(p + ".norm2.bias", cout, &w.n2b);
+    w.c2w = s.conv3(p + ".conv2", cout, cout, &w.c2b);
+    if (cin != cout) w.scw = s.mat(p + ".conv_shortcut", cout, cin, true, true, &w.scb);
+}
+static void reg_attn(Store& s, const std::string& p, int c, int heads, int kv_dim, bool self, AttnW& w) {
+    w.c = c; w.heads = heads; w.kv_dim = kv_dim; w.k_prescaled = 1;
+    // The softmax scale log2(e)/sqrt(head_dim) is folded into the K projection weights (fp32, before their one bf16
+    // rounding): S = q.k then arrives from the matrix core already in the exp2 domain (AttnParams::k_prescaled)
+    const float kscale = 1.4426950408889634f / sqrtf((float)(c / heads));
+    if (self) {   // one [3C][C] matrix: rows Q | K | V, so that the three projections can run as a single GEMM
+        w.wqk = (bf16_t*)s.dmalloc((size_t)3 * c * c * 2, true);
+        s.add(p + ".to_q.weight", {c, c}, PK_MAT, w.wqk, c, c);
+        s.add(p + ".to_k.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c)->scale = kscale;
+        w.wv = w.wqk + (size_t)2 * c * c;
+        s.add(p + ".to_v.weight", {c, c}, PK_MAT, w.wv, c, c);
+        w.qkv_fused = true;
+    } else {
+        w.wq = s.mat(p + ".to_q", c, c, false, false, nullptr);
+        w.wk = s.mat(p + ".to_k", c, kv_dim, false, false, nullptr);
+        s.by_key[p + ".to_k.weight"]->scale = kscale;
+        w.wv = s.mat(p + ".to_v", c, kv_dim, false, false, nullptr);
+    }
+    w.wo = s.mat(p + ".to_out.0", c, c, false, true, &w.bo);
+}
+static void reg_transformer(Store& s, const std::string& p, int c, int heads, int ctx_dim, int depth, bool linproj,
+                            TransW& w) {
+    w.c = c; w.heads = heads;
+    s.vec(p + ".norm.weight", c, &w.ng); s.vec(p + ".norm.bias", c, &w.nb);
+    w.pin = s.mat(p + ".proj_in", c, c, !linproj, true, &w.pinb);
+    w.blocks.resize(depth);
+    for (int d = 0; d < depth; ++d) {
+        std::string b = p + ".transformer_blocks." + std::to_string(d);
+        TBlockW& bw = w.blocks[d];
+        s.vec(b + ".norm1.weight", c, &bw.ln1g); s.vec(b + ".norm1.bias", c, &bw.ln1b);
+        s.vec(b + ".norm2.weight", c, &bw.ln2g); s.vec(b + ".norm2.bias", c, &bw.ln2b);
+        s.vec(b + ".norm3.weight", c, &bw.ln3g); s.vec(b + ".norm3.bias", c, &bw.ln3b);
+        reg_attn(s, b + ".attn1", c, heads, c, true, bw.a1);
+        reg_attn(s, b + ".attn2", c, heads, ctx_dim, false, bw.a2);
+        bw.ff1 = s.mat(b + ".ff.net.0.proj", 8 * c, c, false, true, &bw.ff1b, PK_MAT_GEGLU);
+        bw.ff2 = s.mat(b + ".ff.net.2", c, 4 * c, false, true, &bw.ff2b);
+    }
+    w.pout = s.mat(p + ".proj_out", c, c, !linproj, true, &w.poutb);
+}
+
+// ------------------------------------------------------------------------------------------
+// UNet
+// ------------------------------------------------------------------------------------------
+struct gyre_unet {
+    gyre_unet_cfg cfg;
+    Store store;
+    Exec ex;
+    bool finalized = false;
+    int temb_dim = 0, temb_cols = 0;
+    bf16_t *te1w, *te2w; float *te1b, *te2b;
+    bf16_t* tproj_w = nullptr; float* tproj_b = nullptr;
+    ConvW conv_in, conv_out;
+    float *ong, *onb;
+    struct Level { std::vector<ResW> res; std::vector<TransW> attn; ConvW resample; bool has_resample = false; };
+    std::vector<Level> down, up;
+    ResW mid0, mid1; TransW mid_attn;
+    // debug taps (parity tests): name -> (device f32 NCHW buffer, capacity in bytes); consumed by the next forward
+    std::map<std::string, std::pair<float*, size_t>> taps;
+    // text-context cache (cross-attention K / V^T per layer, and the bf16 copy of the context)
+    std::vector<CtxKV> kv_cache;
+    void* kv_buf = nullptr; size_t kv_bytes = 0;
+    int cache_B = 0, cache_S = 0; bool cache_valid = false;
+    ~gyre_unet() { if (kv_buf) (void)hipFree(kv_buf); }
+
+    template <typename F> void for_each_cross_attn(F f) {
+        for (auto& lv : down) for (auto& t : lv.attn) for (auto& b : t.blocks) f(b.a2);
+        for (auto& b : mid_attn.blocks) f(b.a2);
+        for (auto& lv : up) for (auto& t : lv.attn) for (auto& b : t.blocks) f(b.a2);
+    }
+    // Project the text context through every cross-attention to_k / to_v once; the denoising loop then calls
+    // forward with ctx == NULL (the context is constant over the 50+ UNet evaluations of a request).
+    int set_context(hipStream_t st, const void* ctx, int cdt, int B, int S) {
+        if (B < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty context");
+        const int D = cfg.cross_attention_dim, Spad = (S + 7) / 8 * 8;
+        size_t need = align_up((size_t)B * S * D * 2, 256);
+        for_each_cross_attn([&](AttnW& a) { need += align_up((size_t)B * S * a.c * 2, 256) + align_up((size_t)B * a.c * Spad * 2, 256); });
+        cache_valid = false;
+        if (need > kv_bytes) {
+            if (kv_buf) { GYRE_HIP_CHECK(hipStreamSynchronize(st)); (void)hipFree(kv_buf); kv_buf = nullptr; kv_bytes = 0; }
+            GYRE_HIP_CHECK(hipMalloc(&kv_buf, need));
+            kv_bytes = need;
+        }
+        GYRE_HIP_CHECK(hipMemsetAsync(kv_buf, 0, need, st));   // V^T pad columns must be finite
+        char* ptr = (char*)kv_buf;
+        bf16_t* cx = (bf16_t*)ptr; ptr += align_up((size_t)B * S * D * 2, 256);
+        TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx));
+        kv_cache.clear();
+        int rc = 0;
+        for_each_cross_attn([&](AttnW& a) {
+            if (rc) return;
+            CtxKV e;
+            e.k = (bf16_t*)ptr; ptr += align_up((size_t)B * S * a.c * 2, 256);
+            e.vt = (bf16_t*)ptr; ptr += align_up((size_t)B * a.c * Spad * 2, 256);
+            GemmParams p;
+            p.A = cx; p.lda = D; p.mode = GEMM_LINEAR; p.W = a.wk; p.K = D; p.N = a.c; p.M = B * S; p.bias = a.bk; p.samples = B;
+            p.out = e.k; p.ldc = a.c; p.out_mode = OUT_BF16;
+            rc = launch_gemm(st, p);
+            if (rc) return;
+            GemmParams q;
+            q.A = cx; q.lda = D; q.mode = GEMM_LINEAR; q.W = a.wv; q.K = D; q.N = a.c; q.M = B * S; q.bias = a.bv; q.samples = B;
+            q.out = e.vt; q.out_mode = OUT_BF16_T; q.tokens_per_batch = S; q.ldt = Spad;
+            rc = launch_gemm(st, q);
+            kv_cache.push_back(e);
+        });
+        if (rc) return rc;
+        cache_B = B; cache_S = S; cache_valid = true;
+        return 0;
+    }
+
+    int build() {
+        const gyre_unet_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (n < 1 || n > GYRE_MAX_LEVELS) GYRE_FAIL(GYRE_ERR_INVALID, "n_levels out of range");
+        for (int i = 0; i < n; ++i) {
+            if (c.block_out_channels[i] % c.norm_num_groups || c.block_out_channels[i] % 8)
+                GYRE_FAIL(GYRE_ERR_INVALID, "block_out_channels must be multiples of norm_num_groups and 8");
+            if (c.attn_levels[i] && (c.block_out_channels[i] % c.num_heads[i] || (c.block_out_channels[i] / c.num_heads[i]) % 8))
+                GYRE_FAIL(GYRE_ERR_INVALID, "head dim must be a multiple of 8");
+        }
+        if (c.cross_attention_dim % 8) GYRE_FAIL(GYRE_ERR_INVALID, "cross_attention_dim must be a multiple of 8");
+        ex.groups = c.norm_num_groups;
+        const int c0 = c.block_out_channels[0];
+        temb_dim = 4 * c0;
+        // total columns of the batched time_emb_proj
+        int total_cols = 0;
+        for (int i = 0; i < n; ++i) total_cols += c.layers_per_block * c.block_out_channels[i];
+        total_cols += 2 * c.block_out_channels[n - 1];
+        for (int i = 0; i < n; ++i) total_cols += (c.layers_per_block + 1) * c.block_out_channels[n - 1 - i];
+        tproj_w = (bf16_t*)store.dmalloc((size_t)total_cols * temb_dim * 2, true);
+        tproj_b = (float*)store.dmalloc((size_t)total_cols * 4, true);
+        if (!tproj_w || !tproj_b) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+
+        te1w = store.mat("time_embedding.linear_1", temb_dim, c0, false, true, &te1b);
+        te2w = store.mat("time_embedding.linear_2", temb_dim, temb_dim, false, true, &te2b);
+        conv_in.cin = pad8(c.in_channels); conv_in.cout = c0;
+        conv_in.w = store.conv3("conv_in", c0, c.in_channels, &conv_in.b);
+        std::vector<int> skip_ch{c0};
+        int cin = c0;
+        down.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[i];
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                std::string p = "down_blocks." + std::to_string(i);
+                down[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, true, tproj_w, tproj_b, temb_dim, temb_cols,
+                           down[i].res.back());
+                cin = co;
+                if (c.attn_levels[i]) {
+                    down[i].attn.emplace_back();
+                    reg_transformer(store, p + ".attentions." + std::to_string(j), cin, c.num_heads[i], c.cross_attention_dim,
+                                    c.transformer_depth[i], c.use_linear_projection != 0, down[i].attn.back());
+                }
+                skip_ch.push_back(cin);
+            }
+            if (i < n - 1) {
+                down[i].has_resample = true;
+                down[i].resample.cin = cin; down[i].resample.cout = cin;
+                down[i].resample.w = store.conv3("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin,
+                                                 &down[i].resample.b);
+                skip_ch.push_back(cin);
+            }
+        }
+        reg_resnet(store, "mid_block.resnets.0", cin, cin, true, tproj_w, tproj_b, temb_dim, temb_cols, mid0);
+        reg_transformer(store, "mid_block.attentions.0", cin, c.num_heads[n - 1], c.cross_attention_dim,
+                        c.transformer_depth[n - 1], c.use_linear_projection != 0, mid_attn);
+        reg_resnet(store, "mid_block.resnets.1", cin, cin, true, tproj_w, tproj_b, temb_dim, temb_cols, mid1);
+        up.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int lvl = n - 1 - i, co = c.block_out_channels[lvl];
+            std::string p = "up_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                int sk = skip_ch.back(); skip_ch.pop_back();
+                up[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin + sk, co, true, tproj_w, tproj_b, temb_dim,
+                           temb_cols, up[i].res.back());
+                cin = co;
+                if (c.attn_levels[lvl]) {
+                    up[i].attn.emplace_back();
+                    reg_transformer(store, p + ".attentions." + std::to_string(j), cin, c.num_heads[lvl],
+                                    c.cross_attention_dim, c.transformer_depth[lvl], c.use_linear_projection != 0,
+                                    up[i].attn.back());
+                }
+            }
+            if (i < n - 1) {
+                up[i].has_resample = true;
+                up[i].resample.cin = cin; up[i].resample.cout = cin;
+                up[i].resample.w = store.conv3(p + ".upsamplers.0.conv", cin, cin, &up[i].resample.b);
+            }
+        }
+        store.vec("conv_norm_out.weight", cin, &ong); store.vec("conv_norm_out.bias", cin, &onb);
+        conv_out.cin = cin; conv_out.cout = c.out_channels;
+        conv_out.w = store.conv3("conv_out", c.out_channels, cin, &conv_out.b);
+        if (temb_cols != total_cols) GYRE_FAIL(GYRE_ERR_INVALID, "internal: temb column count mismatch");
+        for (void* a : store.allocs) if (!a) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+        return 0;
+    }
+
+    int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
+            int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr,
+            bool use_ctx_cache = false) {
+        const gyre_unet_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
+        ex.arena.reset((char*)ws, ws_bytes, dry);
+        ex.st = st; ex.batch = B;
+        Exec& e = ex;
+        const int D = c.cross_attention_dim;
+        const bool cached = use_ctx_cache;
+        if (cached && (!cache_valid || cache_B != B || cache_S != S))
+            GYRE_FAIL(GYRE_ERR_INVALID, "unet: ctx == NULL needs a gyre_unet_set_context call with the same B and S");
+        e.ctx_cache = cached ? &kv_cache : nullptr;
+        e.ctx_layer = 0;
+        Tn xin, cx, emb, t1, t2, tp;
+        TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
+        if (!cached) TRY(e.alloc(cx, B, S, 1, D));
+        TRY(e.alloc(emb, B, 1, 1, c.block_out_channels[0], 4));
+        TRY(e.alloc(t1, B, 1, 1, temb_dim, 4));
+        TRY(e.alloc(t2, B, 1, 1, temb_dim, 4));
+        TRY(e.alloc(tp, B, 1, 1, temb_cols, 4));
+        if (!dry) {
+            TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
+            if (!cached) TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
+            TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
+            TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
+            TRY(launch_rowvec_linear(st, (float*)t1.p, B, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
+            // SDXL-style added conditioning (text_time): emb = time_embedding(t) + aug_emb, aug_emb from the host
+            if (temb_add) TRY(launch_add_f32(st, (float*)t2.p, temb_add, (size_t)B * temb_dim));
+            // every resnet's Linear(SiLU(temb)) in one launch
+            TRY(launch_rowvec_linear(st, (float*)t2.p, B, temb_dim, tproj_w, tproj_b, temb_cols, 1, (float*)tp.p, temb_cols));
+        }
+        e.free(emb); e.free(t1); e.free(t2);
+        const float* tproj = (const float*)tp.p;
+
+        auto tap = [&](const std::string& name, const Tn& t, int channels) -> int {
+            if (dry) return 0;
+            auto it = taps.find(name);
+            if (it == taps.end()) return 0;
+            const size_t need = (size_t)t.B * channels * t.H * t.W * sizeof(float);
+            if (it->second.second < need) GYRE_FAIL(GYRE_ERR_INVALID, "tap buffer too small for " + name);
+            return launch_nhwc_to_nchw_f32(st, t.p, t.B, channels, t.H * t.W, t.C, it->second.first);
+        };
+        std::vector<Tn> skips;
+        Tn h;
+        TRY(e.conv3(xin, conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
+        e.free(xin);
+        skips.push_back(h);
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                Tn r;
+                TRY(e.resnet(skips.back(), nullptr, down[i].res[j], tproj, temb_cols, 1e-5f, r));
+                if (c.attn_levels[i]) {
+                    Tn a;
+                    TRY(e.transformer(r, cx, S, D, down[i].attn[j], a));
+                    e.free(r); r = a;
+                }
+                skips.push_back(r);
+            }
+            if (down[i].has_resample) {
+                Tn d;
+                TRY(e.conv3(skips.back(), down[i].resample, 2, 1, 0, nullptr, 0, nullptr, d));
+                skips.push_back(d);
+            }
+            TRY(tap("down" + std::to_string(i), skips.back(), c.block_out_channels[i]));
+        }
+        {
+            Tn a, b2;
+            TRY(e.resnet(skips.back(), nullptr, mid0, tproj, temb_cols, 1e-5f, a));
+            TRY(e.transformer(a, cx, S, D, mid_attn, b2));
+            e.free(a);
+            TRY(e.resnet(b2, nullptr, mid1, tproj, temb_cols, 1e-5f, h));
+            e.free(b2);
+            TRY(tap("mid", h, c.block_out_channels[n - 1]));
+        }
+        for (int i = 0; i < n; ++i) {
+            const int lvl = n - 1 - i;
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                Tn sk = skips.back(); skips.pop_back();
+                Tn r;
+                TRY(e.resnet(h, &sk, up[i].res[j], tproj, temb_cols, 1e-5f, r));
+                e.free(h); e.free(sk);
+                if (c.attn_levels[lvl]) {
+                    Tn a;
+                    TRY(e.transformer(r, cx, S, D, up[i].attn[j], a));
+                    e.free(r); r = a;
+                }
+                h = r;
+            }
+            if (up[i].has_resample) {
+                Tn u;   // resize to the next skip connection's size (= 2x unless the latent size is odd at this level)
+                TRY(e.conv3(h, up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u, skips.back().H, skips.back().W));
+                e.free(h); h = u;
+            }
+            TRY(tap("up" + std::to_string(i), h, c.block_out_channels[lvl]));
+        }
+        if (!dry) taps.clear();
+        Tn a;
+        TRY(e.groupnorm(h, nullptr, ong, onb, 1e-5f, 1, a));
+        e.free(h);
+        TRY(e.conv3_nchw(a, conv_out, out, odt));
+        e.free(a); e.free(tp); e.free(cx);
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// VAE
+// ------------------------------------------------------------------------------------------
+struct gyre_vae {
+    gyre_vae_cfg cfg;
+    Store store;
+    Exec ex;
+    struct Blk { std::vector<ResW> res; ConvW resample; bool has_resample = false; };
+    // encoder
+    ConvW e_in, e_out; std::vector<Blk> e_down; ResW e_mid0, e_mid1; AttnW e_attn; float *e_ag, *e_ab, *e_ng, *e_nb;
+    bf16_t* quant_w; float* quant_b;
+    // decoder
+    ConvW d_in, d_out; std::vector<Blk> d_up; ResW d_mid0, d_mid1; AttnW d_attn; float *d_ag, *d_ab, *d_ng, *d_nb;
+    bf16_t* pq_w; float* pq_b;
+
+    void reg_vattn(const std::string& p, int c, AttnW& w, float** g, float** b) {
+        w.c = c; w.heads = 1; w.kv_dim = c;
+        store.vec(p + ".group_norm.weight", c, g); store.vec(p + ".group_norm.bias", c, b);
+        w.wqk = (bf16_t*)store.dmalloc((size_t)2 * c * c * 2, true);
+        w.bqk = (float*)store.dmalloc((size_t)2 * c * 4, true);
+        store.add(p + ".query.weight", {c, c}, PK_MAT, w.wqk, c, c);
+        store.add(p + ".query.bias", {c}, PK_VEC, w.bqk);
+        store.add(p + ".key.weight", {c, c}, PK_MAT, w.wqk + (size_t)c * c, c, c);
+        store.add(p + ".key.bias", {c}, PK_VEC, w.bqk + c);
+        w.wv = store.mat(p + ".value", c, c, false, true, &w.bv);
+        w.wo = store.mat(p + ".proj_attn", c, c, false, true, &w.bo);
+    }
+    int build() {
+        const gyre_vae_cfg& c = cfg;
+        const int n = c.n_levels;
+        if (n < 1 || n > GYRE_MAX_LEVELS) GYRE_FAIL(GYRE_ERR_INVALID, "n_levels out of range");
+        for (int i = 0; i < n; ++i)
+            if (c.block_out_channels[i] % c.norm_num_groups || c.block_out_channels[i] % 8)
+                GYRE_FAIL(GYRE_ERR_INVALID, "block_out_channels must be multiples of norm_num_groups and 8");
+        ex.groups = c.norm_num_groups;
+        int dummy = 0;
+        const int z = c.latent_channels;
+        // ---- encoder ----
+        int cin = c.block_out_channels[0];
+        e_in.cin = pad8(c.in_channels); e_in.cout = cin;
+        e_in.w = store.conv3("encoder.conv_in", cin, c.in_channels, &e_in.b);
+        e_down.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[i];
+            std::string p = "encoder.down_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                e_down[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, false, nullptr, nullptr, 0, dummy,
+                           e_down[i].res.back());
+                cin = co;
+            }
+            if (i < n - 1) {
+                e_down[i].has_resample = true;
+                e_down[i].resample.cin = cin; e_down[i].resample.cout = cin;
+                e_down[i].resample.w = store.conv3(p + ".downsamplers.0.conv", cin, cin, &e_down[i].resample.b);
+            }
+        }
+        reg_resnet(store, "encoder.mid_block.resnets.0", cin, cin, false, nullptr, nullptr, 0, dummy, e_mid0);
+        reg_vattn("encoder.mid_block.attentions.0", cin, e_attn, &e_ag, &e_ab);
+        reg_resnet(store, "encoder.mid_block.resnets.1", cin, cin, false, nullptr, nullptr, 0, dummy, e_mid1);
+        store.vec("encoder.conv_norm_out.weight", cin, &e_ng); store.vec("encoder.conv_norm_out.bias", cin, &e_nb);
+        e_out.cin = cin; e_out.cout = 2 * z;
+        e_out.w = store.conv3("encoder.conv_out", 2 * z, cin, &e_out.b);
+        quant_w = store.mat("quant_conv", 2 * z, 2 * z, true, true, &quant_b);
+        // ---- decoder ----
+        pq_w = store.mat("post_quant_conv", z, z, true, true, &pq_b);
+        cin = c.block_out_channels[n - 1];
+        d_in.cin = pad8(z); d_in.cout = cin;
+        d_in.w = store.conv3("decoder.conv_in", cin, z, &d_in.b);
+        reg_resnet(store, "decoder.mid_block.resnets.0", cin, cin, false, nullptr, nullptr, 0, dummy, d_mid0);
+        reg_vattn("decoder.mid_block.attentions.0", cin, d_attn, &d_ag, &d_ab);
+        reg_resnet(store, "decoder.mid_block.resnets.1", cin, cin, false, nullptr, nullptr, 0, dummy, d_mid1);
+        d_up.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const int co = c.block_out_channels[n - 1 - i];
+            std::string p = "decoder.up_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                d_up[i].res.emplace_back();
+                reg_resnet(store, p + ".resnets." + std::to_string(j), cin, co, false, nullptr, nullptr, 0, dummy,
+                           d_up[i].res.back());
+                cin = co;
+            }
+            if (i < n - 1) {
+                d_up[i].has_resample = true;
+                d_up[i].resample.cin = cin; d_up[i].resample.cout = cin;
+                d_up[i].resample.w = store.conv3(p + ".upsamplers.0.conv", cin, cin, &d_up[i].resample.b);
+            }
+        }
+        store.vec("decoder.conv_norm_out.weight", cin, &d_ng); store.vec("decoder.conv_norm_out.bias", cin, &d_nb);
+        d_out.cin = cin; d_out.cout = c.out_channels;
+        d_out.w = store.conv3("decoder.conv_out", c.out_channels, cin, &d_out.b);
+        for (void* a : store.allocs) if (!a) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed");
+        return 0;
+    }
+    // GN -> fused QK / V^T projections -> single-head attention -> proj + residual
+    int vattn(Exec& e, const Tn& x, const AttnW& w, const float* g, const float* b, Tn& out) {
+        Tn a;
+        TRY(e.groupnorm(x, nullptr, g, b, 1e-6f, 0, a));
+        TRY(e.mha(a, false, nullptr, 0, 0, w, x, out));
+        e.free(a);
+        return 0;
+    }
+    int mid(Exec& e, Tn& h, const ResW& r0, const AttnW& aw, const float* g, const float* b, const ResW& r1) {
+        Tn a, b2, c2;
+        TRY(e.resnet(h, nullptr, r0, nullptr, 0, 1e-6f, a)); e.free(h);
+        TRY(vattn(e, a, aw, g, b, b2)); e.free(a);
+        TRY(e.resnet(b2, nullptr, r1, nullptr, 0, 1e-6f, c2)); e.free(b2);
+        h = c2;
+        return 0;
+    }
+    int run_encode(bool dry, hipStream_t st, const void* img, int idt, int B, int H, int W, void* ws, size_t wsb,
+                   void* out, int odt) {
+        const int n = cfg.n_levels;
+        if (B < 1 || H < 1 || W < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: empty input");
+        if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: H, W must be multiples of 8");
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
+        Exec& e = ex;
+        Tn x, h;
+        TRY(e.alloc(x, B, H, W, pad8(cfg.in_channels)));
+        if (!dry) TRY(launch_nchw_to_nhwc(st, img, idt, B, cfg.in_channels, H * W, x.C, x.p));
+        TRY(e.conv3(x, e_in, 1, 1, 0, nullptr, 0, nullptr, h)); e.free(x);
+        for (int i = 0; i < n; ++i) {
+            for (auto& rw : e_down[i].res) {
+                Tn r; TRY(e.resnet(h, nullptr, rw, nullptr, 0, 1e-6f, r)); e.free(h); h = r;
+            }
+            if (e_down[i].has_resample) {  // pad (0,1,0,1) + stride-2 conv, pad 0
+                Tn d; TRY(e.conv3(h, e_down[i].resample, 2, 0, 0, nullptr, 0, nullptr, d)); e.free(h); h = d;
+            }
+        }
+        TRY(mid(e, h, e_mid0, e_attn, e_ag, e_ab, e_mid1));
+        Tn a, m;
+        TRY(e.groupnorm(h, nullptr, e_ng, e_nb, 1e-6f, 1, a)); e.free(h);
+        TRY(e.conv3(a, e_out, 1, 1, 0, nullptr, 0, nullptr, m)); e.free(a);
+        if (!dry) {
+            GemmParams p;
+            p.A = m.p; p.lda = m.C; p.mode = GEMM_LINEAR; p.W = quant_w; p.K = m.C; p.N = 2 * cfg.latent_channels;
+            p.M = m.rows(); p.bias = quant_b; p.rows_per_sample = m.H * m.W;
+            p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = odt;
+            TRY(launch_gemm(st, p));
+        }
+        e.free(m);
+        return 0;
+    }
+    int run_decode(bool dry, hipStream_t st, const void* z, int idt, int B, int h_, int w_, void* ws, size_t wsb,
+                   void* out, int odt) {
+        const int n = cfg.n_levels;
+        if (B < 1 || h_ < 1 || w_ < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.decode: empty input");
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
+        Exec& e = ex;
+        Tn x, q, h;
+        const int zc = pad8(cfg.latent_channels);
+        TRY(e.alloc(x, B, h_, w_, zc));
+        if (!dry) TRY(launch_nchw_to_nhwc(st, z, idt, B, cfg.latent_channels, h_ * w_, zc, x.p));
+        TRY(e.alloc(q, B, h_, w_, zc));
+        TRY(e.linear(x.p, zc, nullptr, 0, 0, x.rows(), zc, pq_w, zc, pq_b, nullptr, 0, 0, q.p, zc)); e.free(x);
+        TRY(e.conv3(q, d_in, 1, 1, 0, nullptr, 0, nullptr, h)); e.free(q);
+        TRY(mid(e, h, d_mid0, d_attn, d_ag, d_ab, d_mid1));
+        for (int i = 0; i < n; ++i) {
+            for (auto& rw : d_up[i].res) {
+                Tn r; TRY(e.resnet(h, nullptr, rw, nullptr, 0, 1e-6f, r)); e.free(h); h = r;
+            }
+            if (d_up[i].has_resample) {
+                Tn u; TRY(e.conv3(h, d_up[i].resample, 1, 1, 1, nullptr, 0, nullptr, u)); e.free(h); h = u;
+            }
+        }
+        Tn a;
+        TRY(e.groupnorm(h, nullptr, d_ng, d_nb, 1e-6f, 1, a)); e.free(h);
+        TRY(e.conv3_nchw(a, d_out, out, odt)); e.free(a);
+        return 0;
+    }
+};
+
+// model_vjp.hip: forward + reverse sweep in one call (dry = size the workspace only)
+int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
+                      int B, int H, int W, int S, const void* d_eps, int ddt, void* ws, size_t ws_bytes, void* eps_out, int odt,
+                      void* dx_out, int dxdt, const float* temb_add);
+int gyre_vae_run_decode_vjp(gyre_vae& v, bool dry, hipStream_t st, const void* z, int zdt, int B, int h_, int w_, const void* d_img,
+                            int ddt, void* ws, size_t wsb, void* img_out, int odt, void* dz_out, int dzdt);

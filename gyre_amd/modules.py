@@ -274,10 +274,8 @@ class GyreHipUNet(_NativeModule):
         a = torch.nn.functional.linear(torch.nn.functional.silu(a), ae.linear_2.weight.float(), ae.linear_2.bias.float())
         return a.contiguous()
 
-    @torch.no_grad()
-    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
-                down_block_additional_residuals=None, mid_block_additional_residual=None, adapter_states=None,
-                added_cond_kwargs=None, return_dict: bool = True, **_ignored):
+    def _prepare(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals,
+                 mid_block_additional_residual, adapter_states):
         if encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states is required")
         if down_block_additional_residuals is not None or mid_block_additional_residual is not None \
@@ -285,7 +283,7 @@ class GyreHipUNet(_NativeModule):
             raise NotImplementedError("ControlNet / T2I residual injection is outside the native hot path")
         if sample.ndim != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"expected latents [B,{self.config.in_channels},H,W], got {tuple(sample.shape)}")
-        B, _, H, W = sample.shape
+        B = sample.shape[0]
         if encoder_hidden_states.ndim != 3 or encoder_hidden_states.shape[0] != B \
                 or encoder_hidden_states.shape[2] != self.config.cross_attention_dim:
             raise ValueError(f"expected encoder_hidden_states [{B},S,{self.config.cross_attention_dim}], "
@@ -295,9 +293,6 @@ class GyreHipUNet(_NativeModule):
         if getattr(self, "_tome_applied", (None, None)) != (h, getattr(self, "_tome_r", 0)):
             _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
             self._tome_applied = (h, getattr(self, "_tome_r", 0))
-        x = sample.contiguous()
-        ctx = encoder_hidden_states.to(dev).contiguous()
-        _lib.require_gpu_tensor(x, "latents")
         if isinstance(timestep, torch.Tensor):
             t = timestep.to(dev).to(torch.int64).reshape(-1)
             if t.numel() == 1:
@@ -309,7 +304,29 @@ class GyreHipUNet(_NativeModule):
             t = torch.full((B,), int(timestep), dtype=torch.int64, device=dev)
         if t.numel() != B:
             raise ValueError(f"timestep must be a scalar or have {B} elements")
-        t = t.contiguous()
+        return h, t.contiguous()
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor = None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, adapter_states=None,
+                added_cond_kwargs=None, return_dict: bool = True, **_ignored):
+        """Noise prediction.  When autograd is recording and ``sample`` requires grad (the reference's CLIP-guided mode,
+        unet/clipguided.py:301-338), the result carries a backward that calls the native input-gradient sweep
+        (gyre_unet_vjp); weights and the text context never receive gradients."""
+        h, t = self._prepare(sample, timestep, encoder_hidden_states, down_block_additional_residuals,
+                             mid_block_additional_residual, adapter_states)
+        if torch.is_grad_enabled() and sample.requires_grad:
+            out = _UNetInputGrad.apply(sample, self, h, t, encoder_hidden_states, added_cond_kwargs)
+        else:
+            with torch.no_grad():
+                out = self._forward_native(h, sample, t, encoder_hidden_states, added_cond_kwargs)
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    def _forward_native(self, h, sample, t, encoder_hidden_states, added_cond_kwargs):
+        B, _, H, W = sample.shape
+        dev = sample.device
+        x = sample.contiguous()
+        ctx = encoder_hidden_states.to(dev).contiguous()
+        _lib.require_gpu_tensor(x, "latents")
         S = ctx.shape[1]
         L = _lib.lib()
         with torch.cuda.device(dev):
@@ -337,7 +354,50 @@ class GyreHipUNet(_NativeModule):
                                               _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
                                               C.c_void_p(out.data_ptr()), _lib.dtype_code(out),
                                               C.c_void_p(aug.data_ptr()) if aug is not None else None))
-        return SimpleNamespace(sample=out) if return_dict else (out,)
+        return out
+
+    def _vjp_native(self, h, sample, t, encoder_hidden_states, added_cond_kwargs, d_out):
+        """(eps, d_sample) from one native call: forward keeping the adjoints' inputs + reverse sweep."""
+        B, _, H, W = sample.shape
+        dev = sample.device
+        x, g = sample.contiguous(), d_out.contiguous()
+        ctx = encoder_hidden_states.to(dev).contiguous()
+        _lib.require_gpu_tensor(x, "latents")
+        _lib.require_gpu_tensor(g, "d_eps")
+        S = ctx.shape[1]
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            need = L.gyre_unet_vjp_workspace_bytes(C.c_void_p(h), B, H, W, S)
+            if need == 0:
+                _lib.check(-6 if "ToMe" in L.gyre_last_error().decode() else -4)
+            ws = self._workspace(need, dev)
+            wp = (ws.data_ptr() + 255) & ~255
+            eps = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
+            dx = torch.empty_like(x)
+            aug = self._aug_embedding(added_cond_kwargs, B, dev)
+            _lib.check(L.gyre_unet_vjp(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                       _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                                       _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(g.data_ptr()), _lib.dtype_code(g),
+                                       C.c_void_p(wp), need, C.c_void_p(eps.data_ptr()), _lib.dtype_code(eps),
+                                       C.c_void_p(dx.data_ptr()), _lib.dtype_code(dx),
+                                       C.c_void_p(aug.data_ptr()) if aug is not None else None))
+        return eps, dx
+
+
+class _UNetInputGrad(torch.autograd.Function):
+    """autograd node of GyreHipUNet.forward: backward = gyre_unet_vjp (gradient of the sample only)."""
+
+    @staticmethod
+    def forward(fctx, sample, module, h, t, enc, added):
+        fctx.module, fctx.h, fctx.added = module, h, added
+        fctx.save_for_backward(sample.detach(), t, enc.detach())
+        return module._forward_native(h, sample.detach(), t, enc.detach(), added)
+
+    @staticmethod
+    def backward(fctx, d_out):
+        sample, t, enc = fctx.saved_tensors
+        _, dx = fctx.module._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
+        return dx, None, None, None, None, None
 
 
 def set_batch_invariant(canonical_samples: int = 16) -> int:
@@ -439,25 +499,61 @@ class GyreHipVAE(_NativeModule):
         dist = DiagonalGaussian(out)
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
-    @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """Latents -> image.  Differentiable with respect to ``z`` when autograd is recording (the reference decodes the
+        CLIP cut-outs under autograd, unet/clipguided.py:366-386): backward = gyre_vae_decode_vjp."""
         if z.ndim != 4 or z.shape[1] != self.config.latent_channels:
             raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
+        h = self._sync(z.device)
+        if torch.is_grad_enabled() and z.requires_grad:
+            out = _VAEDecodeInputGrad.apply(z, self, h)
+        else:
+            with torch.no_grad():
+                out = self._decode_native(h, z, None)
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    def _decode_native(self, h, z, d_img):
+        """d_img None: image; else (image, d_z) through gyre_vae_decode_vjp."""
         dev = z.device
-        h = self._sync(dev)
         z = z.contiguous()
         _lib.require_gpu_tensor(z, "latents")
         B, _, hl, wl = z.shape
         L = _lib.lib()
         f = 2 ** (len(self.config.block_out_channels) - 1)
         with torch.cuda.device(dev):
-            need = L.gyre_vae_workspace_bytes(C.c_void_p(h), B, hl, wl, 1)
+            need = (L.gyre_vae_workspace_bytes(C.c_void_p(h), B, hl, wl, 1) if d_img is None else
+                    L.gyre_vae_decode_vjp_workspace_bytes(C.c_void_p(h), B, hl, wl))
             if need == 0:
                 _lib.check(-1)
             ws = self._workspace(need, dev)
             wp = (ws.data_ptr() + 255) & ~255
             out = torch.empty((B, self.config.out_channels, hl * f, wl * f), dtype=z.dtype, device=dev)
-            _lib.check(L.gyre_vae_decode(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(z.data_ptr()),
-                                         _lib.dtype_code(z), B, hl, wl, C.c_void_p(wp), need,
-                                         C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
-        return SimpleNamespace(sample=out) if return_dict else (out,)
+            if d_img is None:
+                _lib.check(L.gyre_vae_decode(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(z.data_ptr()),
+                                             _lib.dtype_code(z), B, hl, wl, C.c_void_p(wp), need,
+                                             C.c_void_p(out.data_ptr()), _lib.dtype_code(out)))
+                return out
+            g = d_img.contiguous()
+            _lib.require_gpu_tensor(g, "d_image")
+            dz = torch.empty_like(z)
+            _lib.check(L.gyre_vae_decode_vjp(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(z.data_ptr()),
+                                             _lib.dtype_code(z), B, hl, wl, C.c_void_p(g.data_ptr()), _lib.dtype_code(g),
+                                             C.c_void_p(wp), need, C.c_void_p(out.data_ptr()), _lib.dtype_code(out),
+                                             C.c_void_p(dz.data_ptr()), _lib.dtype_code(dz)))
+            return out, dz
+
+
+class _VAEDecodeInputGrad(torch.autograd.Function):
+    """autograd node of GyreHipVAE.decode: backward = gyre_vae_decode_vjp (gradient of the latents only)."""
+
+    @staticmethod
+    def forward(fctx, z, module, h):
+        fctx.module, fctx.h = module, h
+        fctx.save_for_backward(z.detach())
+        return module._decode_native(h, z.detach(), None)
+
+    @staticmethod
+    def backward(fctx, d_img):
+        (z,) = fctx.saved_tensors
+        _, dz = fctx.module._decode_native(fctx.h, z, d_img)
+        return dz, None, None

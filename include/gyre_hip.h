@@ -137,6 +137,18 @@ int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_d
  * algorithm lives in the un-vendored facebookresearch/ToMe submodule; restated from the paper, parity unpinned. */
 int gyre_unet_set_tome(gyre_unet* h, int r);
 
+/* Input gradient (vector-Jacobian product) of the noise prediction: one call runs the forward pass, writes
+ * eps_out_nchw like gyre_unet_forward, and writes dx_out_nchw[B, in_channels, H, W] = (d eps / d x)^T d_eps.
+ * Replaces what autograd does in the reference's CLIP-guided mode, gyre/pipeline/unet/clipguided.py:301-338
+ * (`latents.requires_grad_()`, `unet(latents, t)`) + :420 (`torch.autograd.grad(loss, latents)`); weights and the
+ * text context receive no gradient there.  ctx must be passed (the K/V cache is not used); temb_add as in
+ * gyre_unet_forward_ex (may be NULL).  GYRE_ERR_UNSUPPORTED while token merging is enabled. */
+size_t gyre_unet_vjp_workspace_bytes(gyre_unet* h, int B, int H, int W, int S);
+int gyre_unet_vjp(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
+                  const void* ctx, int ctx_dtype, int B, int H, int W, int S,
+                  const void* d_eps_nchw, int d_eps_dtype, void* workspace, size_t workspace_bytes,
+                  void* eps_out_nchw, int out_dtype, void* dx_out_nchw, int dx_dtype, const float* temb_add);
+
 /* Parity tests only: the next forward copies the named intermediate activation (f32, NCHW) into out.  Names follow
  * the oracle's taps: "down<i>" (end of down level i, after its downsampler), "mid", "up<i>" (end of up level i, after
  * its upsampler).  Taps are cleared by that forward. */
@@ -243,6 +255,32 @@ int gyre_op_attention_ex(void* stream, const void* q, int ldq, const void* k, in
 /* ToMe merge of one self-attention's keys / values: k[B,N,ldk], v[B,N,ldv] (bf16 rows of C channels) ->
  * k_out[B,N-r,C], vt_out[B,C,ldvt] (values transposed, columns >= N-r zero); optional order_out / node_idx_out [B,N/2]
  * (int32, dev) receive the a-token ranking and every a token's best match.  r is clipped to N / 2. */
+/* Input gradient of gyre_vae_decode (clipguided.py:366-386 decodes latent cut-outs under autograd): writes the decoded
+ * image and d_z = (d image / d z)^T d_image. */
+size_t gyre_vae_decode_vjp_workspace_bytes(gyre_vae* h, int B, int h_lat, int w_lat);
+int gyre_vae_decode_vjp(gyre_vae* h, void* stream, const void* z_nchw, int z_dtype, int B, int h_lat, int w_lat,
+                        const void* d_image_nchw, int d_dtype, void* workspace, size_t workspace_bytes,
+                        void* image_out_nchw, int out_dtype, void* dz_out_nchw, int dz_dtype);
+
+/* ---- input-gradient kernels, exposed for the parity tests (tests/test_gpu_vjp.py); activations / gradients bf16 ----
+ * groupnorm_bwd: x (|| x2) is the forward INPUT, dy[B,HW,C] the gradient of the (activated) output; dx[B,HW,C1],
+ *   dx2[B,HW,C-C1]; addend (optional, [B,HW,C1]) is added to dx.
+ * layernorm_bwd: same for rows of [M,C].  geglu_bwd: pre[M,2F] in the packed column order of
+ *   gyre_op_repack_linear_weight(geglu=1), dy[M,F], dpre[M,2F].
+ * attention_bwd: q/k/v/o/d_o row-major [B,N,ld] with head h at column h*D (v is NOT transposed here); dk == NULL
+ *   computes dq only (cross-attention). */
+size_t gyre_op_groupnorm_bwd_workspace(int B, int HW, int C, int groups);
+int gyre_op_groupnorm_bwd(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
+                          const float* gamma, const float* beta, float eps, int silu, const void* dy, const void* addend,
+                          void* workspace, size_t workspace_bytes, void* dx, void* dx2);
+int gyre_op_layernorm_bwd(void* stream, const void* x, const void* dy, int M, int C, const float* gamma, float eps,
+                          const void* addend, void* dx);
+int gyre_op_geglu_bwd(void* stream, const void* pre, const void* dy, int M, int F, void* dpre);
+size_t gyre_op_attention_bwd_workspace(int B, int heads, int Nq, int Nk, int D);
+int gyre_op_attention_bwd(void* stream, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                          const void* o, int ldo, const void* d_o, int lddo, int B, int heads, int Nq, int Nk, int D,
+                          int k_prescaled, void* workspace, size_t workspace_bytes, void* dq, int lddq, void* dk, int lddk,
+                          void* dv, int lddv);
 size_t gyre_op_tome_workspace(int B, int N, int C);
 int gyre_op_tome_merge(void* stream, const void* k, int ldk, const void* v, int ldv, int B, int N, int C, int r,
                        void* workspace, size_t workspace_bytes, void* k_out, void* vt_out, int ldvt,
