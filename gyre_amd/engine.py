@@ -35,6 +35,7 @@ from typing import Any, Callable, List, Optional
 
 import torch
 
+from . import clipguided as CG
 from . import lora as LR
 from .pipeline import GyrePipeline
 from .text import LPWTextEmbedder
@@ -87,6 +88,7 @@ class GyreUnifiedPipeline:
         self._hires_oos_fraction, self._hires_image_oos_fraction = 0.6, 1.0
         self._text_embedding_layer = "final"
         self._tome = 0
+        self.clip_default_config = CG.ClipGuidanceConfig()
 
     # ---- what PipelineWrapper / DiffusionPipelineWrapper touch -----------------------------------------------------------
     def pipeline_modules(self):
@@ -139,7 +141,24 @@ class GyreUnifiedPipeline:
                 self._text_embedding_layer = "penultimate" if value else "final"
             elif key in ("xformers", "vae_tiling", "structured_diffusion"):
                 pass                                       # memory knobs / deprecated: accepted, nothing to do
-            elif key in ("grafted_depth", "clip"):
+            elif key == "clip":                            # unified_pipeline.py:1591-1623
+                cfg = self.clip_default_config
+                for sk, sv in (value or {}).items():
+                    if sk in ("unet_grad", "vae_grad"):
+                        pass                               # native weights never receive gradients; only the sample does
+                    elif sk in ("vae_cutouts", "approx_cutouts", "gradient_length"):
+                        setattr(cfg, sk, int(sv))
+                    elif sk == "no_cutouts":
+                        cfg.no_cutouts = bool(sv)
+                    elif sk in ("guidance_scale", "gradient_threshold", "gradient_maxloss"):
+                        setattr(cfg, sk, float(sv))
+                    elif sk == "guidance_base":
+                        if str(sv) not in ("guided", "mixed"):
+                            raise ValueError("Guidance base must be one of 'mixed' or 'guided'")
+                        cfg.guidance_base = str(sv)
+                    else:
+                        raise ValueError(f"Unknown option {sk}: {sv} passed as part of clip settings")
+            elif key == "grafted_depth":
                 if value:
                     raise NotImplementedError(f"option {key!r} is outside the native hot path")
             else:
@@ -181,6 +200,60 @@ class GyreUnifiedPipeline:
         rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
         return rep(cond), rep(unc)
 
+    # ---- CLIP guidance request (unified_pipeline.py:1876-1909, 1927-1940, 2373-2395) ----------------------------------------
+    def _clip_request(self, prompt, clip_prompt, B, num_images_per_prompt, scale, base, glen, gthr, gmax, vae_cutouts,
+                      approx_cutouts, no_cutouts) -> dict:
+        if scale is not None and self.clip_model is None:
+            print("Warning: CLIP guidance passed to a pipeline without a CLIP model. It will be ignored.")
+            scale = None
+        if not scale:
+            return {}
+        import copy
+        cfg = copy.copy(self.clip_default_config)
+        cfg.guidance_scale = scale
+        if base is not None:
+            cfg.guidance_base = base
+        if glen is not None:
+            cfg.gradient_length = glen
+        if gthr is not None:
+            cfg.gradient_threshold = gthr
+        if gmax is not None:
+            cfg.gradient_maxloss = gmax
+        if vae_cutouts is not None:
+            cfg.vae_cutouts = vae_cutouts
+        if approx_cutouts is not None:
+            cfg.guidance_scale = approx_cutouts      # sic: the reference assigns approx_cutouts to guidance_scale (:1899-1900)
+        if no_cutouts is not None:
+            cfg.no_cutouts = no_cutouts
+
+        def texts(p):
+            if hasattr(p, "as_unweighted_string"):
+                t = p.as_unweighted_string()
+                return t if isinstance(t, list) else [t]
+            items = p if isinstance(p, (list, tuple)) else [p]
+            return [q.as_unweighted_string() if hasattr(q, "as_unweighted_string") else
+                    (q if isinstance(q, str) else " ".join(f[0] for f in q)) for q in items]
+        strings = texts(clip_prompt if clip_prompt is not None else prompt)
+        if len(strings) * num_images_per_prompt != B:
+            raise ValueError(f"clip_prompt has batch size {len(strings)}, but prompt has batch size {B // num_images_per_prompt}. "
+                             "They need to match.")
+        tok = self.clip_tokenizer if self.clip_tokenizer is not None else self.tokenizer
+        te_cfg = getattr(self.text_encoder, "config", None)
+        max_pos = getattr(te_cfg, "max_position_embeddings", 77)
+        if hasattr(tok, "model_max_length"):
+            ids = tok(strings, padding="max_length", max_length=min(tok.model_max_length, max_pos), truncation=True,
+                      return_tensors="pt").input_ids
+        else:                                       # bare callable tokenizer (tests): BOS + tokens + EOS, padded with EOS
+            bos, eos = getattr(te_cfg, "bos_token_id", 49406), getattr(te_cfg, "eos_token_id", 49407)
+            rows = []
+            for s_ in strings:
+                body = list(tok(s_, add_special_tokens=False)["input_ids"])[:max_pos - 2]
+                rows.append([bos] + body + [eos] * (max_pos - 1 - len(body)))
+            ids = torch.tensor(rows, dtype=torch.long)
+        feats = CG._features(self.clip_model.get_text_features(ids.to(self.execution_device)))
+        return dict(clip_guidance_scale=scale, clip_config=cfg,
+                    clip_text_embeddings=feats.repeat_interleave(num_images_per_prompt, dim=0))
+
     # ---- the generation call (keywords of reference UnifiedPipeline.__call__, unified_pipeline.py:1722-1790) ---------------
     @torch.no_grad()
     def __call__(self, prompt, height: int = 512, width: int = 512, image=None, mask_image=None, outmask_image=None,
@@ -191,11 +264,12 @@ class GyreUnifiedPipeline:
                  sigma_max: Optional[float] = None, karras_rho: Optional[float] = None, scheduler_noise_type: str = "normal",
                  generator=None, latents=None, max_embeddings_multiples: int = 3, output_type: str = "pil",
                  return_dict: bool = True, callback=None, callback_steps: int = 1, clip_guidance_scale: Optional[float] = None,
-                 clip_guidance_base: Optional[str] = None, clip_prompt=None, lora=None, token_embeddings=None,
+                 clip_guidance_base: Optional[str] = None, clip_gradient_length: Optional[int] = None,
+                 clip_gradient_threshold: Optional[float] = None, clip_gradient_maxloss: Optional[float] = None,
+                 clip_prompt=None, vae_cutouts: Optional[int] = None, approx_cutouts: Optional[int] = None, no_cutouts=False,
+                 lora=None, token_embeddings=None,
                  hires_fix=None, hires_oos_fraction=None, tiling=False, debug_latent_tags=None, debug_latent_prefix="",
                  cfg_execution: str = "parallel"):
-        if clip_guidance_scale:
-            raise NotImplementedError("CLIP guidance needs backward kernels: outside the native hot path")
         if depth_map is not None or hint_images:
             raise NotImplementedError("depth / hint conditioning (ControlNet, T2I adapters) is outside the native hot path")
         if token_embeddings:
@@ -224,7 +298,11 @@ class GyreUnifiedPipeline:
             strength = 0.8
         dev = self.execution_device
         pipe = GyrePipeline(self.unet, self.vae, None, device=dev, inpaint_unet=self.inpaint_unet,
-                            grafted_inpaint=self._grafted_inpaint)
+                            grafted_inpaint=self._grafted_inpaint, clip_model=self.clip_model,
+                            feature_extractor=self.feature_extractor)
+        clip_kw = self._clip_request(prompt, clip_prompt, B, num_images_per_prompt, clip_guidance_scale, clip_guidance_base,
+                                     clip_gradient_length, clip_gradient_threshold, clip_gradient_maxloss, vae_cutouts,
+                                     approx_cutouts, no_cutouts)
         pipe.hires_fix, pipe.hires_threshold_fraction = self._hires_fix, self._hires_threshold_fraction
         pipe.hires_oos_fraction, pipe.hires_image_oos_fraction = self._hires_oos_fraction, self._hires_image_oos_fraction
         for u in (self.unet, self.inpaint_unet):
@@ -261,7 +339,7 @@ class GyreUnifiedPipeline:
                       hires_fix=hires_fix, hires_oos_fraction=hires_oos_fraction, outmask_image=to_dev(outmask_image),
                       prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
                       churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
-                      sigma_max=sigma_max)
+                      sigma_max=sigma_max, **clip_kw)
         images = images.float().cpu()                       # reference: result_image.cpu() ... BCHW 0..1 (:2512-2531)
         nsfw: List[bool] = [False] * images.shape[0]       # tests / engines run with nsfw_behaviour "ignore"
         if output_type == "pil":

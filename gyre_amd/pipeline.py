@@ -10,6 +10,7 @@ Host orchestration restating the reference's ``UnifiedPipeline.__call__``
   strength >= 1 "shaped noise" fill (noise_mode 5)    unified_pipeline.py:402-417, 466-607
   Hires fix (mode tree of a natural-size and a full-size leaf)   unified_pipeline.py:1064-1200, 2100-2181
   Grafted inpaint (inpaint_unet + unet blended by GraftUnets)    unified_pipeline.py:2071-2100, unet/graft.py:16-56
+  CLIP guidance (ClipGuidedMode around every leaf)               unified_pipeline.py:2373-2406, unet/clipguided.py
 
 Call stack per SURVEY.md 3.2/3.3: embeddings -> UNetWithEmbeddings -> (UnetWithExtraChannels)
 -> CFGUNet_Parallel -> KDiffusionUNetWrapper -> sampler loop -> vae.decode(latents / 0.18215)
@@ -27,6 +28,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
+from . import clipguided as CG
 from . import hires as H
 from . import images as I
 from . import schedulers as S
@@ -116,12 +118,18 @@ class GyrePipeline:
     hires_image_oos_fraction = 1.0
 
     def __init__(self, unet, vae, text_encoder: Optional[Callable] = None, device="cuda:0", inpaint_unet=None,
-                 grafted_inpaint=False):
+                 grafted_inpaint=False, clip_model=None, feature_extractor=None):
         """inpaint_unet: optional 9-channel (runway) UNet used whenever a mask is given (reference
         unified_pipeline.py:1352,2058-2062).  grafted_inpaint: True or a blend dict {floor, start, end, easing}: masked
         requests then run BOTH UNets and GraftUnets hands over from the inpaint UNet to `unet` (reference option
-        "grafted_inpaint", unified_pipeline.py:1543, 2082-2098)."""
+        "grafted_inpaint", unified_pipeline.py:1543, 2082-2098).
+        clip_model / feature_extractor: the CLIP model (``get_image_features`` / ``get_text_features``, host PyTorch)
+        and its preprocessing constants (``image_mean``, ``image_std``, ``size``) for CLIP guidance (reference
+        unified_pipeline.py:1347-1349, 1407-1411); without them ``clip_guidance_scale`` is ignored with a warning, as the
+        reference does (:1877-1881)."""
         self.unet, self.vae, self.text_encoder = unet, vae, text_encoder
+        self.clip_model, self.feature_extractor = clip_model, feature_extractor
+        self.clip_default_config = CG.ClipGuidanceConfig()
         self.inpaint_unet, self.grafted_inpaint = inpaint_unet, grafted_inpaint
         self.device = torch.device(device)
         # the reference hard-codes SD1.x's 0.18215 (unified_pipeline.py:319,2488); SDXL's VAE uses 0.13025
@@ -234,7 +242,7 @@ class GyrePipeline:
             leaf.blend_orig, leaf.blend_mask = orig, leaf.latent_mask
 
     def _bind_leaf(self, leaf, *, text_embeddings, uncond_embeddings, guidance_scale, cfg_execution, B, added_cond,
-                   uncond_added_cond, cfg_embeddings):
+                   uncond_added_cond, cfg_embeddings, clip_mode=None):
         """UNet stack of one leaf: embeddings -> extra channels -> CFG (unified_pipeline.py:2235-2337, 2408-2430)."""
         def bind(emb, added=None):
             u = S.UNetWithEmbeddings(leaf.unet, emb, added)
@@ -255,6 +263,12 @@ class GyrePipeline:
                 leaf.eps_unet = S.CFGUNet_Parallel(bind(cfg_embeddings["both"], both), guidance_scale, B)
         else:
             leaf.eps_unet = bind(text_embeddings, added_cond)
+        leaf.clip_mode = clip_mode
+        if clip_mode is not None:       # ClipGuidedMode.wrap_guidance_unet over the conditional / unconditional stems
+            cfg = guidance_scale > 1.0
+            leaf.eps_unet = clip_mode.wrap_guidance_unet(bind(text_embeddings, added_cond),
+                                                         bind(uncond_embeddings, uncond_added_cond) if cfg else None,
+                                                         leaf.eps_unet, guidance_scale)
 
     def _generate_leaf_latents(self, leaf, sched, generators, fill_strength):
         """Mode.generateLatents: txt2img noise, or (init sample, optional shaped-noise fill, noise) for an init image."""
@@ -283,7 +297,14 @@ class GyrePipeline:
                  outmask_image: Optional[Tensor] = None, added_cond: Optional[dict] = None,
                  uncond_added_cond: Optional[dict] = None, prediction_type: str = "epsilon",
                  churn: Optional[float] = None, churn_tmin: float = 0.0, churn_tmax: float = float("inf"),
-                 sigma_min: Optional[float] = None, sigma_max: Optional[float] = None):
+                 sigma_min: Optional[float] = None, sigma_max: Optional[float] = None,
+                 clip_guidance_scale: Optional[float] = None, clip_guidance_base: Optional[str] = None,
+                 clip_gradient_length: Optional[int] = None, clip_gradient_threshold: Optional[float] = None,
+                 clip_gradient_maxloss: Optional[float] = None, vae_cutouts: Optional[int] = None,
+                 approx_cutouts: Optional[int] = None, no_cutouts=None, clip_input_ids: Optional[Tensor] = None,
+                 clip_text_embeddings: Optional[Tensor] = None, clip_config: Optional[CG.ClipGuidanceConfig] = None):
+        """clip_*: CLIP guidance (reference keywords of UnifiedPipeline.__call__, unified_pipeline.py:1756-1764).  The text
+        side comes as ``clip_input_ids`` (encoded by clip_model.get_text_features) or ``clip_text_embeddings`` [B, D]."""
         if height % self.vae_scale_factor or width % self.vae_scale_factor:
             raise ValueError(f"`height` and `width` have to be divisible by {self.vae_scale_factor} "
                              f"but are {height} and {width}.")
@@ -344,6 +365,38 @@ class GyrePipeline:
         sched = S.make_scheduler(sampler, generators, dev, torch.float32)
         is_k = isinstance(sched, S.KDiffusionScheduler)
 
+        # ---- CLIP guidance configuration (unified_pipeline.py:1876-1909, 2373-2395) ----
+        if clip_guidance_scale is not None and (self.clip_model is None or self.feature_extractor is None):
+            print("Warning: CLIP guidance passed to a pipeline without a CLIP model. It will be ignored.")
+            clip_guidance_scale = None
+        if not clip_guidance_scale:
+            clip_config = None
+        if clip_guidance_scale:
+            import copy
+            if clip_config is None:                  # (an engine adapter hands over its resolved configuration instead)
+                clip_config = copy.copy(self.clip_default_config)
+                clip_config.guidance_scale = clip_guidance_scale
+            for name, val in (("guidance_base", clip_guidance_base), ("gradient_length", clip_gradient_length),
+                              ("gradient_threshold", clip_gradient_threshold), ("gradient_maxloss", clip_gradient_maxloss),
+                              ("vae_cutouts", vae_cutouts), ("approx_cutouts", approx_cutouts), ("no_cutouts", no_cutouts)):
+                if val is not None:
+                    setattr(clip_config, name, val)
+            if clip_config.guidance_base not in ("guided", "mixed"):
+                raise ValueError(f"clip_guidance_base must be 'guided' or 'mixed', got {clip_config.guidance_base!r}")
+            if not is_k and prediction_type == "v_prediction":
+                raise ValueError("Can't use Diffusers scheduler with a v-prediction unet and CLIP guidance. "
+                                 "Either use a K-Diffusion scheduler or don't use CLIP guidance.")
+            if clip_text_embeddings is None:
+                if clip_input_ids is None:
+                    raise ValueError("CLIP guidance needs clip_input_ids or clip_text_embeddings")
+                clip_text_embeddings = CG._features(self.clip_model.get_text_features(clip_input_ids.to(dev)))
+            clip_text_embeddings = clip_text_embeddings.to(dev, torch.float32)
+            clip_text_embeddings = clip_text_embeddings / clip_text_embeddings.norm(p=2, dim=-1, keepdim=True)
+            if clip_text_embeddings.shape[0] == 1 and B > 1:
+                clip_text_embeddings = clip_text_embeddings.expand(B, -1)
+            if clip_text_embeddings.shape[0] != B:
+                raise ValueError(f"clip prompt batch {clip_text_embeddings.shape[0]} != number of seeds {B}")
+
         # ---- mode tree (unified_pipeline.py:2054-2181) --------------------------------------------------------
         main_unet = self.inpaint_unet if (mask_image is not None and self.inpaint_unet is not None) else self.unet
         tree = self._Leaf(unet=main_unet, enhanced=False, height=height, width=width, image=image, mask_image=mask_image)
@@ -381,9 +434,18 @@ class GyrePipeline:
             self._construct_leaf(leaf, generators, B)
         shared = {}
         for leaf in leaves:
+            clip_mode = None
+            if clip_config is not None:          # one ClipGuidedMode per leaf (:2396-2406), all on the same generators
+                fe = self.feature_extractor
+                size = fe.size["shortest_edge"] if isinstance(fe.size, dict) else fe.size
+                clip_mode = CG.ClipGuidedMode(scheduler=sched, clip_model=self.clip_model, image_mean=fe.image_mean,
+                                              image_std=fe.image_std, clip_size=size,
+                                              vae_decode=lambda z: self.vae.decode(z).sample,
+                                              vae_scale_factor=self.vae_scale_factor, text_embeddings_clip=clip_text_embeddings,
+                                              config=clip_config, generators=generators, latent_scale=self.latent_scale)
             self._bind_leaf(leaf, text_embeddings=text_embeddings, uncond_embeddings=uncond_embeddings,
                             guidance_scale=guidance_scale, cfg_execution=cfg_execution, B=B, added_cond=added_cond,
-                            uncond_added_cond=uncond_added_cond, cfg_embeddings=shared)
+                            uncond_added_cond=uncond_added_cond, cfg_embeddings=shared, clip_mode=clip_mode)
         sched.set_eps_unets([l.eps_unet for l in leaves])
         sched.set_timesteps(num_inference_steps, strength=strength if image is not None else None,
                             config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho, churn=churn, churn_tmin=churn_tmin,
@@ -411,6 +473,10 @@ class GyrePipeline:
                                    _blend(leaf.blend_mask, u, sched.add_noise_at(leaf.blend_orig, leaf.noise, t).to(x.dtype),
                                           inner(x, t)))(inner, leaf)
 
+        for leaf in leaves:                                     # ClipGuidedMode.wrap_k_unet / wrap_d_unet (outermost)
+            if leaf.clip_mode is not None:
+                leaf.s_unet = leaf.clip_mode.wrap_k_unet(leaf.s_unet) if is_k else leaf.clip_mode.wrap_d_unet(leaf.s_unet)
+
         def collapse(t):
             if not isinstance(t, tuple):
                 return t.s_unet
@@ -430,7 +496,8 @@ class GyrePipeline:
 
         model = collapse(tree)
         latents = initial(tree)
-        plain = len(leaves) == 1 and leaves[0].blend_orig is None
+        plain = len(leaves) == 1 and leaves[0].blend_orig is None and (leaves[0].clip_mode is None or not is_k)
+        self.last_clip_modes = [l.clip_mode for l in leaves if l.clip_mode is not None]
         if is_k:
             latents = sched.loop(latents, callback=callback, k_model=None if plain else model)
         else:

@@ -71,6 +71,77 @@ def resize_lanczos2(x: torch.Tensor, scale: float) -> torch.Tensor:
     return y.to(x.dtype)
 
 
+def cubic(x: torch.Tensor) -> torch.Tensor:
+    """Keys cubic convolution kernel (a = -0.5), support 4 - ResizeRight's default interpolation method."""
+    ax = x.abs()
+    ax2, ax3 = ax * ax, ax * ax * ax
+    return (1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((1 < ax) & (ax <= 2))
+
+
+@lru_cache(maxsize=256)
+def _weight_matrix_general(in_size: int, out_size: int, scale: float, method: str, antialiasing: bool,
+                           pad_mode: str) -> torch.Tensor:
+    """[out_size, in_size] float64 matrix of ResizeRight's 1-D resampling for one axis (same published algorithm as
+    _weight_matrix, with the pieces the CLIP cut-outs use: an explicit output size, the antialiasing stretch of the kernel
+    when downscaling - kernel(x) -> scale * kernel(scale * x), support / scale - and reflect / constant / replicate
+    boundary handling folded into the matrix)."""
+    kernel, support = {"cubic": (cubic, 4.0), "lanczos2": (lanczos2, 4.0)}[method]
+    if scale < 1 and antialiasing:
+        base, k_support = kernel, support / scale
+        kern = lambda a: scale * base(scale * a)
+    else:
+        kern, k_support = kernel, support
+    i = torch.arange(out_size, dtype=torch.float64)
+    proj = i / scale + (in_size - 1) / 2 - (out_size - 1) / (2 * scale)
+    left = torch.ceil(proj - k_support / 2 - _EPS).to(torch.int64)
+    ntaps = int(math.ceil(k_support - _EPS))
+    taps = left[:, None] + torch.arange(ntaps)[None, :]
+    w = kern(proj[:, None] - taps.to(torch.float64))
+    s_ = w.sum(dim=1, keepdim=True)
+    s_[s_ == 0] = 1
+    w = w / s_
+    m = torch.zeros(out_size, in_size, dtype=torch.float64)
+    if pad_mode == "replicate":
+        m.scatter_add_(1, taps.clamp(0, in_size - 1), w)
+    elif pad_mode == "reflect":                       # torch 'reflect': mirror without repeating the edge sample
+        if int(taps.min()) < -(in_size - 1) or int(taps.max()) > 2 * (in_size - 1):
+            raise ValueError("reflect padding needs the padding to be smaller than the input")
+        idx = taps.abs()
+        idx = torch.where(idx > in_size - 1, 2 * (in_size - 1) - idx, idx)
+        m.scatter_add_(1, idx, w)
+    elif pad_mode == "constant":                      # zeros outside
+        inside = (taps >= 0) & (taps < in_size)
+        m.scatter_add_(1, taps.clamp(0, in_size - 1), w * inside)
+    else:
+        raise ValueError(f"pad_mode {pad_mode!r}")
+    return m
+
+
+def resize_right(x: torch.Tensor, out_shape=None, scale_factors=None, interp_method: str = "cubic",
+                 antialiasing: bool = True, pad_mode: str = "constant") -> torch.Tensor:
+    """``resize_right.resize(x, scale_factors=None, out_shape=(h, w), pad_mode=...)`` on the last two axes - the call
+    the reference makes for its CLIP cut-outs (gyre/pipeline/unet/clipguided.py:81-83, 362-364).  Differentiable (two
+    matrix products per sample); un-vendored upstream, *parity unpinned* like resize_lanczos2."""
+    h, w = x.shape[-2], x.shape[-1]
+    if out_shape is not None:
+        oh, ow = int(out_shape[-2]), int(out_shape[-1])
+        sh, sw = oh / h, ow / w
+    elif scale_factors is not None:
+        sh = sw = float(scale_factors)
+        oh, ow = int(math.ceil(h * sh)), int(math.ceil(w * sw))
+    else:
+        raise ValueError("pass out_shape or scale_factors")
+    mh = _weight_matrix_general(h, oh, float(sh), interp_method, bool(antialiasing), pad_mode).to(x.device, torch.float32)
+    mwt = _weight_matrix_general(w, ow, float(sw), interp_method, bool(antialiasing), pad_mode).to(x.device, torch.float32).t().contiguous()
+    xf = x.to(torch.float32)
+    if xf.ndim < 4:
+        return torch.matmul(torch.matmul(mh, xf), mwt).to(x.dtype)
+    lead = xf.shape[:-3]
+    xs = xf.reshape((-1,) + tuple(xf.shape[-3:]))
+    ys = [torch.matmul(torch.matmul(mh, s_), mwt) for s_ in xs]
+    return torch.stack(ys).reshape(lead + ys[0].shape).to(x.dtype)
+
+
 def resize_nearest(x: torch.Tensor, scale: float) -> torch.Tensor:
     hs, ws = int(x.shape[-2] * scale), int(x.shape[-1] * scale)
     return torch.nn.functional.interpolate(x, size=(hs, ws), mode="nearest")

@@ -77,7 +77,18 @@ def build_pipeline():
 
     sched = SimpleNamespace(config=AttrDict(prediction_type="epsilon", steps_offset=1, beta_start=0.00085, beta_end=0.012,
                                             beta_schedule="scaled_linear", num_train_timesteps=1000))
-    return GyreUnifiedPipeline(vae=VAE(), text_encoder=te, tokenizer=tokenizer, unet=UNet(), scheduler=sched)
+    from transformers import CLIPConfig, CLIPModel
+    clip = CLIPModel(CLIPConfig(text_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                                                 vocab_size=49408, max_position_embeddings=77, bos_token_id=49406,
+                                                 eos_token_id=49407),
+                                vision_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                                                   num_attention_heads=2, image_size=32, patch_size=8),
+                                projection_dim=16)).eval()
+    for p_ in clip.parameters():
+        p_.requires_grad_(False)
+    fe = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711], size=32)
+    return GyreUnifiedPipeline(vae=VAE(), text_encoder=te, tokenizer=tokenizer, unet=UNet(), scheduler=sched,
+                               clip_model=clip, feature_extractor=fe)
 
 
 def main():
@@ -120,12 +131,16 @@ def main():
     ev = threading.Event()
     ev.set()
     out["l1_cancelled"] = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, stop_event=ev, **kw) is None
+    # CLIP guidance through the reference's wrapper: the keyword reaches the native engine and changes the images
+    plain, _ = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, **kw)
+    guided, _ = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, clip_guidance_scale=0.3, **kw)
+    out["l1_clip_guidance"] = [list(guided.shape), float((guided - plain).abs().max()) > 1e-3, bool(torch.isfinite(guided).all())]
     # unsupported feature -> NotImplementedError (mapped to gRPC UNIMPLEMENTED by the reference)
     try:
-        wrapper(sampler=generation_pb2.SAMPLER_K_EULER, clip_guidance_scale=1.0, **kw)
-        out["l1_clip_guidance"] = "no error"
+        wrapper(sampler=generation_pb2.SAMPLER_K_EULER, tiling=True, **kw)
+        out["l1_unsupported"] = "no error"
     except NotImplementedError:
-        out["l1_clip_guidance"] = "NotImplementedError"
+        out["l1_unsupported"] = "NotImplementedError"
 
     # ---- level 2: the gRPC servicer ------------------------------------------------------------------------------------
     try:

@@ -38,7 +38,8 @@ def test_reference_wrapper_and_grpc_servicer_run_over_the_native_engine_class():
     assert out["l1_sampler_seen"] == "dpmpp_2m"                          # SAMPLER_K_DPMPP_2M -> the in-tree sample_dpmpp_2m partial
     assert out["l1_equals_direct"]                                       # same tensors as calling the host pipeline directly
     assert out["l1_ddim_img2img"] == [[2, 3, 128, 128], "ddim"]
-    assert out["l1_cancelled"] and out["l1_clip_guidance"] == "NotImplementedError"
+    assert out["l1_cancelled"] and out["l1_unsupported"] == "NotImplementedError"
+    assert out["l1_clip_guidance"] == [[2, 3, 128, 128], True, True]   # clip_guidance_scale reaches the native engine (a16)
     # level 2: the reference's gRPC servicer
     assert "l2_error" not in out, out.get("l2_trace")
     assert out["l2_artifacts"] == 2 and out["l2_png"] and out["l2_seeds"] == [420420420, 420420421]
