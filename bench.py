@@ -117,13 +117,15 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (weak) / per request (strong)")
     ap.add_argument("--inference-steps", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
-    ap.add_argument("--config", choices=["sd15", "sdxl", "inpaint768"], default="sd15")
+    ap.add_argument("--config", choices=["sd15", "sdxl", "inpaint768", "tomeclip"], default="sd15")
+    ap.add_argument("--tome-r", type=int, default=1024, help="tomeclip: keys / values merged per self-attention (clipped to N/2)")
+    ap.add_argument("--clip-scale", type=float, default=0.2, help="tomeclip: clip_guidance_scale")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class-table", action="store_true", help="skip the extra instrumented step after the timed region")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class INSIDE the timed region (adds event overhead)")
     args = ap.parse_args()
-    defaults = {"sd15": (8, 50, 512), "sdxl": (2, 30, 1024), "inpaint768": (4, 50, 768)}[args.config]
+    defaults = {"sd15": (8, 50, 512), "sdxl": (2, 30, 1024), "inpaint768": (4, 50, 768), "tomeclip": (8, 50, 512)}[args.config]
     B = args.batch or defaults[0]
     n_steps = args.inference_steps or defaults[1]
     size = args.size or defaults[2]
@@ -158,7 +160,22 @@ def main():
         inpaint = GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(torch.bfloat16).to(dev)
         fill_synthetic_on_device(inpaint, 3)
     clip = None if args.config == "sdxl" else ClipTextEncoder.synthetic(dev, torch.bfloat16, seed=2)
-    pipe = GyrePipeline(unet, vae, clip, device=dev, inpaint_unet=inpaint, grafted_inpaint=inpaint is not None)
+    clip_model = fe = None
+    if args.config == "tomeclip":
+        # BASELINE configs[4]: ToMe + CLIP guidance.  The CLIP model is host PyTorch by north_star: a random-init ViT-B/32
+        # (transformers' default CLIPConfig sizes, 224 px) - no checkpoint exists offline
+        from types import SimpleNamespace
+        from transformers import CLIPConfig, CLIPModel
+        from gyre_amd.clipguided import patch_embedding_as_matmul
+        torch.manual_seed(7)
+        clip_model = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(dev))
+        for p_ in clip_model.parameters():
+            p_.requires_grad_(False)
+        fe = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711],
+                             size={"shortest_edge": 224})
+        unet.set_tome(args.tome_r)
+    pipe = GyrePipeline(unet, vae, clip, device=dev, inpaint_unet=inpaint, grafted_inpaint=inpaint is not None,
+                        clip_model=clip_model, feature_extractor=fe)
 
     # strong scaling: one request of B images over the ranks; weak: B images on every rank
     if args.scaling == "strong":
@@ -180,6 +197,10 @@ def main():
     else:
         ids = synthetic_prompt_ids(B, seed=1234 + pr).to(dev)
         neg = empty_prompt_ids(B).to(dev)
+    if args.config == "tomeclip":
+        # gradient_threshold 0: the flat-loss stop never triggers, every step of every request is guided (worst case)
+        extra = dict(clip_guidance_scale=args.clip_scale, clip_input_ids=synthetic_prompt_ids(B, seed=99 + pr).to(dev)[lo:hi],
+                     clip_gradient_threshold=0.0)
     if args.config == "inpaint768":
         yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
         init = torch.stack([yy, xx, (yy + xx) / 2])[None].to(dev)
@@ -274,8 +295,9 @@ def main():
                     "share_of_step_time": round(d["ms"] * 1e-3 / elapsed, 4)}
         per_img = {"sd15": evals * 2 * UNET_TFLOP_PER_SAMPLE * (size / 512) ** 2 + VAE_DEC_TFLOP * (size / 512) ** 2}.get(args.config)
         out = {
-            "metric": "SD1.5 512px 50-step images/sec (node)" if args.config == "sd15" else
-                      ("SDXL-base 1024px 30-step images/sec (node)" if args.config == "sdxl" else "SD1.5 grafted inpaint 768px images/sec (node)"),
+            "metric": {"sd15": "SD1.5 512px 50-step images/sec (node)", "sdxl": "SDXL-base 1024px 30-step images/sec (node)",
+                       "inpaint768": "SD1.5 grafted inpaint 768px images/sec (node)",
+                       "tomeclip": "SD1.5 512px 50-step ToMe + CLIP-guided images/sec (node)"}[args.config],
             "value": round(value, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
@@ -286,7 +308,10 @@ def main():
                 "sdxl": f"SDXL-base topology txt2img {size}x{size}, {n_steps} steps DPM++2M ({evals} UNet evals, CFG 5), batch={B} per "
                         f"{'request' if args.scaling == 'strong' else 'GPU'}, bf16, synthetic text embeddings (BASELINE.json configs[3]; not in the reference)",
                 "inpaint768": f"SD1.5 grafted inpaint {size}x{size} (9-ch inpaint UNet + base UNet, hires fix, VAE encode), {n_steps} steps "
-                              f"DPM++2M ({evals} UNet evals), batch={B}, bf16 (BASELINE.json configs[2])"}[args.config],
+                              f"DPM++2M ({evals} UNet evals), batch={B}, bf16 (BASELINE.json configs[2])",
+                "tomeclip": f"SD1.5 txt2img {size}x{size}, ToMe r={args.tome_r} + CLIP guidance (scale {args.clip_scale}, guided base, 2 + 2 "
+                            f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch), {n_steps} steps DPM++2M ({evals} UNet "
+                            f"evals incl. the differentiated stems), batch={B}, bf16 (BASELINE.json configs[4])"}[args.config],
                        "images_per_step": sum(sizes), "images_per_rank": sizes, "parallelism": f"dp{world}",
                        "weights": "random-init weights of the exact architecture (SD1.5: 859.5 M UNet, 83.7 M VAE, 123 M CLIP)"},
             "latency_p50_s": round(statistics.median(step_times), 4),

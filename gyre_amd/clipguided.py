@@ -101,6 +101,32 @@ def _features(out) -> Tensor:
     return out if isinstance(out, torch.Tensor) else out.pooler_output
 
 
+class PatchEmbedAsMatmul(torch.nn.Module):
+    """CLIP's patch embedding (a Conv2d with stride = kernel = patch size) as unfold + matmul: the same arithmetic without a
+    MIOpen convolution.  On ROCm the first backward-data call of that one convolution triggers MIOpen's kernel search
+    (minutes on a machine with a cold cache); the guidance gradient passes through it every step."""
+
+    def __init__(self, conv: torch.nn.Conv2d):
+        super().__init__()
+        self.weight, self.bias, self.p = conv.weight, conv.bias, conv.kernel_size[0]
+
+    def forward(self, x: Tensor) -> Tensor:
+        B, _, H, W = x.shape
+        cols = torch.nn.functional.unfold(x, self.p, stride=self.p)                       # [B, C*p*p, L]
+        out = self.weight.flatten(1).to(x.dtype) @ cols
+        if self.bias is not None:
+            out = out + self.bias.to(x.dtype)[None, :, None]
+        return out.view(B, -1, H // self.p, W // self.p)
+
+
+def patch_embedding_as_matmul(clip_model):
+    """In-place: swap a transformers CLIPModel's vision patch-embedding conv for PatchEmbedAsMatmul; returns the model."""
+    emb = clip_model.vision_model.embeddings
+    if isinstance(emb.patch_embedding, torch.nn.Conv2d):
+        emb.patch_embedding = PatchEmbedAsMatmul(emb.patch_embedding)
+    return clip_model
+
+
 def _resize_short_edge(x: Tensor, size: int) -> Tensor:
     """torchvision ``T.Resize(int)`` on a tensor: shorter edge to ``size``, bilinear (the no_cutouts branch, :351-358)."""
     h, w = x.shape[-2:]

@@ -146,7 +146,13 @@ struct TomeParams {
     void* ws; size_t ws_bytes;    // tome_workspace_bytes(B, N, C)
     int* order_out = nullptr;     // optional [B][N/2]: a-token indices by descending best-match score
     int* node_idx_out = nullptr;  // optional [B][N/2]: best b match of every a token
+    bf16_t* vrows_out = nullptr;  // optional [B][N - r][C]: merged values row-major (the backward pass reads rows)
+    int* dstlist_out = nullptr;   // optional [B][N/2]: entry k < r = b token the k-th ranked a token was merged into
 };
 size_t tome_workspace_bytes(int B, int N, int C);
 int tome_effective_r(int N, int r);       // min(r, N / 2), 0 when N < 2
 int launch_tome_merge(hipStream_t st, const TomeParams& p);
+// adjoint of the merge for one merged tensor: dy [B][N - r][C] -> dx [B][N][ldx] (every original token receives the gradient
+// of the row it went into, divided by that row's token count); order / dstlist from launch_tome_merge, inv: int scratch [B][N/2]
+int launch_tome_unmerge(hipStream_t st, const bf16_t* dy, int B, int N, int C, int r, const int* order, const int* dstlist,
+                        int* inv, bf16_t* dx, int ldx);

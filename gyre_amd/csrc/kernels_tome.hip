@@ -223,7 +223,7 @@ int launch_tome_merge(hipStream_t st, const TomeParams& p) {
     int* node_idx = (int*)w; w += al256((size_t)p.B * half * 4);
     int* order = (int*)w; w += al256((size_t)p.B * half * 4);
     int* dstlist = (int*)w; w += al256((size_t)p.B * half * 4);
-    bf16_t* vrows = (bf16_t*)w;
+    bf16_t* vrows = p.vrows_out ? p.vrows_out : (bf16_t*)w;
     {
         GyreProfScope prof_(KC_OTHER, st, 0, (double)p.B * p.N * p.C * 4.0);
         hipLaunchKernelGGL(k_tome_normalize_split, dim3((p.B * p.N + 3) / 4), dim3(256), 0, st, p.k, p.ldk, p.B, p.N, p.C, a, b);
@@ -259,5 +259,58 @@ int launch_tome_merge(hipStream_t st, const TomeParams& p) {
     GYRE_LAUNCH_CHECK();
     if (p.order_out) (void)hipMemcpyAsync(p.order_out, order, (size_t)p.B * half * 4, hipMemcpyDeviceToDevice, st);
     if (p.node_idx_out) (void)hipMemcpyAsync(p.node_idx_out, node_idx, (size_t)p.B * half * 4, hipMemcpyDeviceToDevice, st);
+    if (p.dstlist_out) (void)hipMemcpyAsync(p.dstlist_out, dstlist, (size_t)p.B * half * 4, hipMemcpyDeviceToDevice, st);
+    return 0;
+}
+
+// ---- adjoint of k_tome_merge_rows (input-gradient pass of the CLIP-guided mode; the matching itself carries no gradient) ----
+__global__ __launch_bounds__(256) void k_tome_inv_rank(const int* order, int B, int half, int* inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half;
+    inv[(size_t)b * half + order[i]] = i - b * half;
+}
+__global__ __launch_bounds__(256) void k_tome_unmerge_rows(const bf16_t* dy, int B, int N, int C, int r, const int* inv,
+                                                           const int* dstlist, bf16_t* dx, int ldx) {
+    const int half = N / 2, nu = half - r, nout = N - r;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * N) return;
+    const int b = row / N, n = row - b * N;
+    const int* dl = dstlist + (size_t)b * half;
+    int src, j = -1;                                      // source row of dy; j >= 0: a merged b-side row (divide by its count)
+    if (n >= 2 * half) src = nout - 1;                    // unpaired trailing token
+    else if (n & 1) { j = n >> 1; src = nu + j; }
+    else {
+        const int rank = inv[(size_t)b * half + (n >> 1)];
+        if (rank >= r) src = rank - r;
+        else { j = dl[rank]; src = nu + j; }
+    }
+    float w = 1.0f;
+    if (j >= 0) {
+        int cnt = 1;
+        for (int k0 = 0; k0 < r; k0 += 64) {
+            const int k = k0 + lane;
+            cnt += __popcll(__ballot(k < r && dl[k] == j));
+        }
+        w = 1.0f / (float)cnt;
+    }
+    const bf16_t* s = dy + ((size_t)b * nout + src) * C;
+    bf16_t* d = dx + ((size_t)b * N + n) * ldx;
+    for (int v = lane; v < C / 8; v += 64) {
+        float f[8];
+        unpack8(*(const uint4*)(s + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= w;
+        *(uint4*)(d + v * 8) = pack8(f);
+    }
+}
+int launch_tome_unmerge(hipStream_t st, const bf16_t* dy, int B, int N, int C, int r, const int* order, const int* dstlist,
+                        int* inv, bf16_t* dx, int ldx) {
+    const int half = N / 2;
+    if (C % 8 || ldx % 8 || r < 1 || r > half) GYRE_FAIL(-1, "tome_unmerge: C, ldx multiples of 8 and 1 <= r <= N / 2");
+    hipLaunchKernelGGL(k_tome_inv_rank, dim3((B * half + 255) / 256), dim3(256), 0, st, order, B, half, inv);
+    GYRE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tome_unmerge_rows, dim3((B * N + 3) / 4), dim3(256), 0, st, dy, B, N, C, r, inv, dstlist, dx, ldx);
+    GYRE_LAUNCH_CHECK();
     return 0;
 }

@@ -116,6 +116,8 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
         TRY(linear_bwd(e, dqkv.p, C, M, C, w.wq, C, nullptr, 0, d_xq.p, C));
     } else {
         const int W3 = w.qkv_fused ? 3 * C : 2 * C;     // Q | K (| V) in one row
+        const int tr = (e.tome_r > 0 && Nq % 16 == 0) ? tome_effective_r(Nq, e.tome_r) : 0;   // same rule as Exec::mha
+        if (tr > 0 && !w.qkv_fused) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "vjp: token merging needs the fused Q|K|V projection");
         TRY(e.alloc(qkv, B, xq.H, xq.W, W3));
         TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wqk, W3, w.qkv_fused ? nullptr : w.bqk, nullptr, 0, 0, qkv.p, W3));
         const bf16_t* vrows; int ldv;
@@ -129,15 +131,51 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
         TRY(e.alloc(dot, B, C, 1, ldqt));
         TRY(e.alloc(dqkv, B, xq.H, xq.W, W3));
         if (!w.qkv_fused) TRY(e.alloc(dv, B, xq.H, xq.W, C));
-        a.q = qkv.p; a.ldq = W3; a.k = e.dry() ? nullptr : qkv.p + C; a.ldk = W3; a.v = vrows; a.ldv = ldv;
-        a.qt = qt.p; a.d_ot = dot.p; a.ldqt = ldqt;
-        a.dq = dqkv.p; a.lddq = W3; a.dk = e.dry() ? nullptr : dqkv.p + C; a.lddk = W3;
-        a.dv = w.qkv_fused ? (e.dry() ? nullptr : dqkv.p + 2 * C) : dv.p; a.lddv = w.qkv_fused ? W3 : C;
-        if (!e.dry()) {
-            TRY(launch_transpose(e.st, qkv.p + C, W3, Nk, C, kt.p, ldkt, B, (size_t)Nk * W3, (size_t)C * ldkt));
-            TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
-            TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
-            TRY(launch_attention_bwd(e.st, a));
+        a.q = qkv.p; a.ldq = W3; a.qt = qt.p; a.d_ot = dot.p; a.ldqt = ldqt;
+        a.dq = dqkv.p; a.lddq = W3;
+        if (tr > 0) {
+            // ToMe (nonfree/tome_unet.py:138-182): keys / values are merged to N - r rows before the attention.  The matching
+            // is re-derived (deterministic), the attention adjoint runs against the merged rows, and the merge's adjoint
+            // spreads d K_merged / d V_merged back over the original tokens; indices carry no gradient.
+            const int nout = Nq - tr, half = Nq / 2, ldkm = (nout + 31) / 32 * 32, ldvt = (nout + 7) / 8 * 8;
+            Tn km, vm, vtm, tws, idx, dkm, dvm, ktm;
+            TRY(e.alloc(km, B, nout, 1, C));
+            TRY(e.alloc(vm, B, nout, 1, C));
+            TRY(e.alloc(vtm, B, C, 1, ldvt));
+            TRY(e.alloc_raw(tws, tome_workspace_bytes(B, Nq, C)));
+            TRY(e.alloc_raw(idx, (size_t)3 * B * half * 4 + 768));
+            TRY(e.alloc(ktm, B, C, 1, ldkm));
+            TRY(e.alloc(dkm, B, nout, 1, C));
+            TRY(e.alloc(dvm, B, nout, 1, C));
+            if (!e.dry()) {
+                int* order = (int*)idx.p;
+                int* dstl = order + (((size_t)B * half + 63) & ~(size_t)63);
+                int* inv = dstl + (((size_t)B * half + 63) & ~(size_t)63);
+                TomeParams tp;
+                tp.k = qkv.p + C; tp.ldk = W3; tp.v = qkv.p + 2 * C; tp.ldv = W3; tp.B = B; tp.N = Nq; tp.C = C; tp.r = tr;
+                tp.k_out = km.p; tp.vt_out = vtm.p; tp.ldvt = ldvt; tp.ws = tws.p; tp.ws_bytes = tws.bytes;
+                tp.vrows_out = vm.p; tp.order_out = order; tp.dstlist_out = dstl;
+                TRY(launch_tome_merge(e.st, tp));
+                a.k = km.p; a.ldk = C; a.v = vm.p; a.ldv = C; a.Nk = nout; a.kt = ktm.p; a.ldkt = ldkm;
+                a.dk = dkm.p; a.lddk = C; a.dv = dvm.p; a.lddv = C;
+                TRY(launch_transpose(e.st, km.p, C, nout, C, ktm.p, ldkm, B, (size_t)nout * C, (size_t)C * ldkm));
+                TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
+                TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                TRY(launch_attention_bwd(e.st, a));
+                TRY(launch_tome_unmerge(e.st, dkm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + C, W3));
+                TRY(launch_tome_unmerge(e.st, dvm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + 2 * C, W3));
+            }
+            e.free(km); e.free(vm); e.free(vtm); e.free(tws); e.free(idx); e.free(ktm); e.free(dkm); e.free(dvm);
+        } else {
+            a.k = e.dry() ? nullptr : qkv.p + C; a.ldk = W3; a.v = vrows; a.ldv = ldv;
+            a.dk = e.dry() ? nullptr : dqkv.p + C; a.lddk = W3;
+            a.dv = w.qkv_fused ? (e.dry() ? nullptr : dqkv.p + 2 * C) : dv.p; a.lddv = w.qkv_fused ? W3 : C;
+            if (!e.dry()) {
+                TRY(launch_transpose(e.st, qkv.p + C, W3, Nk, C, kt.p, ldkt, B, (size_t)Nk * W3, (size_t)C * ldkt));
+                TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
+                TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                TRY(launch_attention_bwd(e.st, a));
+            }
         }
         if (w.qkv_fused) {
             TRY(linear_bwd(e, dqkv.p, W3, M, W3, w.wqk, C, nullptr, 0, d_xq.p, C));
@@ -278,8 +316,6 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
     Exec& e = u.ex;
     e.arena.reset((char*)ws, ws_bytes, dry);
     e.st = st; e.batch = B; e.ctx_cache = nullptr; e.ctx_layer = 0;
-    const int saved_tome = e.tome_r;
-    if (saved_tome) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "unet vjp: token merging (ToMe) has no adjoint; call gyre_unet_set_tome(h, 0)");
     const int D = c.cross_attention_dim;
     Tn xin, cx, emb, t1, t2, tp;
     TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));

@@ -369,7 +369,7 @@ class GyreHipUNet(_NativeModule):
         with torch.cuda.device(dev):
             need = L.gyre_unet_vjp_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
-                _lib.check(-6 if "ToMe" in L.gyre_last_error().decode() else -4)
+                _lib.check(-4)
             ws = self._workspace(need, dev)
             wp = (ws.data_ptr() + 255) & ~255
             eps = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)

@@ -142,7 +142,8 @@ int gyre_unet_set_tome(gyre_unet* h, int r);
  * Replaces what autograd does in the reference's CLIP-guided mode, gyre/pipeline/unet/clipguided.py:301-338
  * (`latents.requires_grad_()`, `unet(latents, t)`) + :420 (`torch.autograd.grad(loss, latents)`); weights and the
  * text context receive no gradient there.  ctx must be passed (the K/V cache is not used); temb_add as in
- * gyre_unet_forward_ex (may be NULL).  GYRE_ERR_UNSUPPORTED while token merging is enabled. */
+ * gyre_unet_forward_ex (may be NULL).  With token merging enabled (gyre_unet_set_tome) the sweep re-derives the matching and
+ * applies the merge's adjoint to d K / d V; the matching indices themselves carry no gradient (as under autograd). */
 size_t gyre_unet_vjp_workspace_bytes(gyre_unet* h, int B, int H, int W, int S);
 int gyre_unet_vjp(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
                   const void* ctx, int ctx_dtype, int B, int H, int W, int S,

@@ -11,27 +11,8 @@ from gyre_amd.resize import resize_right
 from test_host_pipeline import OracleUNet, OracleVAE, tiny  # noqa: F401  (fixture)
 
 
-class _PatchEmbedAsMatmul(torch.nn.Module):
-    """CLIP's patch embedding (Conv2d with stride = kernel = patch) as unfold + matmul: same arithmetic, but no MIOpen
-    convolution - on a fresh GPU box MIOpen's first-use kernel search for that one backward-data conv takes minutes."""
-
-    def __init__(self, conv):
-        super().__init__()
-        self.weight, self.bias, self.p = conv.weight, conv.bias, conv.kernel_size[0]
-
-    def forward(self, x):
-        B, _, H, W = x.shape
-        cols = torch.nn.functional.unfold(x, self.p, stride=self.p)                       # [B, C*p*p, L]
-        out = self.weight.flatten(1).to(x.dtype) @ cols
-        if self.bias is not None:
-            out = out + self.bias.to(x.dtype)[None, :, None]
-        return out.view(B, -1, H // self.p, W // self.p)
-
-
 def patch_embed_as_matmul(clip):
-    emb = clip.vision_model.embeddings
-    emb.patch_embedding = _PatchEmbedAsMatmul(emb.patch_embedding)
-    return clip
+    return CG.patch_embedding_as_matmul(clip)
 
 
 def tiny_clip():

@@ -220,3 +220,54 @@ def test_config4_sdxl_base_properties_full_size():
     vae = fill(GyreHipVAE(gcfg.sdxl_vae()).to(torch.bfloat16).to(DEV), 9)
     img = vae.decode(x[:1] / 0.13025).sample
     assert img.shape == (1, 3, 1024, 1024) and bool(torch.isfinite(img).all())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: SD1.5 512x512 with ToMe token-merged attention + CLIP guidance, batch 8
+# ------------------------------------------------------------------------------------------------------------------
+def test_config5_sd15_tome_clip_guidance_batch8_full_size():
+    """The real SD1.5 topology at 512x512, batch 8, ToMe r = 1024 and CLIP guidance together (reference
+    tests/engines.clip.yaml + option `tome`): every guided step runs the conditional stem's native reverse sweep THROUGH the
+    merged attention.  No CPU oracle at this size (its backward alone takes minutes): size-independent properties -
+    finite, bit-reproducible, guidance and merging both act, evaluation count, and the result of image i does not change
+    when the images after it are dropped from the batch EXCEPT through the batch-wide loss history (flat-loss test off)."""
+    from types import SimpleNamespace
+    from transformers import CLIPConfig, CLIPModel
+    from gyre_amd.clipguided import patch_embedding_as_matmul
+    ucfg, vcfg = gcfg.sd15_unet(), gcfg.sd15_vae()
+    unet = GyreHipUNet(ucfg).load_synthetic(0).to(DEV)
+    vae = GyreHipVAE(vcfg).load_synthetic(1).to(DEV)
+    torch.manual_seed(0)
+    clip = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(DEV))
+    for p_ in clip.parameters():
+        p_.requires_grad_(False)
+    fe = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711],
+                         size={"shortest_edge": 224})
+    pipe = GyrePipeline(unet, vae, device=DEV, clip_model=clip, feature_extractor=fe)
+    g = torch.Generator().manual_seed(5)
+    B = 8
+    text, unc = torch.randn(B, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g).expand(B, -1, -1).contiguous()
+    ids = torch.randint(3, 40000, (B, 77), generator=g)
+    kw = dict(seeds=list(range(100, 100 + B)), text_embeddings=text, uncond_embeddings=unc, height=512, width=512,
+              num_inference_steps=3, guidance_scale=7.5, sampler="dpmpp_2m", output_type="latent")
+    ckw = dict(clip_guidance_scale=0.2, clip_input_ids=ids, clip_gradient_threshold=0.0)
+    plain = pipe(**kw)
+    unet.set_tome(1024)
+    merged = pipe(**kw)
+    import time
+    torch.cuda.synchronize(); t0 = time.time()
+    a = pipe(**ckw, **kw)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    evals, mode = pipe.last_unet_evals, pipe.last_clip_modes[0]
+    b = pipe(**ckw, **kw)
+    vae_only = pipe(vae_cutouts=4, approx_cutouts=0, **ckw, **kw)
+    unet.set_tome(0)
+    guided_no_tome = pipe(**ckw, **kw)
+    print(f"[config5] B=8 512x512 ToMe 1024 + CLIP guidance: {dt / 3 * 1e3:.0f} ms per guided step (batch 8), loss {mode.lossavg}, "
+          f"evals {evals}; |tome - plain| {float((merged - plain).abs().max()):.3f}, |guided - tome| {float((a - merged).abs().max()):.3f}, "
+          f"|guided(tome) - guided(no tome)| {float((a - guided_no_tome).abs().max()):.3f}")
+    assert a.shape == (B, 4, 64, 64) and bool(torch.isfinite(a).all()) and bool(torch.isfinite(vae_only).all())
+    assert torch.equal(a, b)
+    assert evals == 2 * 4 and mode.grad_evals == 4            # dpmpp_2m: 3 steps + 1 warm-up evaluation, each guided: g-stem + (u)
+    assert float((merged - plain).abs().max()) > 1e-3 and float((a - merged).abs().max()) > 1e-3
+    assert float((a - guided_no_tome).abs().max()) > 1e-3 and float((a - vae_only).abs().max()) > 1e-3

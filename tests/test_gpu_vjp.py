@@ -173,14 +173,28 @@ def test_tiny_sdxl_style_unet_vjp():
     report("tiny linear-proj depth-2 unet vjp", got.cpu(), ref, 5e-2)
 
 
-def test_unet_vjp_rejects_tome():
+@pytest.mark.parametrize("r", [8, 40, 1000])
+def test_tiny_unet_vjp_with_tome(r):
+    """Token merging in the reverse sweep: the merge's adjoint spreads d K / d V of a merged row over the tokens that went
+    into it (divided by their count); the matching indices carry no gradient, as under autograd in the oracle."""
     cfg = gcfg.tiny_unet()
-    net, _ = _unet(cfg)
-    net.set_tome(8)
-    xd = randn(1, 4, 16, 16).to(DEV).requires_grad_()
-    eps = net(xd, 5, encoder_hidden_states=randn(1, 77, cfg.cross_attention_dim).to(DEV)).sample
-    with pytest.raises(NotImplementedError):
-        torch.autograd.grad(eps.sum(), xd)
+    net, sd = _unet(cfg)
+    net.set_tome(r)
+    x = randn(2, 4, 16, 16, seed=1)
+    t = torch.tensor([981, 17])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    cot = randn(2, 4, 16, 16, seed=3)
+    xr = x.clone().requires_grad_()
+    ref_eps = M.unet_forward(sd, cfg, xr, t, ctx, tome_r=r)
+    (ref,) = torch.autograd.grad(ref_eps, xr, cot)
+    xd = x.to(DEV).requires_grad_()
+    eps = net(xd, t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    (got,) = torch.autograd.grad(eps, xd, cot.to(DEV))
+    report(f"tiny unet tome r={r} eps", eps.detach().cpu(), ref_eps.detach(), 3e-2)
+    report(f"tiny unet tome r={r} vjp d_x", got.cpu(), ref, 5e-2)
+    net.set_tome(0)
+    (plain,) = torch.autograd.grad(net(xd, t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample, xd, cot.to(DEV))
+    assert float((plain - got).abs().max()) > 1e-4          # merging really changed the gradient
 
 
 def test_tiny_vae_decode_vjp():
