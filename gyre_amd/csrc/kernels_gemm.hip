@@ -25,6 +25,8 @@
 // torch.nn.Conv2d inside the third-party UNet/VAE the reference calls at
 // gyre/pipeline/unet/core.py:274 and gyre/pipeline/unified_pipeline.py:309,1531.
 #include "gemm_shared.h"
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <atomic>
 #include <utility>
@@ -774,7 +776,12 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
             // very long reductions (3x3 convs over 1280+ channels at 32x32 / 16x16): the 256x320 tile's better
             // operand reuse outweighs the larger slabs - measured +3 % (K = 11520) to +10 % (K = 17280 / 23040)
             // (same-box A/B: UNet forward 20.56 -> 20.12 ms)
-            if (p.N % 320 == 0 && p.K >= 11000) tryk(4, 1.05, 256, 320);
+            if (p.N % 320 == 0 && p.K >= 11000) {
+                tryk(4, 1.05, 256, 320);
+                // the pipelined main loop also wins with split K (tools/gemm_sweep.py, r02: 16x16 convs K = 11520 ... 23040,
+                // 4 slices: 133 -> 127, 182 -> 170, 227 -> 216 us)
+                if (!(p.debug & 0x400) && gemm4s_supports(p, 24)) tryk(24, 1.10, 256, 320);
+            }
         }
     }
     return cfg;
@@ -852,6 +859,14 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     }
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
+    {   // tuning aid (tools/gemm_sweep.py): GYRE_GEMM_DUMP=1 prints every problem shape with the planner's choice
+        static const bool dump = getenv("GYRE_GEMM_DUMP") != nullptr;
+        if (dump)
+            fprintf(stderr, "GYRE_GEMM mode=%d M=%d N=%d K=%d Cin=%d C1=%d Hi=%d Wi=%d stride=%d ups=%d geglu=%d res=%d rowbias=%d "
+                            "out=%d vt=%d batch=%d samples=%d cfg=%d splits=%d\n", p.mode, p.M, p.N, p.K, p.Cin, p.C1, p.Hi, p.Wi,
+                    p.stride, p.ups, p.geglu, p.residual ? 1 : 0, p.rowbias ? 1 : 0, p.out_mode, p.vt_out ? 1 : 0, p.batch, p.samples,
+                    cfg, splits);
+    }
     if (p.force_cfg) { cfg = p.force_cfg & 0xff; splits = (p.force_cfg >> 8) & 0xff; if (splits < 1) splits = 1; }
     if (splits > 1) {
         if (!p.splitk_ws) { p.splitk_ws = g_dbg_ws; p.splitk_ws_bytes = g_dbg_ws_bytes; }
