@@ -8,8 +8,9 @@ int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, 
 int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_t* y);
 int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n);
 int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);
-// out[b][n] = act(sum_k x[b][k] * W[n][k] + bias[n]); x f32 [B][K], W bf16 [N][K], out f32 [B][ldo] (+col offset)
-int launch_rowvec_linear(hipStream_t st, const float* x, int B, int K, const bf16_t* W, const float* bias, int N,
+// out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]; x f32 [B][K], W bf16 [N][K], out f32 [B][ldo].  act_in_silu: f = SiLU,
+// and x is OVERWRITTEN with SiLU(x) (its only use on the time-embedding path)
+int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W, const float* bias, int N,
                          int act_in_silu, float* out, int ldo);
 
 // GroupNorm over NHWC bf16, optional second source for the skip-concat case:

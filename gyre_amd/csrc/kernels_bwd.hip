@@ -448,7 +448,9 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x16_t& v, int m) {
                                                    pack_bf16x2(v[8 * m + 4], v[8 * m + 5]), pack_bf16x2(v[8 * m + 6], v[8 * m + 7])));
 }
 
-template <int NDB>
+// DS = ceil(D / 16) when the loop-invariant operand fragments (this lane's query rows in the dQ kernel, its key rows in the
+// dK / dV kernel) fit in registers (D <= 160), 0 = reload them every tile (VAE: one head of 512 channels)
+template <int NDB, int DS>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunks) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
     const int qblk = blockIdx.x / dchunks, dchunk = blockIdx.x % dchunks;
@@ -465,6 +467,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
     const size_t stat = ((size_t)b * p.H + h) * p.NqPad + q;
     const int nkb = (p.Nk + 31) / 32;
     const float NEG = -1e30f;
+    bf16x8_t qh[DS > 0 ? DS : 1], doh[DS > 0 ? DS : 1];
+    if constexpr (DS > 0) {
+#pragma unroll
+        for (int i = 0; i < DS; ++i) {
+            qh[i] = ld_frag(Q, p.ldq, q, p.Nq, i * 16 + 8 * hi, D);
+            doh[i] = ld_frag(DO, p.lddo, q, p.Nq, i * 16 + 8 * hi, D);
+        }
+    }
 
     // pass 1: row maximum and sum of 2^(s - max) over all keys (lane-local over its 16 keys per tile, halves merged last)
     float lse2;
@@ -472,9 +482,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
         float mx = NEG, sum = 0.f;
         for (int kb = 0; kb < nkb; ++kb) {
             f32x16_t s = {};
-            for (int d0 = 0; d0 < D; d0 += 16)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D),
-                                                            ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D), s, 0, 0, 0);
+            if constexpr (DS > 0) {
+#pragma unroll
+                for (int i = 0; i < DS; ++i)
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+            } else {
+                for (int d0 = 0; d0 < D; d0 += 16)
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D),
+                                                                ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D), s, 0, 0, 0);
+            }
             float tmx = NEG;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -504,11 +520,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
     const int dbase = dchunk * NDB * 32;
     for (int kb = 0; kb < nkb; ++kb) {
         f32x16_t s = {}, dp = {};
-        for (int d0 = 0; d0 < D; d0 += 16) {
-            const bf16x8_t qf = ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D);
-            const bf16x8_t dof = ld_frag(DO, p.lddo, q, p.Nq, d0 + 8 * hi, D);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D), qf, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, d0 + 8 * hi, D), dof, dp, 0, 0, 0);
+        if constexpr (DS > 0) {
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
+            }
+        } else {
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                const bf16x8_t qf = ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D);
+                const bf16x8_t dof = ld_frag(DO, p.lddo, q, p.Nq, d0 + 8 * hi, D);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D), qf, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, d0 + 8 * hi, D), dof, dp, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
         }
 }
 
-template <int NDB>
+template <int NDB, int DS>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchunks) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, hi = lane >> 5;
     const int kblk = blockIdx.x / dchunks, dchunk = blockIdx.x % dchunks;
@@ -562,13 +586,29 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchun
 #pragma unroll
     for (int i = 0; i < NDB; ++i) { dk[i] = f32x16_t{}; dv[i] = f32x16_t{}; }
     const int dbase = dchunk * NDB * 32;
+    bf16x8_t kh[DS > 0 ? DS : 1], vh[DS > 0 ? DS : 1];
+    if constexpr (DS > 0) {
+#pragma unroll
+        for (int i = 0; i < DS; ++i) {
+            kh[i] = ld_frag(K, p.ldk, key, p.Nk, i * 16 + 8 * hi, D);
+            vh[i] = ld_frag(V, p.ldv, key, p.Nk, i * 16 + 8 * hi, D);
+        }
+    }
     for (int qb = 0; qb < nqb; ++qb) {
         f32x16_t s = {}, dp = {};
-        for (int d0 = 0; d0 < D; d0 += 16) {
-            const bf16x8_t kf = ld_frag(K, p.ldk, key, p.Nk, d0 + 8 * hi, D);
-            const bf16x8_t vf = ld_frag(V, p.ldv, key, p.Nk, d0 + 8 * hi, D);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, d0 + 8 * hi, D), kf, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, d0 + 8 * hi, D), vf, dp, 0, 0, 0);
+        if constexpr (DS > 0) {
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
+            }
+        } else {
+            for (int d0 = 0; d0 < D; d0 += 16) {
+                const bf16x8_t kf = ld_frag(K, p.ldk, key, p.Nk, d0 + 8 * hi, D);
+                const bf16x8_t vf = ld_frag(V, p.ldv, key, p.Nk, d0 + 8 * hi, D);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, d0 + 8 * hi, D), kf, s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, d0 + 8 * hi, D), vf, dp, 0, 0, 0);
+            }
         }
         // lane: key fixed, queries qb*32 + 8g + 4hi + {0..3}; NqPad is a multiple of 32 so the statistics reads stay in range
 #pragma unroll
@@ -634,22 +674,25 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     hipLaunchKernelGGL(k_attn_bwd_delta, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
     const int ndb_total = (p.D + 31) / 32;
-    const int ndb = ndb_total <= 2 ? 2 : (ndb_total <= 3 ? 3 : (ndb_total <= 5 ? 5 : 4));
+    const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : (p.D <= 160 ? 3 : 4)));
+    const int ndb = sel <= 1 ? 2 : (sel == 2 ? 3 : (sel == 3 ? 5 : 4));
     const int dchunks = (ndb_total + ndb - 1) / ndb;
     const dim3 gq((unsigned)((p.Nq + 127) / 128 * dchunks), p.H, p.B), gk((unsigned)((p.Nk + 127) / 128 * dchunks), p.H, p.B);
-    switch (ndb) {
-        case 2: hipLaunchKernelGGL(k_attn_bwd_dq<2>, gq, dim3(256), 0, st, p, dchunks); break;
-        case 3: hipLaunchKernelGGL(k_attn_bwd_dq<3>, gq, dim3(256), 0, st, p, dchunks); break;
-        case 5: hipLaunchKernelGGL(k_attn_bwd_dq<5>, gq, dim3(256), 0, st, p, dchunks); break;
-        default: hipLaunchKernelGGL(k_attn_bwd_dq<4>, gq, dim3(256), 0, st, p, dchunks); break;
+    switch (sel) {
+        case 0: hipLaunchKernelGGL((k_attn_bwd_dq<2, 3>), gq, dim3(256), 0, st, p, dchunks); break;
+        case 1: hipLaunchKernelGGL((k_attn_bwd_dq<2, 4>), gq, dim3(256), 0, st, p, dchunks); break;
+        case 2: hipLaunchKernelGGL((k_attn_bwd_dq<3, 6>), gq, dim3(256), 0, st, p, dchunks); break;
+        case 3: hipLaunchKernelGGL((k_attn_bwd_dq<5, 10>), gq, dim3(256), 0, st, p, dchunks); break;
+        default: hipLaunchKernelGGL((k_attn_bwd_dq<4, 0>), gq, dim3(256), 0, st, p, dchunks); break;
     }
     GYRE_LAUNCH_CHECK();
     if (!p.dk) return 0;
-    switch (ndb) {
-        case 2: hipLaunchKernelGGL(k_attn_bwd_dkv<2>, gk, dim3(256), 0, st, p, dchunks); break;
-        case 3: hipLaunchKernelGGL(k_attn_bwd_dkv<3>, gk, dim3(256), 0, st, p, dchunks); break;
-        case 5: hipLaunchKernelGGL(k_attn_bwd_dkv<5>, gk, dim3(256), 0, st, p, dchunks); break;
-        default: hipLaunchKernelGGL(k_attn_bwd_dkv<4>, gk, dim3(256), 0, st, p, dchunks); break;
+    switch (sel) {
+        case 0: hipLaunchKernelGGL((k_attn_bwd_dkv<2, 3>), gk, dim3(256), 0, st, p, dchunks); break;
+        case 1: hipLaunchKernelGGL((k_attn_bwd_dkv<2, 4>), gk, dim3(256), 0, st, p, dchunks); break;
+        case 2: hipLaunchKernelGGL((k_attn_bwd_dkv<3, 6>), gk, dim3(256), 0, st, p, dchunks); break;
+        case 3: hipLaunchKernelGGL((k_attn_bwd_dkv<5, 10>), gk, dim3(256), 0, st, p, dchunks); break;
+        default: hipLaunchKernelGGL((k_attn_bwd_dkv<4, 0>), gk, dim3(256), 0, st, p, dchunks); break;
     }
     GYRE_LAUNCH_CHECK();
     return 0;

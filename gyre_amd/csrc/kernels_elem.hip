@@ -93,13 +93,19 @@ int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n) {
 }
 
 // ------------------------------------------------------------------------------
-// out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]   (f = SiLU when act_in_silu)
-// One wave per output column n, rows in groups of 8.  Weight-read bound (B <= 32).
+// out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]   (f = SiLU when act_in_silu: applied to x IN PLACE by a tiny
+// elementwise launch first - inside the dot products it was evaluated once per output column, 367 M exponentials for
+// the batched time_emb_proj of a CFG batch of 16, which made this 46 MB weight stream take 200 us)
+// One wave per output column n, rows in groups of 16.  Weight-read bound (B <= 32).
 // ------------------------------------------------------------------------------
-#define RV_ROWS 8
+#define RV_ROWS 16
+__global__ __launch_bounds__(256) void k_silu_inplace_f32(float* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = silu_f(x[i]);
+}
 __global__ __launch_bounds__(256) void k_rowvec_linear(const float* __restrict__ x, int B, int K,
                                                        const bf16_t* __restrict__ W, const float* __restrict__ bias,
-                                                       int N, int act_in_silu, float* __restrict__ out, int ldo) {
+                                                       int N, float* __restrict__ out, int ldo) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
@@ -118,10 +124,7 @@ __global__ __launch_bounds__(256) void k_rowvec_linear(const float* __restrict__
                     float4 x0 = *(const float4*)xr, x1 = *(const float4*)(xr + 4);
                     float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float v = act_in_silu ? silu_f(xv[j]) : xv[j];
-                        acc[r] = fmaf(v, w[j], acc[r]);
-                    }
+                    for (int j = 0; j < 8; ++j) acc[r] = fmaf(xv[j], w[j], acc[r]);
                 }
             }
         }
@@ -134,10 +137,15 @@ __global__ __launch_bounds__(256) void k_rowvec_linear(const float* __restrict__
         }
     }
 }
-int launch_rowvec_linear(hipStream_t st, const float* x, int B, int K, const bf16_t* W, const float* bias, int N,
+int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W, const float* bias, int N,
                          int act_in_silu, float* out, int ldo) {
     if (K % 8) GYRE_FAIL(-1, "rowvec_linear: K must be a multiple of 8");
-    hipLaunchKernelGGL(k_rowvec_linear, dim3((N + 3) / 4), dim3(256), 0, st, x, B, K, W, bias, N, act_in_silu, out, ldo);
+    if (act_in_silu) {
+        const size_t n = (size_t)B * K;
+        hipLaunchKernelGGL(k_silu_inplace_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+        GYRE_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_rowvec_linear, dim3((N + 3) / 4), dim3(256), 0, st, x, B, K, W, bias, N, out, ldo);
     GYRE_LAUNCH_CHECK();
     return 0;
 }
