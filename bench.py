@@ -257,14 +257,18 @@ def main():
 
     # one extra, fully instrumented step (outside the timed region): the per-class table
     classes = None
-    if rank == 0 and nloc and not args.no_class_table and not args.profile_all:
-        _lib.prof_enable(None)
+    if not args.no_class_table and not args.profile_all:
+        # EVERY rank runs the extra step (it contains the all_gather of the finished latents - a collective that only rank 0
+        # entered would hang the job); only rank 0 instruments it
+        if rank == 0:
+            _lib.prof_enable(None)
         c0 = time.perf_counter()
         step(args.steps)
         torch.cuda.synchronize()
         c_el = time.perf_counter() - c0
-        classes = _lib.prof_collect()
-        _lib.prof_enable([])
+        if rank == 0:
+            classes = _lib.prof_collect() if nloc else None
+            _lib.prof_enable([])
     elif args.profile_all:
         classes, c_el = prof, elapsed
     if world > 1:
