@@ -137,11 +137,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (tests/test_gpu_bench_ranks.py runs two ranks on ONE GPU, which RCCL refuses): BENCH_FORCE_DEVICE pins the
+    # device index, BENCH_DIST_BACKEND=gloo swaps the collective backend.  The driver sets neither.
+    dev_index = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gyre_amd import _lib, config as gcfg
     from gyre_amd.modules import GyreHipUNet, GyreHipVAE
@@ -251,7 +258,7 @@ def main():
         assert bool(torch.isfinite(images).all()), "non-finite output"
     evals = getattr(pipe, "last_unet_evals", 0)
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -37,11 +37,15 @@ def gather_batches(local: torch.Tensor, sizes: Sequence[int], group=None) -> tor
     """all_gather of per-rank [b_r, ...] tensors with ragged b_r (padded to the largest shard)."""
     world = dist.get_world_size(group)
     mx = max(sizes)
-    pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    # gloo gathers host tensors only: stage through the CPU there (tests / single-GPU development; RCCL takes the device path)
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    src = local.cpu() if via_host else local
+    pad = torch.zeros((mx, *src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[: src.shape[0]] = src
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous(), group=group)
-    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+    out = torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+    return out.to(local.device) if via_host else out
 
 
 def generate_sharded(pipe, *, seeds: Sequence[int], text_embeddings: torch.Tensor,

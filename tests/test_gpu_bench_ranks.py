@@ -1,0 +1,38 @@
+"""bench.py with more than one rank (-m gpu): the exact launch line the driver uses for the scaling run
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`), with two ranks on the one GPU of
+the test box.  RCCL refuses two ranks on one device, so the collectives go over gloo here (BENCH_DIST_BACKEND / BENCH_FORCE_DEVICE
+test hooks); everything else - rendezvous, barriers, max-over-ranks timing, the per-step all_gather of the latents, the extra
+instrumented step every rank must enter, rank 0 printing one JSON line, clean exit - is the code path of an N-GPU node."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("scaling,batch", [("weak", 2), ("strong", 3)])
+def test_bench_two_ranks(scaling, batch):
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--inference-steps", "2", "--batch", str(batch), "--scaling", scaling]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+    per_rank = out["config"]["images_per_rank"]
+    assert per_rank == ([batch, batch] if scaling == "weak" else [2, 1])       # strong: the reference's batched_seeds split
+    assert out["config"]["images_per_step"] == sum(per_rank)
+    assert "kernel_classes" in out and out["cpu_baseline"] is None
