@@ -8,6 +8,10 @@ PARITY UNPINNED: the arithmetic lives in diffusers ~= 0.16.0
   gyre/pipeline/unified_pipeline.py:1531  vae.decode(latents).sample
 Topology / hyper-parameters follow gyre/ldm_config/v1-inference.yaml:29-64 and
 the diffusers key names consumed by gyre/ckpt_utils.py:259-285.
+Pinned as far as the tree allows: hyper-parameters and encoder wiring against the vendored ControlNet copy
+(tests/test_oracle_structure.py), and the UNet ASSEMBLY by executing the reference's vendored block forwards
+(nonfree/tome_unet.py:34-221, models/memory_efficient_cross_attention.py:32-60) over this file's leaf functions
+(tests/test_oracle_block_wiring.py: every level equal to 1e-5).  The leaves' internals and the VAE stay unpinned.
 
 Everything is plain ``torch.nn.functional`` over a flat ``{diffusers_key: tensor}``
 dict, i.e. the same ATen ops the reference's CPU path dispatches to
