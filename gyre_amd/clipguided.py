@@ -111,12 +111,14 @@ class PatchEmbedAsMatmul(torch.nn.Module):
         self.weight, self.bias, self.p = conv.weight, conv.bias, conv.kernel_size[0]
 
     def forward(self, x: Tensor) -> Tensor:
-        B, _, H, W = x.shape
-        cols = torch.nn.functional.unfold(x, self.p, stride=self.p)                       # [B, C*p*p, L]
-        out = self.weight.flatten(1).to(x.dtype) @ cols
+        B, C, H, W = x.shape
+        p, gh, gw = self.p, H // self.p, W // self.p
+        # non-overlapping patches are a pure reshape (no im2col kernel): [B, gh*gw, C*p*p] in the conv weight's (c, ky, kx) order
+        cols = x[:, :, :gh * p, :gw * p].reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
+        out = cols @ self.weight.flatten(1).to(x.dtype).t()
         if self.bias is not None:
-            out = out + self.bias.to(x.dtype)[None, :, None]
-        return out.view(B, -1, H // self.p, W // self.p)
+            out = out + self.bias.to(x.dtype)
+        return out.transpose(1, 2).reshape(B, -1, gh, gw)
 
 
 def patch_embedding_as_matmul(clip_model):
@@ -286,7 +288,9 @@ class ClipGuidedMode:
                         a5 = image.view(batch_total, approx_cutouts, *image.shape[-3:])
                         image = torch.stack([a5, a5], dim=1).view(batch_total * num_cutouts, *image.shape[-3:])
             image = (image / 2 + 0.5).clamp(0, 1)
-            image = (image - self.mean.to(image.device, image.dtype)) / self.std.to(image.device, image.dtype)
+            if self.mean.device != image.device or self.mean.dtype != image.dtype:     # once: no per-step host-to-device copy
+                self.mean, self.std = self.mean.to(image.device, image.dtype), self.std.to(image.device, image.dtype)
+            image = (image - self.mean) / self.std
             image_embeddings_clip = _features(self.clip_model.get_image_features(image))
             if no_cutouts:
                 loss = spherical_dist_loss(image_embeddings_clip, self.text_embeddings_clip).mean()

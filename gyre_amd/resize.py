@@ -78,33 +78,46 @@ def cubic(x: torch.Tensor) -> torch.Tensor:
     return (1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) + (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((1 < ax) & (ax <= 2))
 
 
-@lru_cache(maxsize=256)
+_GENERAL_CACHE: dict = {}
+
+
 def _weight_matrix_general(in_size: int, out_size: int, scale: float, method: str, antialiasing: bool,
-                           pad_mode: str) -> torch.Tensor:
-    """[out_size, in_size] float64 matrix of ResizeRight's 1-D resampling for one axis (same published algorithm as
+                           pad_mode: str, device="cpu") -> torch.Tensor:
+    """[out_size, in_size] float32 matrix of ResizeRight's 1-D resampling for one axis (same published algorithm as
     _weight_matrix, with the pieces the CLIP cut-outs use: an explicit output size, the antialiasing stretch of the kernel
     when downscaling - kernel(x) -> scale * kernel(scale * x), support / scale - and reflect / constant / replicate
-    boundary handling folded into the matrix)."""
+    boundary handling folded into the matrix).  Built in float64 ON the target device: the CLIP cut-outs ask for a new
+    (random) size every time, and a host-built matrix would cost a pageable host-to-device copy - a stream sync - per cut-out."""
+    device = torch.device(device)
+    key = (in_size, out_size, float(scale), method, bool(antialiasing), pad_mode, str(device))
+    hit = _GENERAL_CACHE.get(key)
+    if hit is not None:
+        return hit
     kernel, support = {"cubic": (cubic, 4.0), "lanczos2": (lanczos2, 4.0)}[method]
     if scale < 1 and antialiasing:
         base, k_support = kernel, support / scale
         kern = lambda a: scale * base(scale * a)
     else:
         kern, k_support = kernel, support
-    i = torch.arange(out_size, dtype=torch.float64)
+    i = torch.arange(out_size, dtype=torch.float64, device=device)
     proj = i / scale + (in_size - 1) / 2 - (out_size - 1) / (2 * scale)
     left = torch.ceil(proj - k_support / 2 - _EPS).to(torch.int64)
     ntaps = int(math.ceil(k_support - _EPS))
-    taps = left[:, None] + torch.arange(ntaps)[None, :]
+    taps = left[:, None] + torch.arange(ntaps, device=device)[None, :]
     w = kern(proj[:, None] - taps.to(torch.float64))
     s_ = w.sum(dim=1, keepdim=True)
-    s_[s_ == 0] = 1
+    s_ = torch.where(s_ == 0, torch.ones_like(s_), s_)
     w = w / s_
-    m = torch.zeros(out_size, in_size, dtype=torch.float64)
+    m = torch.zeros(out_size, in_size, dtype=torch.float64, device=device)
+    # extreme taps from the closed form (no device read-back): first / last row reach furthest
+    p_first = (in_size - 1) / 2 - (out_size - 1) / (2 * scale)
+    p_last = (out_size - 1) / scale + p_first
+    lo = math.ceil(p_first - k_support / 2 - _EPS)
+    hi = math.ceil(p_last - k_support / 2 - _EPS) + ntaps - 1
     if pad_mode == "replicate":
         m.scatter_add_(1, taps.clamp(0, in_size - 1), w)
     elif pad_mode == "reflect":                       # torch 'reflect': mirror without repeating the edge sample
-        if int(taps.min()) < -(in_size - 1) or int(taps.max()) > 2 * (in_size - 1):
+        if lo < -(in_size - 1) or hi > 2 * (in_size - 1):
             raise ValueError("reflect padding needs the padding to be smaller than the input")
         idx = taps.abs()
         idx = torch.where(idx > in_size - 1, 2 * (in_size - 1) - idx, idx)
@@ -114,6 +127,10 @@ def _weight_matrix_general(in_size: int, out_size: int, scale: float, method: st
         m.scatter_add_(1, taps.clamp(0, in_size - 1), w * inside)
     else:
         raise ValueError(f"pad_mode {pad_mode!r}")
+    m = m.to(torch.float32)
+    if len(_GENERAL_CACHE) > 512:
+        _GENERAL_CACHE.clear()
+    _GENERAL_CACHE[key] = m
     return m
 
 
@@ -131,8 +148,8 @@ def resize_right(x: torch.Tensor, out_shape=None, scale_factors=None, interp_met
         oh, ow = int(math.ceil(h * sh)), int(math.ceil(w * sw))
     else:
         raise ValueError("pass out_shape or scale_factors")
-    mh = _weight_matrix_general(h, oh, float(sh), interp_method, bool(antialiasing), pad_mode).to(x.device, torch.float32)
-    mwt = _weight_matrix_general(w, ow, float(sw), interp_method, bool(antialiasing), pad_mode).to(x.device, torch.float32).t().contiguous()
+    mh = _weight_matrix_general(h, oh, float(sh), interp_method, bool(antialiasing), pad_mode, x.device)
+    mwt = _weight_matrix_general(w, ow, float(sw), interp_method, bool(antialiasing), pad_mode, x.device).t().contiguous()
     xf = x.to(torch.float32)
     if xf.ndim < 4:
         return torch.matmul(torch.matmul(mh, xf), mwt).to(x.dtype)
