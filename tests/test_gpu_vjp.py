@@ -248,3 +248,40 @@ def test_sd15_vae_decode_vjp_cutout_size():
     zd = z.to(DEV).requires_grad_()
     (got,) = torch.autograd.grad(net.decode(zd).sample, zd, cot.to(DEV))
     report("SD1.5 vae decode vjp 28x28", got.cpu(), ref, 5e-2)
+
+
+def test_tiny_sdxl_unet_vjp_with_text_time_and_bf16_io():
+    """SDXL-style added conditioning enters the time embedding (no gradient path to the sample) and bf16 boundary tensors"""
+    cfg = gcfg.tiny_sdxl_unet()
+    net, sd = _unet(cfg)
+    x = randn(2, 4, 16, 16, seed=1)
+    t = torch.tensor([500, 40])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    added = {"text_embeds": randn(2, 32, seed=4), "time_ids": torch.tensor([[128., 128, 0, 0, 128, 128]] * 2)}
+    cot = randn(2, 4, 16, 16, seed=3)
+    xr = x.clone().requires_grad_()
+    (ref,) = torch.autograd.grad(M.unet_forward(sd, cfg, xr, t, ctx, added_cond=added), xr, cot)
+    add_dev = {k: v.to(DEV) for k, v in added.items()}
+    xd = x.to(DEV).requires_grad_()
+    (got,) = torch.autograd.grad(net(xd, t.to(DEV), encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=add_dev).sample, xd, cot.to(DEV))
+    report("tiny sdxl unet vjp (text_time)", got.cpu(), ref, 5e-2)
+    xb = x.to(DEV, torch.bfloat16).requires_grad_()
+    eps = net(xb, t.to(DEV), encoder_hidden_states=ctx.to(DEV, torch.bfloat16), added_cond_kwargs=add_dev).sample
+    (gb,) = torch.autograd.grad(eps, xb, cot.to(DEV, torch.bfloat16))
+    assert eps.dtype == torch.bfloat16 and gb.dtype == torch.bfloat16
+    report("tiny sdxl unet vjp bf16 io", gb.float().cpu(), ref, 6e-2)
+
+
+def test_vjp_batch_one_and_repeatable():
+    cfg = gcfg.tiny_unet()
+    net, sd = _unet(cfg)
+    x = randn(1, 4, 12, 20, seed=1)
+    ctx = randn(1, 33, cfg.cross_attention_dim, seed=2)
+    cot = randn(1, 4, 12, 20, seed=3)
+    xr = x.clone().requires_grad_()
+    (ref,) = torch.autograd.grad(M.unet_forward(sd, cfg, xr, torch.tensor([7]), ctx), xr, cot)
+    xd = x.to(DEV).requires_grad_()
+    (a,) = torch.autograd.grad(net(xd, 7, encoder_hidden_states=ctx.to(DEV)).sample, xd, cot.to(DEV))
+    (b,) = torch.autograd.grad(net(xd, 7, encoder_hidden_states=ctx.to(DEV)).sample, xd, cot.to(DEV))
+    report("tiny unet vjp batch 1, 12x20, S=33", a.cpu(), ref, 5e-2)
+    assert torch.equal(a, b)
