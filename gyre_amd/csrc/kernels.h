@@ -135,6 +135,7 @@ struct AttnBwdParams {
     float* lse = nullptr; float* delta = nullptr; int NqPad = 0; float alpha = 0.f, beta = 0.f;
 };
 size_t attn_bwd_stats_bytes(int B, int H, int Nq);
+bool attn_bwd_needs_transposes(int D);     // false: the LDS-tiled kernels (D <= 160) ignore kt / qt / d_ot
 int launch_attention_bwd(hipStream_t st, AttnBwdParams p);
 
 // ---- ToMe: bipartite soft matching + merge of self-attention K / V tokens (kernels_tome.hip) ---------------------------

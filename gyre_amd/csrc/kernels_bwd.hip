@@ -652,6 +652,291 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchun
     }
 }
 
+// ------------------------------------------------------------------------------
+// LDS-tiled forms (head dim <= 160, i.e. every UNet attention): the tile of the streamed side - 32 queries for the dK / dV
+// kernel, 32 keys for the dQ kernel - is fetched ONCE per workgroup into LDS, row-major for the A operands and transposed
+// for the permuted B / A operands of the second products, instead of once per wave from L2; that also removes the global
+// transposed copies.  Register prefetch of tile t+1 under the MFMAs of tile t, two LDS buffers, one barrier per tile.
+// Row strides are 16 x odd bytes (row-major tiles, ds_read_b128) and 72 bytes (transposed tiles, ds_read_b64): conflict-free
+// for the fragment reads.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int attn_bwd_row_stride(int D) { return D + (((D >> 3) & 1) ? 0 : 8); }   // elements
+// RT = 32-row MFMA tiles per LDS tile; transposed rows hold 32 RT tokens + 4 (72 / 136 bytes)
+__host__ __device__ inline size_t attn_bwd_stage_bytes(int D, int RT) {
+    const int rs = D + (((D >> 3) & 1) ? 0 : 8), ts = 32 * RT + 4;
+    return ((size_t)(2 * 32 * RT * rs + 2 * D * ts) * 2 + 512 + 255) & ~(size_t)255;
+}
+__device__ __forceinline__ bf16x8_t lds_frag(const bf16_t* tile, int rs, int row, int k, int D) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k < D) v = *(const uint4*)(tile + row * rs + k);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t lds_frag_t(const bf16_t* tile_t, int ts, int d, int D, int t) {
+    uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
+    if (d < D) { a = *(const uint2*)(tile_t + d * ts + t); b = *(const uint2*)(tile_t + d * ts + t + 8); }
+    return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+// one tile of two row-major [ROWS][D] operands (rows r0 ..) -> registers; then registers -> LDS (row-major + transposed copies)
+template <int MAXIT, int ROWS>
+struct AbwTile {
+    uint4 a[MAXIT], b[MAXIT];
+    __device__ __forceinline__ void fetch(const bf16_t* A, int lda, const bf16_t* B, int ldb, int r0, int nrows, int D, int tid) {
+        const int nv = D >> 3;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + it * 256;
+            a[it] = make_uint4(0, 0, 0, 0); b[it] = make_uint4(0, 0, 0, 0);
+            if (idx < ROWS * nv) {
+                const int r = idx / nv, v = idx - r * nv;
+                if (r0 + r < nrows) {
+                    a[it] = *(const uint4*)(A + (size_t)(r0 + r) * lda + v * 8);
+                    if (B) b[it] = *(const uint4*)(B + (size_t)(r0 + r) * ldb + v * 8);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* As, bf16_t* Bs, bf16_t* At, bf16_t* Bt, int D, int tid) const {
+        const int nv = D >> 3, rs = attn_bwd_row_stride(D);
+        constexpr int TS = ROWS + 4;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < ROWS * nv) {
+                const int r = idx / nv, v = idx - r * nv;
+                *(uint4*)(As + r * rs + v * 8) = a[it];
+                if (Bs) *(uint4*)(Bs + r * rs + v * 8) = b[it];
+                const uint32_t wa[4] = {a[it].x, a[it].y, a[it].z, a[it].w}, wb[4] = {b[it].x, b[it].y, b[it].z, b[it].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (At) At[(v * 8 + j) * TS + r] = (bf16_t)(wa[j >> 1] >> (16 * (j & 1)));
+                    if (Bt) Bt[(v * 8 + j) * TS + r] = (bf16_t)(wb[j >> 1] >> (16 * (j & 1)));
+                }
+            }
+        }
+    }
+};
+
+template <int NDB, int DS, int RT>
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
+    constexpr int ROWS = 32 * RT, TS = ROWS + 4;
+    constexpr int MAXIT = (ROWS * (DS * 2) + 255) / 256;         // D <= 16 DS -> D/8 <= 2 DS vectors per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, D = p.D, rs = attn_bwd_row_stride(D);
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    const float* LSE = p.lse + ((size_t)b * p.H + h) * p.NqPad;
+    const float* DEL = p.delta + ((size_t)b * p.H + h) * p.NqPad;
+    const size_t stage = attn_bwd_stage_bytes(D, RT);
+    auto part = [&](int buf, int which) -> bf16_t* {              // 0 Q, 1 dO, 2 Q^T, 3 dO^T
+        bf16_t* base = (bf16_t*)(smem + buf * stage);
+        return which < 2 ? base + which * ROWS * rs : base + 2 * ROWS * rs + (which - 2) * D * TS;
+    };
+    auto stats = [&](int buf) -> float* { return (float*)(smem + buf * stage + (size_t)(2 * ROWS * rs + 2 * D * TS) * 2); };
+    const int key = k0 + col;
+    bf16x8_t kh[DS], vh[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+        kh[i] = ld_frag(K, p.ldk, key, p.Nk, i * 16 + 8 * hi, D);
+        vh[i] = ld_frag(V, p.ldv, key, p.Nk, i * 16 + 8 * hi, D);
+    }
+    f32x16_t dk[NDB], dv[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) { dk[i] = f32x16_t{}; dv[i] = f32x16_t{}; }
+    const int nqb = (p.Nq + ROWS - 1) / ROWS;
+    AbwTile<MAXIT, ROWS> tile;
+    float st_pref = 0.f;
+    auto fetch = [&](int qb) {
+        tile.fetch(Q, p.ldq, DO, p.lddo, qb * ROWS, p.Nq, D, tid);
+        if (tid < 2 * ROWS) { const int q = qb * ROWS + (tid % ROWS); st_pref = q < p.Nq ? (tid < ROWS ? LSE[q] : DEL[q]) : 0.f; }
+    };
+    auto store = [&](int buf) {
+        tile.store(part(buf, 0), part(buf, 1), part(buf, 2), part(buf, 3), D, tid);
+        if (tid < 2 * ROWS) stats(buf)[tid] = st_pref;            // [0,ROWS) LSE, [ROWS,2 ROWS) delta
+    };
+    fetch(0);
+    store(0);
+    __syncthreads();
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int buf = qb & 1;
+        if (qb + 1 < nqb) fetch(qb + 1);
+        const bf16_t *Qs = part(buf, 0), *DOs = part(buf, 1), *QTs = part(buf, 2), *DOTs = part(buf, 3);
+        const float* sts = stats(buf);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x16_t s = {}, dp = {};
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qs, rs, rt * 32 + col, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(DOs, rs, rt * 32 + col, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = rt * 32 + 8 * g + 4 * hi;
+                const float4 l4 = *(const float4*)(sts + ql), d4 = *(const float4*)(sts + ROWS + ql);
+                const float l[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (qb * ROWS + ql + r) < p.Nq && key < p.Nk;
+                    const float pr = ok ? __builtin_amdgcn_exp2f(s[4 * g + r] * p.alpha - l[r]) : 0.f;
+                    s[4 * g + r] = pr;
+                    dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8_t pf = pack_frag(s, m), dsf = pack_frag(dp, m);
+                const int t = rt * 32 + 16 * m + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i) {
+                    const int d = i * 32 + col;
+                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, lds_frag_t(DOTs, TS, d, D, t), dv[i], 0, 0, 0);
+                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, lds_frag_t(QTs, TS, d, D, t), dk[i], 0, 0, 0);
+                }
+            }
+        }
+        if (qb + 1 < nqb) store(buf ^ 1);
+        __syncthreads();
+    }
+    if (k0 >= p.Nk) return;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) {
+        const int d = i * 32 + col;
+        if (d >= D) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (kk < p.Nk) {
+                p.dk[((size_t)b * p.Nk + kk) * p.lddk + h * D + d] = f32_to_bf16(dk[i][r] * p.beta);
+                p.dv[((size_t)b * p.Nk + kk) * p.lddv + h * D + d] = f32_to_bf16(dv[i][r]);
+            }
+        }
+    }
+}
+
+template <int NDB, int DS, int RT>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(AttnBwdParams p) {
+    constexpr int ROWS = 32 * RT, TS = ROWS + 4;
+    constexpr int MAXIT = (ROWS * (DS * 2) + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, D = p.D, rs = attn_bwd_row_stride(D);
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    const size_t stage = attn_bwd_stage_bytes(D, RT);
+    auto part = [&](int buf, int which) -> bf16_t* {              // 0 K, 1 V, 2 K^T
+        bf16_t* base = (bf16_t*)(smem + buf * stage);
+        return which < 2 ? base + which * ROWS * rs : base + 2 * ROWS * rs;
+    };
+    const int q = q0 + col;
+    const size_t stat = ((size_t)b * p.H + h) * p.NqPad + q;
+    const int nkb = (p.Nk + ROWS - 1) / ROWS;
+    const float NEG = -1e30f;
+    bf16x8_t qh[DS], doh[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+        qh[i] = ld_frag(Q, p.ldq, q, p.Nq, i * 16 + 8 * hi, D);
+        doh[i] = ld_frag(DO, p.lddo, q, p.Nq, i * 16 + 8 * hi, D);
+    }
+    AbwTile<MAXIT, ROWS> tile;
+    // ---- pass 1: row log-sum-exp (streams K only) ----
+    float mx = NEG, sum = 0.f;
+    tile.fetch(K, p.ldk, nullptr, 0, 0, p.Nk, D, tid);
+    tile.store(part(0, 0), nullptr, nullptr, nullptr, D, tid);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) tile.fetch(K, p.ldk, nullptr, 0, (kb + 1) * ROWS, p.Nk, D, tid);
+        const bf16_t* Ks = part(buf, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x16_t s = {};
+#pragma unroll
+            for (int i = 0; i < DS; ++i)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+            float tmx = NEG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s[r] = key < p.Nk ? s[r] * p.alpha : NEG;
+                tmx = fmaxf(tmx, s[r]);
+            }
+            const float nm = fmaxf(mx, tmx);
+            float ts = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ts += __builtin_amdgcn_exp2f(s[r] - nm);
+            sum = sum * __builtin_amdgcn_exp2f(mx - nm) + ts;
+            mx = nm;
+        }
+        if (kb + 1 < nkb) tile.store(part(buf ^ 1, 0), nullptr, nullptr, nullptr, D, tid);
+        __syncthreads();
+    }
+    float lse2;
+    {
+        const float omx = __shfl_xor(mx, 32), osum = __shfl_xor(sum, 32);
+        const float nm = fmaxf(mx, omx);
+        sum = sum * __builtin_amdgcn_exp2f(mx - nm) + osum * __builtin_amdgcn_exp2f(omx - nm);
+        lse2 = nm + __builtin_amdgcn_logf(sum);
+        if (hi == 0 && q < p.Nq) p.lse[stat] = lse2;
+    }
+    const float delta = q < p.Nq ? p.delta[stat] : 0.f;
+    // ---- pass 2: dQ^T[d][q] += K^T[d][keys] dS^T[keys][q] ----
+    f32x16_t acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) acc[i] = f32x16_t{};
+    tile.fetch(K, p.ldk, V, p.ldv, 0, p.Nk, D, tid);
+    tile.store(part(0, 0), part(0, 1), part(0, 2), nullptr, D, tid);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) tile.fetch(K, p.ldk, V, p.ldv, (kb + 1) * ROWS, p.Nk, D, tid);
+        const bf16_t *Ks = part(buf, 0), *Vs = part(buf, 1), *KTs = part(buf, 2);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x16_t s = {}, dp = {};
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vs, rs, rt * 32 + col, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(s[r] * p.alpha - lse2) : 0.f;
+                s[r] = pr * (dp[r] - delta);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8_t dsf = pack_frag(s, m);
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_t(KTs, TS, i * 32 + col, D, rt * 32 + 16 * m + 4 * hi), dsf,
+                                                                     acc[i], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < nkb) tile.store(part(buf ^ 1, 0), part(buf ^ 1, 1), part(buf ^ 1, 2), nullptr, D, tid);
+        __syncthreads();
+    }
+    if (q >= p.Nq) return;
+    bf16_t* out = p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = i * 32 + 8 * g + 4 * hi;
+            if (d < D)
+                *(uint2*)(out + d) = make_uint2(pack_bf16x2(acc[i][4 * g] * p.beta, acc[i][4 * g + 1] * p.beta),
+                                                pack_bf16x2(acc[i][4 * g + 2] * p.beta, acc[i][4 * g + 3] * p.beta));
+        }
+}
+
+bool attn_bwd_needs_transposes(int D) { return D > 160; }
 size_t attn_bwd_stats_bytes(int B, int H, int Nq) {
     const size_t npad = (size_t)(Nq + 31) / 32 * 32;
     return 2 * (((size_t)B * H * npad * 4 + 255) & ~(size_t)255);
@@ -660,7 +945,8 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     if (p.D % 8 || p.ldq % 8 || p.ldk % 8 || p.ldv % 8 || p.lddo % 8 || p.ldo % 8 || p.lddq % 4 || p.ldkt % 4 || p.ldqt % 4)
         GYRE_FAIL(-1, "attention_bwd: head dim and row strides must be multiples of 8 elements");
     if (p.B < 1 || p.H < 1 || p.Nq < 1 || p.Nk < 1) GYRE_FAIL(-1, "attention_bwd: empty problem");
-    if (p.ldkt < (p.Nk + 31) / 32 * 32 || (p.dk && p.ldqt < (p.Nq + 31) / 32 * 32))
+    const bool lds_path = !attn_bwd_needs_transposes(p.D);
+    if (!lds_path && (!p.kt || p.ldkt < (p.Nk + 31) / 32 * 32 || (p.dk && (!p.qt || !p.d_ot || p.ldqt < (p.Nq + 31) / 32 * 32))))
         GYRE_FAIL(-1, "attention_bwd: transposed operands need token strides padded to a multiple of 32");
     p.NqPad = (p.Nq + 31) / 32 * 32;
     const size_t half = ((size_t)p.B * p.H * p.NqPad * 4 + 255) & ~(size_t)255;
@@ -673,6 +959,37 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     const size_t nd = (size_t)p.B * p.Nq * p.H;
     hipLaunchKernelGGL(k_attn_bwd_delta, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
+    if (lds_path) {
+        const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : 3));
+        // 32-row LDS tiles: 64-row tiles (RT = 2) were measured slower (2.71 vs 2.14 ms at N = 4096, D = 40: fewer resident
+        // workgroups outweigh the halved barrier count)
+        const size_t lds = 2 * attn_bwd_stage_bytes(p.D, 1);
+        const dim3 gq((unsigned)((p.Nq + 127) / 128), p.H, p.B), gk((unsigned)((p.Nk + 127) / 128), p.H, p.B);
+#define GYRE_ABW_GO(KERN, GRID)                                                                                   \
+        do {                                                                                                          \
+            auto kern = KERN;                                                                                         \
+            static std::atomic<unsigned long long> attr_done{0};                                                      \
+            if (gyre_lds_attr_needed(attr_done))                                                                      \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+            hipLaunchKernelGGL(kern, GRID, dim3(256), lds, st, p);                                                    \
+            GYRE_LAUNCH_CHECK();                                                                                      \
+        } while (0)
+        switch (sel) {
+            case 0: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); break;
+            case 1: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 4, 1>), gq); break;
+            case 2: GYRE_ABW_GO((k_attn_bwd_dq_lds<3, 6, 1>), gq); break;
+            default: GYRE_ABW_GO((k_attn_bwd_dq_lds<5, 10, 1>), gq); break;
+        }
+        if (!p.dk) return 0;
+        switch (sel) {
+            case 0: GYRE_ABW_GO((k_attn_bwd_dkv_lds<2, 3, 1>), gk); break;
+            case 1: GYRE_ABW_GO((k_attn_bwd_dkv_lds<2, 4, 1>), gk); break;
+            case 2: GYRE_ABW_GO((k_attn_bwd_dkv_lds<3, 6, 1>), gk); break;
+            default: GYRE_ABW_GO((k_attn_bwd_dkv_lds<5, 10, 1>), gk); break;
+        }
+#undef GYRE_ABW_GO
+        return 0;
+    }
     const int ndb_total = (p.D + 31) / 32;
     const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : (p.D <= 160 ? 3 : 4)));
     const int ndb = sel <= 1 ? 2 : (sel == 2 ? 3 : (sel == 3 ? 5 : 4));

@@ -149,8 +149,9 @@ int gyre_op_attention_bwd(void* st_, const void* q, int ldq, const void* k, int 
     a.kt = kt; a.ldkt = lk; a.qt = qt; a.d_ot = dot; a.ldqt = lq;
     a.dq = (bf16_t*)dq; a.lddq = lddq; a.dk = (bf16_t*)dk; a.lddk = lddk; a.dv = (bf16_t*)dv; a.lddv = lddv;
     a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = k_prescaled;
-    TRY(launch_transpose(st, a.k, ldk, Nk, C, kt, lk, B, (size_t)Nk * ldk, (size_t)C * lk));
-    if (dk) {
+    const bool need_t = attn_bwd_needs_transposes(D);
+    if (need_t) TRY(launch_transpose(st, a.k, ldk, Nk, C, kt, lk, B, (size_t)Nk * ldk, (size_t)C * lk));
+    if (dk && need_t) {
         TRY(launch_transpose(st, a.q, ldq, Nq, C, qt, lq, B, (size_t)Nq * ldq, (size_t)C * lq));
         TRY(launch_transpose(st, a.d_o, lddo, Nq, C, dot, lq, B, (size_t)Nq * lddo, (size_t)C * lq));
     }

@@ -88,6 +88,7 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
     const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads, M = B * Nq;
     const int Nk = cross ? S : Nq;
     const int ldkt = (Nk + 31) / 32 * 32, ldqt = (Nq + 31) / 32 * 32;
+    const bool need_t = attn_bwd_needs_transposes(D);    // only the register-streaming kernels (D > 160: the VAE block) read K^T / Q^T / dO^T
     Tn d_ao, qkv, kc, vc, kt, qt, dot, dqkv, dv, stats;
     TRY(e.alloc(d_ao, B, xq.H, xq.W, C));
     TRY(linear_bwd(e, d_out.p, C, M, C, w.wo, C, nullptr, 0, d_ao.p, C));
@@ -110,7 +111,7 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
         a.q = qkv.p; a.ldq = C; a.k = kc.p; a.ldk = C; a.v = vc.p; a.ldv = C;
         a.dq = dqkv.p; a.lddq = C; a.dk = nullptr; a.dv = nullptr; a.qt = nullptr; a.d_ot = nullptr; a.ldqt = ldqt;
         if (!e.dry()) {
-            TRY(launch_transpose(e.st, kc.p, C, Nk, C, kt.p, ldkt, B, (size_t)Nk * C, (size_t)C * ldkt));
+            if (need_t) TRY(launch_transpose(e.st, kc.p, C, Nk, C, kt.p, ldkt, B, (size_t)Nk * C, (size_t)C * ldkt));
             TRY(launch_attention_bwd(e.st, a));
         }
         TRY(linear_bwd(e, dqkv.p, C, M, C, w.wq, C, nullptr, 0, d_xq.p, C));
@@ -158,9 +159,11 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
                 TRY(launch_tome_merge(e.st, tp));
                 a.k = km.p; a.ldk = C; a.v = vm.p; a.ldv = C; a.Nk = nout; a.kt = ktm.p; a.ldkt = ldkm;
                 a.dk = dkm.p; a.lddk = C; a.dv = dvm.p; a.lddv = C;
-                TRY(launch_transpose(e.st, km.p, C, nout, C, ktm.p, ldkm, B, (size_t)nout * C, (size_t)C * ldkm));
-                TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
-                TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                if (need_t) {
+                    TRY(launch_transpose(e.st, km.p, C, nout, C, ktm.p, ldkm, B, (size_t)nout * C, (size_t)C * ldkm));
+                    TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
+                    TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                }
                 TRY(launch_attention_bwd(e.st, a));
                 TRY(launch_tome_unmerge(e.st, dkm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + C, W3));
                 TRY(launch_tome_unmerge(e.st, dvm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + 2 * C, W3));
@@ -171,9 +174,11 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
             a.dk = e.dry() ? nullptr : dqkv.p + C; a.lddk = W3;
             a.dv = w.qkv_fused ? (e.dry() ? nullptr : dqkv.p + 2 * C) : dv.p; a.lddv = w.qkv_fused ? W3 : C;
             if (!e.dry()) {
-                TRY(launch_transpose(e.st, qkv.p + C, W3, Nk, C, kt.p, ldkt, B, (size_t)Nk * W3, (size_t)C * ldkt));
-                TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
-                TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                if (need_t) {
+                    TRY(launch_transpose(e.st, qkv.p + C, W3, Nk, C, kt.p, ldkt, B, (size_t)Nk * W3, (size_t)C * ldkt));
+                    TRY(launch_transpose(e.st, qkv.p, W3, Nq, C, qt.p, ldqt, B, (size_t)Nq * W3, (size_t)C * ldqt));
+                    TRY(launch_transpose(e.st, d_ao.p, C, Nq, C, dot.p, ldqt, B, (size_t)Nq * C, (size_t)C * ldqt));
+                }
                 TRY(launch_attention_bwd(e.st, a));
             }
         }
