@@ -151,6 +151,7 @@ int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
     if (!p.x2) p.x2 = p.x;
     int rc = launch_groupnorm_stats(st, f);
     if (rc) return rc;
+    GyreProfScope prof_(KC_NORM_BWD, st, 0.0, (double)p.B * p.HW * p.C * 2.0 * 5.0);     // x, dy twice; dx once
     const int CV = p.C / 8;
     const int TX = CV < 256 ? CV : 256;
     if ((CV + TX - 1) / TX > GNB_MAXV) GYRE_FAIL(-6, "groupnorm_bwd: C too large");
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const bf16_t* __restrict__ x, co
 int launch_layernorm_bwd(hipStream_t st, const bf16_t* x, const bf16_t* dy, int M, int C, const float* gamma, float eps,
                          const bf16_t* addend, bf16_t* dx) {
     if (C % 8 || C > 8 * 64 * LNB_MAXV) GYRE_FAIL(-6, "layernorm_bwd: C must be a multiple of 8 and <= 2048");
+    GyreProfScope prof_(KC_NORM_BWD, st, 0.0, (double)M * C * 2.0 * (addend ? 4.0 : 3.0));
     hipLaunchKernelGGL(k_ln_bwd, dim3((M + 3) / 4), dim3(256), 0, st, x, dy, M, C, gamma, eps, addend, dx);
     GYRE_LAUNCH_CHECK();
     return 0;
@@ -956,6 +958,9 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     p.alpha = p.k_prescaled ? 1.0f : sc * 1.4426950408889634f;
     p.beta = p.k_prescaled ? 0.6931471805599453f : sc;
     GYRE_HIP_CHECK(hipMemsetAsync(p.stats, 0, 2 * half, st));
+    // S, dP, dQ (and dK, dV) products; the recomputation of S / dP in the second kernel and the statistics pass are not counted
+    GyreProfScope prof_(KC_ATTN_BWD, st, (p.dk ? 5.0 : 3.0) * 2.0 * p.B * p.H * (double)p.Nq * p.Nk * p.D,
+                        2.0 * ((double)p.B * p.Nq * p.H * p.D * 4 + (double)p.B * p.Nk * p.H * p.D * (p.dk ? 4 : 2)));
     const size_t nd = (size_t)p.B * p.Nq * p.H;
     hipLaunchKernelGGL(k_attn_bwd_delta, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
