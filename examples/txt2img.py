@@ -4,6 +4,8 @@ without it, random-init SD1.5-shaped weights are used (the output is noise-like,
 
     python examples/txt2img.py --out /tmp/out.png --steps 20 --sampler dpmpp_2m --seeds 1 2
     python examples/txt2img.py --model /models/stable-diffusion-v1-5 --prompt "a (red:1.3) fox" --out fox.png
+    python examples/txt2img.py --clip-guidance 0.3 --tome 1024        # CLIP-guided (native reverse sweeps) + token merging
+    python examples/txt2img.py --model ... --clip-model /models/clip-vit-base-patch32 --clip-guidance 0.3
 """
 import argparse
 import os
@@ -30,6 +32,9 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[512, 512], metavar=("H", "W"))
     ap.add_argument("--cfg", type=float, default=7.5)
     ap.add_argument("--out", default="out.png")
+    ap.add_argument("--clip-guidance", type=float, default=None, help="clip_guidance_scale (reference ClipGuidedMode)")
+    ap.add_argument("--clip-model", default=None, help="transformers CLIPModel folder (default: random-init ViT-B/32)")
+    ap.add_argument("--tome", type=int, default=0, help="ToMe: keys / values merged per self-attention")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = len(args.seeds)
@@ -45,6 +50,21 @@ def main():
         vae = GyreHipVAE(gcfg.sd15_vae()).load_synthetic(1).to(torch.bfloat16).to(dev)
         pipe = GyrePipeline(unet, vae, ClipTextEncoder.synthetic(dev, torch.bfloat16, seed=2), device=dev)
         kw = dict(input_ids=synthetic_prompt_ids(B), negative_ids=empty_prompt_ids(B))
+    if args.tome:
+        pipe.unet.set_tome(args.tome)
+    if args.clip_guidance:
+        from types import SimpleNamespace
+        from transformers import CLIPConfig, CLIPModel
+        from gyre_amd.clipguided import patch_embedding_as_matmul
+        clip = CLIPModel.from_pretrained(args.clip_model) if args.clip_model else CLIPModel(CLIPConfig(projection_dim=512))
+        pipe.clip_model = patch_embedding_as_matmul(clip.eval().to(dev).requires_grad_(False))
+        pipe.feature_extractor = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073],
+                                                 image_std=[0.26862954, 0.26130258, 0.27577711], size={"shortest_edge": 224})
+        if args.model:
+            ids = tok([args.prompt] * B, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        else:
+            ids = synthetic_prompt_ids(B, seed=7)
+        kw.update(clip_guidance_scale=args.clip_guidance, clip_input_ids=ids)
     t0 = time.time()
     img = pipe(seeds=args.seeds, height=args.size[0], width=args.size[1], num_inference_steps=args.steps,
                guidance_scale=args.cfg, sampler=args.sampler, **kw)
