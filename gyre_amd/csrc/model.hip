@@ -209,6 +209,21 @@ int gyre_unet_vjp(gyre_unet* h, void* st, const void* x, int xdt, const int64_t*
                              dxdt, temb_add);
 }
 
+int gyre_unet_vjp_begin(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H, int W,
+                        int S, void* ws, size_t wsb, void* eps_out, int odt, const float* temb_add) {
+    if (!h || !x || !t || !ctx || !ws || !eps_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    for (int d : {xdt, cdt, odt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    g_launches = 0;
+    return gyre_unet_vjp_forward(*h, false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, eps_out, odt, temb_add);
+}
+int gyre_unet_vjp_finish(gyre_unet* h, void* st, const void* d_eps, int ddt, void* dx_out, int dxdt) {
+    if (!h || !d_eps || !dx_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    for (int d : {ddt, dxdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    g_launches = 0;
+    return gyre_unet_vjp_reverse(*h, (hipStream_t)st, d_eps, ddt, dx_out, dxdt);
+}
+
 int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out) {
     if (!cfg || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     GYRE_HIP_CHECK(hipSetDevice(device));

@@ -533,10 +533,28 @@ static void reg_transformer(Store& s, const std::string& p, int c, int heads, in
 // ------------------------------------------------------------------------------------------
 // UNet
 // ------------------------------------------------------------------------------------------
+// Bookkeeping between the forward and the reverse half of a UNet input-gradient call (model_vjp.hip): one node per resnet
+// (+ transformer) of the down / mid / up path or per resampling conv, with the activations its adjoint needs
+struct UNetVjpNode {
+    const ResW* rw = nullptr; const TransW* tw = nullptr; const ConvW* cw = nullptr;
+    Tn x, skip, r, out; bool has_skip = false;
+    ResSave rs; TransSave ts;
+};
+struct UNetVjpState {
+    bool valid = false, dry = false;
+    int B = 0, H = 0, W = 0, S = 0, xin_c = 0;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    std::vector<UNetVjpNode> downs, ups;
+    UNetVjpNode midn, mid1n;
+    std::vector<Tn> skips;
+    Tn h, cx, tp;
+};
+
 struct gyre_unet {
     gyre_unet_cfg cfg;
     Store store;
     Exec ex;
+    UNetVjpState vjp;
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
     bf16_t *te1w, *te2w; float *te1b, *te2b;
@@ -694,6 +712,7 @@ struct gyre_unet {
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
         ex.arena.reset((char*)ws, ws_bytes, dry);
+        vjp.valid = false;                           // the arena is being reused: a pending reverse sweep has lost its activations
         ex.st = st; ex.batch = B;
         Exec& e = ex;
         const int D = c.cross_attention_dim;
@@ -970,5 +989,8 @@ struct gyre_vae {
 int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
                       int B, int H, int W, int S, const void* d_eps, int ddt, void* ws, size_t ws_bytes, void* eps_out, int odt,
                       void* dx_out, int dxdt, const float* temb_add);
+int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
+                          int B, int H, int W, int S, void* ws, size_t ws_bytes, void* eps_out, int odt, const float* temb_add);
+int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt);
 int gyre_vae_run_decode_vjp(gyre_vae& v, bool dry, hipStream_t st, const void* z, int zdt, int B, int h_, int w_, const void* d_img,
                             int ddt, void* ws, size_t wsb, void* img_out, int odt, void* dz_out, int dzdt);

@@ -311,9 +311,12 @@ int conv_in_bwd(Exec& e, const Tn& dh, const ConvW& w, int cin, int cin_pad, voi
 // ------------------------------------------------------------------------------------------
 // UNet: eps = f(x), d_x = (d eps / d x)^T d_eps
 // ------------------------------------------------------------------------------------------
-int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
-                      int B, int H, int W, int S, const void* d_eps, int ddt, void* ws, size_t ws_bytes, void* eps_out, int odt,
-                      void* dx_out, int dxdt, const float* temb_add) {
+// Forward half: runs the UNet keeping what the reverse sweep needs and leaves that bookkeeping in u.vjp (the activations live in
+// the caller's workspace, which must stay untouched until gyre_unet_vjp_reverse; any other call on the handle drops the state).
+int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
+                          int B, int H, int W, int S, void* ws, size_t ws_bytes, void* eps_out, int odt, const float* temb_add) {
+    UNetVjpState& V = u.vjp;
+    V = UNetVjpState();
     const gyre_unet_cfg& c = u.cfg;
     const int n = c.n_levels;
     if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet vjp: empty batch / image / context");
@@ -342,14 +345,10 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
     const float* tproj = (const float*)tp.p;
 
     // ---- forward, keeping what the reverse sweep needs (forward activations are not returned to the arena) ----
-    struct Node {            // resnet (+ transformer) of the down / mid / up path, or a resampling conv
-        const ResW* rw = nullptr; const TransW* tw = nullptr; const ConvW* cw = nullptr;
-        Tn x, skip, r, out; bool has_skip = false;
-        ResSave rs; TransSave ts;
-    };
-    std::vector<Node> downs, ups;
-    Node midn, mid1n;
-    std::vector<Tn> skips;
+    typedef UNetVjpNode Node;
+    std::vector<Node>&downs = V.downs, &ups = V.ups;
+    Node &midn = V.midn, &mid1n = V.mid1n;
+    std::vector<Tn>& skips = V.skips;
     Tn h;
     TRY(e.conv3(xin, u.conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
     skips.push_back(h);
@@ -406,7 +405,27 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
     TRY(e.groupnorm(h, nullptr, u.ong, u.onb, 1e-5f, 1, a));
     TRY(e.conv3_nchw(a, u.conv_out, eps_out, odt));
     e.free(a);
+    V.h = h; V.cx = cx; V.tp = tp; V.xin_c = xin.C;
+    V.B = B; V.H = H; V.W = W; V.S = S; V.ws = ws; V.ws_bytes = ws_bytes; V.dry = dry; V.valid = true;
+    return 0;
+}
 
+// Reverse half: d_x = (d eps / d x)^T d_eps from the state gyre_unet_vjp_forward left behind
+int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt) {
+    UNetVjpState& V = u.vjp;
+    if (!V.valid) GYRE_FAIL(GYRE_ERR_INVALID, "unet vjp: no forward state pending (another call on this handle ran in between)");
+    V.valid = false;                                   // one reverse sweep per forward: gradients are freed as they are consumed
+    const gyre_unet_cfg& c = u.cfg;
+    Exec& e = u.ex;
+    const bool dry = V.dry;
+    const int B = V.B, H = V.H, W = V.W, S = V.S, D = c.cross_attention_dim;
+    e.st = st;
+    std::vector<UNetVjpNode>&downs = V.downs, &ups = V.ups;
+    UNetVjpNode &midn = V.midn, &mid1n = V.mid1n;
+    std::vector<Tn>& skips = V.skips;
+    Tn h = V.h, cx = V.cx, tp = V.tp;
+    const float* tproj = (const float*)tp.p;
+    typedef UNetVjpNode Node;
     // ---- reverse sweep ----
     Tn d_a, dh;
     TRY(conv_out_bwd(e, d_eps, ddt, B, H, W, c.out_channels, u.conv_out, h.C, d_a));
@@ -456,9 +475,17 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
         }
         e.free(dskips[k]);
     }
-    TRY(conv_in_bwd(e, dh, u.conv_in, c.in_channels, xin.C, dx_out, dxdt));
+    TRY(conv_in_bwd(e, dh, u.conv_in, c.in_channels, V.xin_c, dx_out, dxdt));
     e.free(dh);
     return 0;
+}
+
+// one-shot form: forward + reverse in one call (also the dry run that sizes the workspace)
+int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
+                      int B, int H, int W, int S, const void* d_eps, int ddt, void* ws, size_t ws_bytes, void* eps_out, int odt,
+                      void* dx_out, int dxdt, const float* temb_add) {
+    TRY(gyre_unet_vjp_forward(u, dry, st, x, xdt, t, ctx, cdt, B, H, W, S, ws, ws_bytes, eps_out, odt, temb_add));
+    return gyre_unet_vjp_reverse(u, st, d_eps, ddt, dx_out, dxdt);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -356,6 +356,44 @@ class GyreHipUNet(_NativeModule):
                                               C.c_void_p(aug.data_ptr()) if aug is not None else None))
         return out
 
+    def _vjp_begin(self, h, sample, t, encoder_hidden_states, added_cond_kwargs):
+        """Forward pass that leaves the reverse sweep's activations in self._ws_vjp; returns the pending token (id, eps)."""
+        B, _, H, W = sample.shape
+        dev = sample.device
+        x = sample.contiguous()
+        ctx = encoder_hidden_states.to(dev).contiguous()
+        _lib.require_gpu_tensor(x, "latents")
+        S = ctx.shape[1]
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            need = L.gyre_unet_vjp_workspace_bytes(C.c_void_p(h), B, H, W, S)
+            if need == 0:
+                _lib.check(-4)
+            ws = getattr(self, "_ws_vjp", None)
+            if ws is None or ws.device != dev or ws.numel() < need + 256:
+                self._ws_vjp = None
+                self._ws_vjp = ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+            wp = (ws.data_ptr() + 255) & ~255
+            eps = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
+            aug = self._aug_embedding(added_cond_kwargs, B, dev)
+            _lib.check(L.gyre_unet_vjp_begin(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                             _lib.dtype_code(x), C.c_void_p(t.data_ptr()), C.c_void_p(ctx.data_ptr()),
+                                             _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need, C.c_void_p(eps.data_ptr()),
+                                             _lib.dtype_code(eps), C.c_void_p(aug.data_ptr()) if aug is not None else None))
+        self._vjp_pending = token = (object(), eps)
+        return token
+
+    def _vjp_finish(self, h, sample, d_out):
+        dev = sample.device
+        g = d_out.contiguous()
+        _lib.require_gpu_tensor(g, "d_eps")
+        dx = torch.empty_like(sample)
+        self._vjp_pending = None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().gyre_unet_vjp_finish(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(g.data_ptr()),
+                                                       _lib.dtype_code(g), C.c_void_p(dx.data_ptr()), _lib.dtype_code(dx)))
+        return dx
+
     def _vjp_native(self, h, sample, t, encoder_hidden_states, added_cond_kwargs, d_out):
         """(eps, d_sample) from one native call: forward keeping the adjoints' inputs + reverse sweep."""
         B, _, H, W = sample.shape
@@ -385,18 +423,27 @@ class GyreHipUNet(_NativeModule):
 
 
 class _UNetInputGrad(torch.autograd.Function):
-    """autograd node of GyreHipUNet.forward: backward = gyre_unet_vjp (gradient of the sample only)."""
+    """autograd node of GyreHipUNet.forward: the forward pass keeps the activations the adjoints need in a workspace of its
+    own (gyre_unet_vjp_begin), backward runs the reverse sweep on them (gyre_unet_vjp_finish).  If anything else ran on the
+    handle in between, backward recomputes through the one-shot gyre_unet_vjp instead."""
 
     @staticmethod
     def forward(fctx, sample, module, h, t, enc, added):
         fctx.module, fctx.h, fctx.added = module, h, added
         fctx.save_for_backward(sample.detach(), t, enc.detach())
-        return module._forward_native(h, sample.detach(), t, enc.detach(), added)
+        fctx.token = module._vjp_begin(h, sample.detach(), t, enc.detach(), added)
+        return fctx.token[1]
 
     @staticmethod
     def backward(fctx, d_out):
         sample, t, enc = fctx.saved_tensors
-        _, dx = fctx.module._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
+        m = fctx.module
+        if getattr(m, "_vjp_pending", None) is fctx.token:
+            try:
+                return m._vjp_finish(fctx.h, sample, d_out), None, None, None, None, None
+            except ValueError:
+                pass                                   # state dropped by another call on the handle: recompute
+        _, dx = m._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
         return dx, None, None, None, None, None
 
 

@@ -150,6 +150,15 @@ int gyre_unet_vjp(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, c
                   const void* d_eps_nchw, int d_eps_dtype, void* workspace, size_t workspace_bytes,
                   void* eps_out_nchw, int out_dtype, void* dx_out_nchw, int dx_dtype, const float* temb_add);
 
+/* The same in two calls, for an autograd node: _begin runs the forward pass (eps_out as gyre_unet_forward) and keeps the
+ * activations the adjoints need in `workspace` (gyre_unet_vjp_workspace_bytes; must stay untouched), _finish runs the reverse
+ * sweep for a cotangent.  At most one pending pair per handle: any other call on the handle in between drops the state and
+ * _finish then returns GYRE_ERR_INVALID (the caller falls back to gyre_unet_vjp). */
+int gyre_unet_vjp_begin(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
+                        const void* ctx, int ctx_dtype, int B, int H, int W, int S, void* workspace, size_t workspace_bytes,
+                        void* eps_out_nchw, int out_dtype, const float* temb_add);
+int gyre_unet_vjp_finish(gyre_unet* h, void* stream, const void* d_eps_nchw, int d_eps_dtype, void* dx_out_nchw, int dx_dtype);
+
 /* Parity tests only: the next forward copies the named intermediate activation (f32, NCHW) into out.  Names follow
  * the oracle's taps: "down<i>" (end of down level i, after its downsampler), "mid", "up<i>" (end of up level i, after
  * its upsampler).  Taps are cleared by that forward. */

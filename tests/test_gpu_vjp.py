@@ -285,3 +285,25 @@ def test_vjp_batch_one_and_repeatable():
     (b,) = torch.autograd.grad(net(xd, 7, encoder_hidden_states=ctx.to(DEV)).sample, xd, cot.to(DEV))
     report("tiny unet vjp batch 1, 12x20, S=33", a.cpu(), ref, 5e-2)
     assert torch.equal(a, b)
+
+
+def test_vjp_pending_state_is_dropped_by_other_calls_and_recomputed():
+    """Two forwards before the first backward, and a no-grad forward in between: the pending begin / finish state is lost,
+    backward falls back to the one-shot sweep - same gradient either way."""
+    cfg = gcfg.tiny_unet()
+    net, _ = _unet(cfg)
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2).to(DEV)
+    t = torch.tensor([500, 40], device=DEV)
+    cot = randn(2, 4, 16, 16, seed=3).to(DEV)
+    xa, xb = randn(2, 4, 16, 16, seed=1).to(DEV).requires_grad_(), randn(2, 4, 16, 16, seed=9).to(DEV).requires_grad_()
+    (ga_direct,) = torch.autograd.grad(net(xa, t, encoder_hidden_states=ctx).sample, xa, cot)      # begin / finish pair
+    ea = net(xa, t, encoder_hidden_states=ctx).sample
+    eb = net(xb, t, encoder_hidden_states=ctx).sample                                               # overwrites a's state
+    (ga,) = torch.autograd.grad(ea, xa, cot)                                                        # -> recomputed
+    (gb,) = torch.autograd.grad(eb, xb, cot)                                                        # -> pending pair
+    assert torch.equal(ga, ga_direct)
+    ec = net(xb, t, encoder_hidden_states=ctx).sample
+    with torch.no_grad():
+        net(xa, t, encoder_hidden_states=ctx)                                                       # drops the native state
+    (gc,) = torch.autograd.grad(ec, xb, cot)
+    assert torch.equal(gb, gc)
