@@ -84,7 +84,23 @@ struct Store {
     std::vector<std::unique_ptr<Param>> params;
     std::unordered_map<std::string, Param*> by_key;
     std::vector<void*> allocs;
+    // transposed copies of weight matrices for the input-gradient pass (model_vjp.hip), made on first use and refreshed when
+    // any weight was set since (per-request LoRA re-uploads): key = forward weight pointer
+    struct WtEntry { bf16_t* p = nullptr; size_t bytes = 0; uint64_t version = 0; };
+    std::unordered_map<const void*, WtEntry> wt_cache;
+    uint64_t weights_version = 1;
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
+    // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
+    bf16_t* wt_lookup(const void* w, size_t bytes, bool* fresh) {
+        WtEntry& en = wt_cache[w];
+        if (!en.p || en.bytes < bytes) {
+            en.p = (bf16_t*)dmalloc(bytes, false);
+            en.bytes = bytes; en.version = 0;
+        }
+        *fresh = en.p && en.version == weights_version;
+        if (en.p) en.version = weights_version;
+        return en.p;
+    }
     void* dmalloc(size_t bytes, bool zero) {
         void* p = nullptr;
         if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
@@ -162,6 +178,7 @@ struct Store {
             case PK_VEC_GEGLU: TRY(launch_cast_f32(st, src, dtype, (size_t)O, 1, (float*)p.dev)); break;
         }
         p.set = true;
+        ++weights_version;
         return 0;
     }
     int finalize() {
@@ -215,6 +232,7 @@ struct TransSave { std::vector<TBlockSave> blocks; Tn hlast; };     // hlast: re
 struct Exec {
     Arena arena;
     hipStream_t st = nullptr;
+    Store* store = nullptr;   // owner's weight store (transposed-weight cache of the input-gradient pass); null for bare op calls
     int groups = 32;
     std::string fail;
     // cross-attention K / V^T of the current text context, projected once per request (gyre_unet_set_context)
@@ -629,6 +647,7 @@ struct gyre_unet {
         }
         if (c.cross_attention_dim % 8) GYRE_FAIL(GYRE_ERR_INVALID, "cross_attention_dim must be a multiple of 8");
         ex.groups = c.norm_num_groups;
+        ex.store = &store;
         const int c0 = c.block_out_channels[0];
         temb_dim = 4 * c0;
         // total columns of the batched time_emb_proj
@@ -848,6 +867,7 @@ struct gyre_vae {
             if (c.block_out_channels[i] % c.norm_num_groups || c.block_out_channels[i] % 8)
                 GYRE_FAIL(GYRE_ERR_INVALID, "block_out_channels must be multiples of norm_num_groups and 8");
         ex.groups = c.norm_num_groups;
+        ex.store = &store;
         int dummy = 0;
         const int z = c.latent_channels;
         // ---- encoder ----

@@ -7,21 +7,54 @@
 // outputs, attention outputs) + the reverse sweep; nothing survives the call, so the C ABI stays stateless:
 //   gyre_unet_vjp(x, t, ctx, d_eps)        -> eps, d_x
 //   gyre_vae_decode_vjp(z, d_image)        -> image, d_z
-// Transposed weights (W^T for linears, rotated [Cin][3][3][Cout] for convs) are produced into the workspace per use: the
-// whole UNet is 1.7 GB of weights, i.e. well under a millisecond of HBM time per sweep, and nothing has to be kept
-// coherent with gyre_unet_set_weight (per-request LoRA).
+// Transposed weights (W^T for linears, rotated [Cin][3][3][Cout] for convs) are made on first use and kept next to the forward
+// weights (Store::wt_cache, +1.7 GB for SD1.5); every gyre_*_set_weight bumps a version, so a per-request LoRA re-upload
+// refreshes them at the next sweep.  Bare op calls (no model handle) transpose into the workspace instead.
 #include "model_impl.h"
 
 namespace {
 
+// W^T [K][N] of a linear weight W [N][K]: from the owner's cache (transposed once per weight upload) or, for bare op calls,
+// into the arena (tmp is then valid and must be freed by the caller)
+int weight_t_linear(Exec& e, const bf16_t* w, int N, int K, Tn& tmp, const bf16_t** out) {
+    if (e.store) {
+        if (e.dry()) { *out = nullptr; return 0; }
+        bool fresh = false;
+        bf16_t* p = e.store->wt_lookup(w, (size_t)K * N * 2, &fresh);
+        if (!p) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed (transposed weight cache)");
+        if (!fresh) TRY(launch_transpose(e.st, w, K, N, K, p, N, 1, 0, 0));
+        *out = p;
+        return 0;
+    }
+    TRY(e.alloc(tmp, 1, 1, K, N));
+    if (!e.dry()) TRY(launch_transpose(e.st, w, K, N, K, tmp.p, N, 1, 0, 0));
+    *out = tmp.p;
+    return 0;
+}
+// rotated conv weight [cin_pad][3][3][co] of W [co][3][3][cin_pad], same policy
+int weight_t_conv(Exec& e, const bf16_t* w, int co, int cin_pad, Tn& tmp, const bf16_t** out) {
+    if (e.store) {
+        if (e.dry()) { *out = nullptr; return 0; }
+        bool fresh = false;
+        bf16_t* p = e.store->wt_lookup(w, (size_t)cin_pad * 9 * co * 2, &fresh);
+        if (!p) GYRE_FAIL(GYRE_ERR_HIP, "hipMalloc failed (transposed weight cache)");
+        if (!fresh) TRY(launch_conv_weight_t(e.st, w, co, cin_pad, p));
+        *out = p;
+        return 0;
+    }
+    TRY(e.alloc(tmp, 1, cin_pad, 9, co));
+    if (!e.dry()) TRY(launch_conv_weight_t(e.st, w, co, cin_pad, tmp.p));
+    *out = tmp.p;
+    return 0;
+}
+
 // dx[M][K] = dy[M][N] W[N][K]  (+ addend)
 int linear_bwd(Exec& e, const bf16_t* dy, int ldy, int M, int N, const bf16_t* w, int K, const bf16_t* addend, int lda,
                bf16_t* dx, int ldx) {
-    Tn wt;
-    TRY(e.alloc(wt, 1, 1, K, N));
-    if (!e.dry()) TRY(launch_transpose(e.st, w, K, N, K, wt.p, N, 1, 0, 0));
-    int rc = e.linear(dy, ldy, nullptr, 0, 0, M, N, wt.p, K, nullptr, addend, lda, 0, dx, ldx);
-    e.free(wt);
+    Tn tmp; const bf16_t* wt;
+    TRY(weight_t_linear(e, w, N, K, tmp, &wt));
+    int rc = e.linear(dy, ldy, nullptr, 0, 0, M, N, wt, K, nullptr, addend, lda, 0, dx, ldx);
+    e.free(tmp);
     return rc;
 }
 
@@ -30,10 +63,9 @@ int conv3_bwd(Exec& e, const Tn& dy, const ConvW& w, int cin_pad, int stride, in
               Tn& dx) {
     if (stride == 2 && !pad) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "vjp: stride-2 conv without padding (VAE encoder) has no adjoint here");
     const int co = dy.C;                       // pad8(cout)
-    Tn wt;
-    TRY(e.alloc(wt, 1, cin_pad, 9, co));
-    if (!e.dry()) TRY(launch_conv_weight_t(e.st, w.w, co, cin_pad, wt.p));
-    ConvW t{wt.p, nullptr, co, cin_pad};
+    Tn wt; const bf16_t* wtp;
+    TRY(weight_t_conv(e, w.w, co, cin_pad, wt, &wtp));
+    ConvW t{const_cast<bf16_t*>(wtp), nullptr, co, cin_pad};
     if (stride == 2) {
         Tn dz;
         TRY(e.alloc(dz, dy.B, Hx, Wx, co));
@@ -216,14 +248,14 @@ int resnet_bwd(Exec& e, const Tn& x, const Tn* skip, const ResW& w, const float*
         TRY(groupnorm_bwd(e, x, skip, w.n1g, w.n1b, eps, 1, d_a, nullptr, g1, skip ? &g2 : nullptr));
         e.free(d_a);
         const int N = d_out.C, M = x.rows();
-        TRY(e.alloc(wt, 1, 1, cin_tot, N));
-        if (!e.dry()) TRY(launch_transpose(e.st, w.scw, cin_tot, N, cin_tot, wt.p, N, 1, 0, 0));
+        const bf16_t* wtp;
+        TRY(weight_t_linear(e, w.scw, N, cin_tot, wt, &wtp));
         TRY(e.alloc(dx, x.B, x.H, x.W, x.C));
-        TRY(e.linear(d_out.p, N, nullptr, 0, 0, M, N, wt.p, x.C, nullptr, g1.p, x.C, 0, dx.p, x.C));
+        TRY(e.linear(d_out.p, N, nullptr, 0, 0, M, N, wtp, x.C, nullptr, g1.p, x.C, 0, dx.p, x.C));
         e.free(g1);
         if (skip) {
             TRY(e.alloc(*dskip, x.B, x.H, x.W, skip->C));
-            TRY(e.linear(d_out.p, N, nullptr, 0, 0, M, N, e.dry() ? nullptr : wt.p + (size_t)x.C * N, skip->C, nullptr, g2.p, skip->C, 0,
+            TRY(e.linear(d_out.p, N, nullptr, 0, 0, M, N, e.dry() ? nullptr : wtp + (size_t)x.C * N, skip->C, nullptr, g2.p, skip->C, 0,
                          dskip->p, skip->C));
             e.free(g2);
         }
@@ -296,11 +328,10 @@ int conv_out_bwd(Exec& e, const void* d_out, int ddt, int B, int H, int W, int c
 }
 // adjoint of the first conv: gradient of the padded NHWC input, returned to the caller as NCHW
 int conv_in_bwd(Exec& e, const Tn& dh, const ConvW& w, int cin, int cin_pad, void* dx_out, int xdt) {
-    Tn wt;
-    TRY(e.alloc(wt, 1, cin_pad, 9, dh.C));
+    Tn wt; const bf16_t* wtp;
+    TRY(weight_t_conv(e, w.w, dh.C, cin_pad, wt, &wtp));
     if (e.dry()) { e.free(wt); return 0; }
-    TRY(launch_conv_weight_t(e.st, w.w, dh.C, cin_pad, wt.p));
-    ConvW t{wt.p, nullptr, dh.C, cin};
+    ConvW t{const_cast<bf16_t*>(wtp), nullptr, dh.C, cin};
     TRY(e.conv3_nchw(dh, t, dx_out, xdt));
     e.free(wt);
     return 0;
@@ -574,12 +605,11 @@ int gyre_vae_run_decode_vjp(gyre_vae& v, bool dry, hipStream_t st, const void* z
     TRY(conv3_bwd(e, dh, v.d_in, zc, 1, 1, 0, h_, w_, nullptr, dq));
     e.free(dh);
     // post_quant_conv (1x1) adjoint straight to the caller's NCHW buffer
-    Tn wt;
-    TRY(e.alloc(wt, 1, 1, zc, zc));
+    Tn wt; const bf16_t* wtp;
+    TRY(weight_t_linear(e, v.pq_w, zc, zc, wt, &wtp));
     if (!dry) {
-        TRY(launch_transpose(st, v.pq_w, zc, zc, zc, wt.p, zc, 1, 0, 0));
         GemmParams p;
-        p.A = dq.p; p.lda = zc; p.mode = GEMM_LINEAR; p.W = wt.p; p.K = zc; p.N = c.latent_channels; p.M = dq.rows();
+        p.A = dq.p; p.lda = zc; p.mode = GEMM_LINEAR; p.W = wtp; p.K = zc; p.N = c.latent_channels; p.M = dq.rows();
         p.rows_per_sample = h_ * w_; p.out = dz_out; p.out_mode = OUT_NCHW; p.out_dtype = dzdt;
         TRY(launch_gemm(st, p));
     }

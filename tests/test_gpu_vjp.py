@@ -307,3 +307,28 @@ def test_vjp_pending_state_is_dropped_by_other_calls_and_recomputed():
         net(xa, t, encoder_hidden_states=ctx)                                                       # drops the native state
     (gc,) = torch.autograd.grad(ec, xb, cot)
     assert torch.equal(gb, gc)
+
+
+def test_vjp_follows_weight_updates():
+    """the reverse sweep's transposed weights are cached per handle: a re-upload (what a per-request LoRA merge does) must
+    refresh them"""
+    cfg = gcfg.tiny_unet()
+    net, sd = _unet(cfg, seed=0)
+    x = randn(2, 4, 16, 16, seed=1)
+    t = torch.tensor([981, 17])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    cot = randn(2, 4, 16, 16, seed=3)
+
+    def both(state):
+        xr = x.clone().requires_grad_()
+        (ref,) = torch.autograd.grad(M.unet_forward(state, cfg, xr, t, ctx), xr, cot)
+        xd = x.to(DEV).requires_grad_()
+        (got,) = torch.autograd.grad(net(xd, t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample, xd, cot.to(DEV))
+        return got.cpu(), ref
+    g0, r0 = both(sd)
+    report("vjp before the weight update", g0, r0, 5e-2)
+    sd2 = weights.synthetic_state_dict(weights.unet_param_shapes(cfg), 7)
+    net.load_state_dict(sd2)
+    g1, r1 = both(sd2)
+    report("vjp after the weight update", g1, r1, 5e-2)
+    assert float((r1 - r0).norm() / r0.norm()) > 0.1          # the two weight sets really give different gradients
