@@ -5,6 +5,7 @@
 
 // ---- layout / small ops (kernels_elem.hip) ----------------------------------
 int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
+int launch_add_nchw_into_nhwc(hipStream_t st, const void* r, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
 int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_t* y);
 int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n);
 int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);

@@ -41,6 +41,28 @@ int launch_nhwc_to_nchw_f32(hipStream_t st, const bf16_t* x, int B, int C, int H
     GYRE_LAUNCH_CHECK();
     return 0;
 }
+// y[b][p][c] += r[b][c][p]  (ControlNet residuals arrive NCHW from host PyTorch; one bf16 rounding of the fp32 sum)
+__global__ void k_add_nchw_into_nhwc(const void* __restrict__ r, int dtype, int C, int HW, int Cpad, bf16_t* __restrict__ y,
+                                     size_t total_pix) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total_pix) return;
+    size_t n = pix / HW, p = pix % HW;
+    const size_t base = n * (size_t)C * HW + p;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float f[8];
+        unpack8(*(const uint4*)(y + pix * Cpad + c0), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < C) f[j] += load_as_f32(r, dtype, base + (size_t)(c0 + j) * HW);
+        *(uint4*)(y + pix * Cpad + c0) = pack8(f);
+    }
+}
+int launch_add_nchw_into_nhwc(hipStream_t st, const void* r, int dtype, int B, int C, int HW, int Cpad, bf16_t* y) {
+    size_t total = (size_t)B * HW;
+    hipLaunchKernelGGL(k_add_nchw_into_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r, dtype, C, HW, Cpad, y, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
 int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y) {
     size_t total = (size_t)B * HW;
     hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, dtype, C, HW, Cpad, y,

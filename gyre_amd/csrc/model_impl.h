@@ -724,9 +724,14 @@ struct gyre_unet {
         return 0;
     }
 
+    // ControlNet-style residual injection (reference gyre/pipeline/controlnet/unet_patcher.py:30-95, fed by
+    // unet/core.py:40-64): down_res[k] (NCHW, shape of the k-th skip connection in the order they are produced, conv_in
+    // first) is added to the skip tensor the UP path consumes, mid_res to the mid block's output; the down path and the mid
+    // block themselves run on the un-augmented activations.
     int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
             int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr,
-            bool use_ctx_cache = false) {
+            bool use_ctx_cache = false, const void* const* down_res = nullptr, int n_down_res = 0, int rdt = 0,
+            const void* mid_res = nullptr) {
         const gyre_unet_cfg& c = cfg;
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
@@ -801,6 +806,18 @@ struct gyre_unet {
             e.free(b2);
             TRY(tap("mid", h, c.block_out_channels[n - 1]));
         }
+        if (down_res) {
+            if (n_down_res != (int)skips.size())
+                GYRE_FAIL(GYRE_ERR_INVALID, "unet: " + std::to_string(skips.size()) + " down-block residuals expected, got " +
+                          std::to_string(n_down_res));
+            if (!dry)
+                for (size_t k = 0; k < skips.size(); ++k) {
+                    if (!down_res[k]) GYRE_FAIL(GYRE_ERR_INVALID, "unet: null down-block residual");
+                    const Tn& sk = skips[k];
+                    TRY(launch_add_nchw_into_nhwc(st, down_res[k], rdt, B, sk.C, sk.H * sk.W, sk.C, sk.p));
+                }
+        }
+        if (mid_res && !dry) TRY(launch_add_nchw_into_nhwc(st, mid_res, rdt, B, h.C, h.H * h.W, h.C, h.p));
         for (int i = 0; i < n; ++i) {
             const int lvl = n - 1 - i;
             for (int j = 0; j < c.layers_per_block + 1; ++j) {

@@ -278,9 +278,8 @@ class GyreHipUNet(_NativeModule):
                  mid_block_additional_residual, adapter_states):
         if encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states is required")
-        if down_block_additional_residuals is not None or mid_block_additional_residual is not None \
-                or adapter_states is not None:
-            raise NotImplementedError("ControlNet / T2I residual injection is outside the native hot path")
+        if adapter_states is not None:
+            raise NotImplementedError("T2I-adapter state injection is outside the native hot path")
         if sample.ndim != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"expected latents [B,{self.config.in_channels},H,W], got {tuple(sample.shape)}")
         B = sample.shape[0]
@@ -314,14 +313,21 @@ class GyreHipUNet(_NativeModule):
         (gyre_unet_vjp); weights and the text context never receive gradients."""
         h, t = self._prepare(sample, timestep, encoder_hidden_states, down_block_additional_residuals,
                              mid_block_additional_residual, adapter_states)
+        residuals = None
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            # ControlNet outputs (reference unet/core.py:40-64): host tensors in NCHW, added natively to the skip connections
+            # the up path consumes / to the mid block's output (controlnet/unet_patcher.py:30-95)
+            residuals = (list(down_block_additional_residuals or []), mid_block_additional_residual)
         if torch.is_grad_enabled() and sample.requires_grad:
+            if residuals is not None:
+                raise NotImplementedError("input gradients through ControlNet residuals (CLIP guidance + ControlNet)")
             out = _UNetInputGrad.apply(sample, self, h, t, encoder_hidden_states, added_cond_kwargs)
         else:
             with torch.no_grad():
-                out = self._forward_native(h, sample, t, encoder_hidden_states, added_cond_kwargs)
+                out = self._forward_native(h, sample, t, encoder_hidden_states, added_cond_kwargs, residuals)
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
-    def _forward_native(self, h, sample, t, encoder_hidden_states, added_cond_kwargs):
+    def _forward_native(self, h, sample, t, encoder_hidden_states, added_cond_kwargs, residuals=None):
         B, _, H, W = sample.shape
         dev = sample.device
         x = sample.contiguous()
@@ -349,11 +355,27 @@ class GyreHipUNet(_NativeModule):
             wp = (ws.data_ptr() + 255) & ~255
             out = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
             aug = self._aug_embedding(added_cond_kwargs, B, dev)
-            _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
-                                              _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None,
-                                              _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
-                                              C.c_void_p(out.data_ptr()), _lib.dtype_code(out),
-                                              C.c_void_p(aug.data_ptr()) if aug is not None else None))
+            augp = C.c_void_p(aug.data_ptr()) if aug is not None else None
+            if residuals is None:
+                _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                                  _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None,
+                                                  _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
+                                                  C.c_void_p(out.data_ptr()), _lib.dtype_code(out), augp))
+            else:
+                down, mid = residuals
+                rdt = (down[0] if down else mid).dtype
+                keep = [r.to(dev, rdt).contiguous() for r in down]             # alive until the call has been enqueued
+                for r in keep:
+                    if r.ndim != 4 or r.shape[0] != B:
+                        raise ValueError(f"down-block residuals must be [B,C,h,w] with B={B}, got {tuple(r.shape)}")
+                midk = mid.to(dev, rdt).contiguous() if mid is not None else None
+                arr = (C.c_void_p * max(len(keep), 1))(*[r.data_ptr() for r in keep])
+                _lib.check(L.gyre_unet_forward_ctrl(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
+                                                    _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None, _lib.dtype_code(ctx),
+                                                    B, H, W, S, C.c_void_p(wp), need, C.c_void_p(out.data_ptr()),
+                                                    _lib.dtype_code(out), augp, arr, len(keep), _lib.dtype_code(keep[0] if keep else midk),
+                                                    C.c_void_p(midk.data_ptr()) if midk is not None else None))
+                self._residual_keep = (keep, midk)
         return out
 
     def _vjp_begin(self, h, sample, t, encoder_hidden_states, added_cond_kwargs):

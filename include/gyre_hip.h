@@ -137,6 +137,16 @@ int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_d
  * algorithm lives in the un-vendored facebookresearch/ToMe submodule; restated from the paper, parity unpinned. */
 int gyre_unet_set_tome(gyre_unet* h, int r);
 
+/* gyre_unet_forward_ex plus ControlNet-style residual injection - the optional keyword arguments of the reference's UNet call,
+ * unet/core.py:40-64 (`down_block_additional_residuals`, `mid_block_additional_residual`) with the semantics of the in-tree
+ * patcher controlnet/unet_patcher.py:30-95: down_res[k] (NCHW, dev, res_dtype; one per skip connection in production order,
+ * conv_in's output first - 12 for SD1.x) is added to the skip tensor the up path consumes, mid_res to the mid block's output.
+ * n_down_res == 0 / mid_res == NULL switch either off. */
+int gyre_unet_forward_ctrl(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
+                           const void* ctx, int ctx_dtype, int B, int H, int W, int S,
+                           void* workspace, size_t workspace_bytes, void* eps_out_nchw, int out_dtype, const float* temb_add,
+                           const void* const* down_res, int n_down_res, int res_dtype, const void* mid_res);
+
 /* Input gradient (vector-Jacobian product) of the noise prediction: one call runs the forward pass, writes
  * eps_out_nchw like gyre_unet_forward, and writes dx_out_nchw[B, in_channels, H, W] = (d eps / d x)^T d_eps.
  * Replaces what autograd does in the reference's CLIP-guided mode, gyre/pipeline/unet/clipguided.py:301-338

@@ -183,9 +183,13 @@ def added_cond_embedding(sd: SD, cfg, text_embeds: Tensor, time_ids: Tensor) -> 
 
 
 def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder_hidden_states: Tensor,
-                 taps: Optional[dict] = None, added_cond: Optional[dict] = None, tome_r: int = 0) -> Tensor:
+                 taps: Optional[dict] = None, added_cond: Optional[dict] = None, tome_r: int = 0,
+                 down_res: Optional[Sequence[Tensor]] = None, mid_res: Optional[Tensor] = None) -> Tensor:
     """eps = unet(latents[NCHW], t[int64 N], ctx[N,S,D]).  ``taps`` (optional dict)
-    receives named intermediate activations for block-level parity tests."""
+    receives named intermediate activations for block-level parity tests.
+    down_res / mid_res: ControlNet residuals with the semantics of the reference's in-tree patcher
+    (gyre/pipeline/controlnet/unet_patcher.py:30-95): added to the skip connections as the UP path consumes them
+    (`res_sample + extra`) and to the mid block's output; the down path and the mid block see the plain activations."""
     g, eps = cfg.norm_num_groups, 1e-5
     boc = cfg.block_out_channels
     if t.ndim == 0:
@@ -220,6 +224,12 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
     h = resnet_block(h, temb, sd, "mid_block.resnets.1", g, eps)
     if taps is not None:
         taps["mid"] = h
+    if down_res is not None:
+        if len(down_res) != len(skips):
+            raise ValueError(f"{len(skips)} down-block residuals expected, got {len(down_res)}")
+        skips = [s_ + r for s_, r in zip(skips, down_res)]
+    if mid_res is not None:
+        h = h + mid_res
 
     for i in range(nlev):
         lvl = nlev - 1 - i

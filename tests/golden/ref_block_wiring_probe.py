@@ -113,58 +113,117 @@ def main():
     temb = taps["temb"]
     res = lambda p_: (lambda h, te=None: M.resnet_block(h, temb, sd, p_, g, eps))
     n = len(boc)
-    h = M._conv(x, sd, "conv_in")
-    skips = (h,)
-    level_err = {}
-    for i in range(n):
-        pre = f"down_blocks.{i}"
-        down = None if i == n - 1 else [lambda hh, i=i: M._conv(hh, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)]
-        resnets = [res(f"{pre}.resnets.{j}") for j in range(cfg.layers_per_block)]
-        if cfg.attn_levels[i]:
-            blk = make(T.ToMeDownBlock, resnets=resnets, downsamplers=down, training=False, gradient_checkpointing=False,
-                       attentions=[ref_spatial(f"{pre}.attentions.{j}", cfg.num_heads[i], cfg.transformer_depth[i])
-                                   for j in range(cfg.layers_per_block)])
-            h, states, _ = T.ToMeDownBlock.forward(blk, h, temb, ctx)
-        else:                                   # DownBlock2D has no vendored copy: same loop without the attentions
-            states = ()
-            for r_ in resnets:
-                h = r_(h, temb)
-                states += (h,)
-            if down is not None:
-                h = down[0](h)
-                states += (h,)
-        skips += states
-        level_err[f"down{i}"] = float((h - taps[f"down{i}"]).abs().max())
-    mid = make(T.ToMeMidBlock, resnets=[res("mid_block.resnets.0"), res("mid_block.resnets.1")],
-               attentions=[ref_spatial("mid_block.attentions.0", cfg.num_heads[-1], cfg.transformer_depth[-1])])
-    h, _ = T.ToMeMidBlock.forward(mid, h, temb, ctx)
-    level_err["mid"] = float((h - taps["mid"]).abs().max())
-    for i in range(n):
-        lvl = n - 1 - i
-        pre = f"up_blocks.{i}"
-        k = cfg.layers_per_block + 1
-        res_tuple, skips = skips[-k:], skips[:-k]
-        ups = None
-        if i < n - 1:
-            tgt = skips[-1].shape[-2:]
-            ups = [lambda hh, size=None, i=i, tgt=tgt: M._conv(F.interpolate(hh, size=tgt, mode="nearest"), sd, f"up_blocks.{i}.upsamplers.0.conv")]
-        resnets = [res(f"{pre}.resnets.{j}") for j in range(k)]
-        if cfg.attn_levels[lvl]:
-            blk = make(T.ToMeUpBlock, resnets=resnets, upsamplers=ups, training=False, gradient_checkpointing=False,
-                       attentions=[ref_spatial(f"{pre}.attentions.{j}", cfg.num_heads[lvl], cfg.transformer_depth[lvl]) for j in range(k)])
-            h, _ = T.ToMeUpBlock.forward(blk, h, res_tuple, temb, ctx)
-        else:                                   # UpBlock2D: the vendored CrossAttnUpBlock2D loop without the attentions
-            for r_ in resnets:
-                h = r_(torch.cat([h, res_tuple[-1]], dim=1), temb)
-                res_tuple = res_tuple[:-1]
-            if ups is not None:
-                h = ups[0](h)
-        level_err[f"up{i}"] = float((h - taps[f"up{i}"]).abs().max())
-    h = M._conv(F.silu(M._gn(h, sd, "conv_norm_out", g, eps)), sd, "conv_out")
+
+    class UpBlock2D:                           # UpBlock2D has no vendored copy: the vendored CrossAttnUpBlock2D loop without attentions
+        def __init__(self, resnets, ups):
+            self.resnets, self.upsamplers = resnets, ups
+
+        def __call__(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, upsample_size=None):
+            for r_ in self.resnets:
+                hidden_states = r_(torch.cat([hidden_states, res_hidden_states_tuple[-1]], dim=1), temb)
+                res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+            if self.upsamplers is not None:
+                hidden_states = self.upsamplers[0](hidden_states)
+            return hidden_states
+
+    def trunk(down_res=None, mid_res=None, want_taps=None):
+        h = M._conv(x, sd, "conv_in")
+        skips = (h,)
+        level_err = {}
+        for i in range(n):
+            pre = f"down_blocks.{i}"
+            down = None if i == n - 1 else [lambda hh, i=i: M._conv(hh, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)]
+            resnets = [res(f"{pre}.resnets.{j}") for j in range(cfg.layers_per_block)]
+            if cfg.attn_levels[i]:
+                blk = make(T.ToMeDownBlock, resnets=resnets, downsamplers=down, training=False, gradient_checkpointing=False,
+                           attentions=[ref_spatial(f"{pre}.attentions.{j}", cfg.num_heads[i], cfg.transformer_depth[i])
+                                       for j in range(cfg.layers_per_block)])
+                h, states, _ = T.ToMeDownBlock.forward(blk, h, temb, ctx)
+            else:                               # DownBlock2D has no vendored copy: same loop without the attentions
+                states = ()
+                for r_ in resnets:
+                    h = r_(h, temb)
+                    states += (h,)
+                if down is not None:
+                    h = down[0](h)
+                    states += (h,)
+            skips += states
+            if want_taps is not None:
+                level_err[f"down{i}"] = float((h - want_taps[f"down{i}"]).abs().max())
+        mid_obj = make(T.ToMeMidBlock, resnets=[res("mid_block.resnets.0"), res("mid_block.resnets.1")],
+                       attentions=[ref_spatial("mid_block.attentions.0", cfg.num_heads[-1], cfg.transformer_depth[-1])])
+        mid_block = lambda hh, te, c_: T.ToMeMidBlock.forward(mid_obj, hh, te, c_)[0]
+        up_blocks = []
+        sizes = [s_.shape[-2:] for s_ in skips]
+        consumed = len(skips)
+        for i in range(n):
+            lvl = n - 1 - i
+            pre = f"up_blocks.{i}"
+            k = cfg.layers_per_block + 1
+            consumed -= k
+            ups = None
+            if i < n - 1:
+                tgt = sizes[consumed - 1]
+                ups = [lambda hh, size=None, i=i, tgt=tgt: M._conv(F.interpolate(hh, size=tgt, mode="nearest"), sd, f"up_blocks.{i}.upsamplers.0.conv")]
+            resnets = [res(f"{pre}.resnets.{j}") for j in range(k)]
+            if cfg.attn_levels[lvl]:
+                blk = make(T.ToMeUpBlock, resnets=resnets, upsamplers=ups, training=False, gradient_checkpointing=False,
+                           attentions=[ref_spatial(f"{pre}.attentions.{j}", cfg.num_heads[lvl], cfg.transformer_depth[lvl]) for j in range(k)])
+                up_blocks.append((lambda blk: (lambda hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None, upsample_size=None:
+                                               T.ToMeUpBlock.forward(blk, hidden_states, res_hidden_states_tuple, temb, encoder_hidden_states)[0]))(blk))
+                up_blocks[-1].resnets = resnets
+            else:
+                up_blocks.append(UpBlock2D(resnets, ups))
+        if down_res is not None or mid_res is not None:
+            # the reference's OWN ControlNet patcher (gyre/pipeline/controlnet/unet_patcher.py:60-95) rewires the up / mid blocks
+            from gyre.pipeline.controlnet import unet_patcher as P
+
+            class Callable(torch.nn.Module):
+                def __init__(self, fn, resnets=None):
+                    super().__init__()
+                    self.fn = fn
+                    if resnets is not None:
+                        self.resnets = resnets
+
+                def forward(self, *a, **k):
+                    return self.fn(*a, **k)
+            plain_mid = mid_block
+            module = SimpleNamespace(up_blocks=[Callable(b, b.resnets) for b in up_blocks], mid_block=Callable(plain_mid))
+            hook = P.UNet2DConditionModelHook()
+            hook.pre_forward(module, down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res)
+            up_blocks, mid_block = list(module.up_blocks), module.mid_block
+        h = mid_block(h, temb, ctx)
+        if want_taps is not None:
+            level_err["mid"] = float((h - want_taps["mid"]).abs().max())
+        for i in range(n):
+            k = cfg.layers_per_block + 1
+            res_tuple, skips = skips[-k:], skips[:-k]
+            h = up_blocks[i](hidden_states=h, res_hidden_states_tuple=res_tuple, temb=temb, encoder_hidden_states=ctx)
+            if want_taps is not None:
+                level_err[f"up{i}"] = float((h - want_taps[f"up{i}"]).abs().max())
+        h = M._conv(F.silu(M._gn(h, sd, "conv_norm_out", g, eps)), sd, "conv_out")
+        return h, level_err, len(skips) == 0
+
+    h, level_err, consumed_all = trunk(want_taps=taps)
     out["levels_max_abs"] = level_err
     out["unet_out_max_abs"] = float((h - ref_out).abs().max())
     out["unet_out_absmax"] = float(ref_out.abs().max())
-    out["skips_consumed"] = len(skips) == 0
+    out["skips_consumed"] = consumed_all
+
+    # ---- ControlNet residual injection: the reference's patcher vs the oracle's down_res / mid_res -------------------------
+    shapes, hh, ww = [(boc[0], 16, 16)], 16, 16
+    for i, c_ in enumerate(boc):
+        shapes += [(c_, hh, ww)] * cfg.layers_per_block
+        if i < n - 1:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            shapes.append((c_, hh, ww))
+    gen = torch.Generator().manual_seed(11)
+    down_res = [torch.randn(2, *s_, generator=gen) * 0.5 for s_ in shapes]
+    mid_res = torch.randn(2, boc[-1], hh, ww, generator=gen) * 0.5
+    want = M.unet_forward(sd, cfg, x, t, ctx, down_res=down_res, mid_res=mid_res)
+    got, _, _ = trunk(down_res=list(down_res), mid_res=mid_res)
+    out["controlnet_patcher_max_abs"] = float((got - want).abs().max())
+    out["controlnet_effect"] = float((want - ref_out).abs().max())
     print("PROBE_JSON " + json.dumps(out))
 
 

@@ -82,7 +82,7 @@ def test_unet_errors():
     out = net(randn(1, 4, 12, 12).to(DEV), 1, encoder_hidden_states=ctx).sample  # not a multiple of 8: fine (diffusers too)
     assert out.shape == (1, 4, 12, 12) and bool(torch.isfinite(out).all())
     with pytest.raises(NotImplementedError):
-        net(x, 1, encoder_hidden_states=ctx, mid_block_additional_residual=x)
+        net(x, 1, encoder_hidden_states=ctx, adapter_states=[x])
     with pytest.raises(RuntimeError):
         GyreHipUNet(cfg)(x.cpu(), 1, encoder_hidden_states=ctx.cpu())  # no CPU fallback
 
@@ -277,3 +277,35 @@ def test_sd15_unet_tome_full_size_properties():
     rel = float((a - base).norm() / base.norm())
     print(f"[property] SD1.5 UNet with ToMe r=1024 vs without: rel-L2 {rel:.3e}")
     assert 1e-4 < rel < 0.5
+
+
+def test_tiny_unet_controlnet_residual_injection():
+    """`down_block_additional_residuals` / `mid_block_additional_residual` (reference unet/core.py:40-64; semantics of the
+    in-tree patcher controlnet/unet_patcher.py:30-95) on the native path vs the oracle"""
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 16, 24, seed=1)
+    t = torch.tensor([981, 17])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=2)
+    taps = {}
+    plain = M.unet_forward(sd, cfg, x, t, ctx, taps=taps)
+    # skip shapes in production order: conv_in, then per level layers_per_block resnets (+ the downsampler except at the last)
+    shapes, hh, ww = [(cfg.block_out_channels[0], 16, 24)], 16, 24
+    for i, c in enumerate(cfg.block_out_channels):
+        shapes += [(c, hh, ww)] * cfg.layers_per_block
+        if i < len(cfg.block_out_channels) - 1:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            shapes.append((c, hh, ww))
+    down = [randn(2, *s, seed=10 + k) * 0.5 for k, s in enumerate(shapes)]
+    mid = randn(2, cfg.block_out_channels[-1], hh, ww, seed=99) * 0.5
+    ref = M.unet_forward(sd, cfg, x, t, ctx, down_res=down, mid_res=mid)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), down_block_additional_residuals=[d.to(DEV) for d in down],
+              mid_block_additional_residual=mid.to(DEV)).sample
+    report("tiny unet + ControlNet residuals", got.cpu(), ref, 3e-2)
+    assert float((ref - plain).norm() / plain.norm()) > 0.05              # the residuals matter
+    only_mid = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), mid_block_additional_residual=mid.to(DEV, torch.bfloat16)).sample
+    report("tiny unet + mid residual only (bf16 residual)", only_mid.cpu(), M.unet_forward(sd, cfg, x, t, ctx, mid_res=mid), 3e-2)
+    with pytest.raises(ValueError):
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), down_block_additional_residuals=[d.to(DEV) for d in down[:-1]])
+    with pytest.raises(NotImplementedError):
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[down[0]])

@@ -32,3 +32,6 @@ def test_oracle_assembly_equals_the_reference_block_forwards():
     assert set(out["levels_max_abs"]) == {"down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3"}
     assert max(out["levels_max_abs"].values()) <= tol
     assert out["unet_out_max_abs"] <= tol and out["unet_out_absmax"] > 0.5 and out["skips_consumed"]
+    # ControlNet residual injection: the reference's own patcher (controlnet/unet_patcher.py:60-95 UNet2DConditionModelHook.pre_forward,
+    # UpBlockWrapper, MidBlockWrapper) rewires that trunk; the oracle's down_res / mid_res must give the same output
+    assert out["controlnet_patcher_max_abs"] <= tol and out["controlnet_effect"] > 0.1
