@@ -56,7 +56,7 @@ _SIGS = {
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_unet_forward_ctrl": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp,
-                                    C.POINTER(_vp), _i, _i, _vp]),
+                                    C.POINTER(_vp), _i, _i, _vp, C.POINTER(_vp), _i]),
     "gyre_unet_vjp_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_unet_vjp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i, _vp]),
     "gyre_unet_vjp_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),

@@ -189,14 +189,17 @@ int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const i
 }
 int gyre_unet_forward_ctrl(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                            int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add,
-                           const void* const* down_res, int n_down_res, int rdt, const void* mid_res) {
+                           const void* const* down_res, int n_down_res, int rdt, const void* mid_res,
+                           const void* const* adapter_states, int n_adapter_states) {
     if (!h || !x || !t || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     for (int d : {xdt, cdt, odt, rdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
-    if (n_down_res < 0 || (n_down_res > 0 && !down_res)) GYRE_FAIL(GYRE_ERR_INVALID, "bad residual list");
+    if (n_down_res < 0 || (n_down_res > 0 && !down_res) || n_adapter_states < 0 || (n_adapter_states > 0 && !adapter_states))
+        GYRE_FAIL(GYRE_ERR_INVALID, "bad residual list");
     g_launches = 0;
     return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr,
-                  n_down_res ? down_res : nullptr, n_down_res, rdt, mid_res);
+                  n_down_res ? down_res : nullptr, n_down_res, rdt, mid_res, n_adapter_states ? adapter_states : nullptr,
+                  n_adapter_states);
 }
 int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                       int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {

@@ -731,7 +731,13 @@ struct gyre_unet {
     int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
             int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr,
             bool use_ctx_cache = false, const void* const* down_res = nullptr, int n_down_res = 0, int rdt = 0,
-            const void* mid_res = nullptr) {
+            const void* mid_res = nullptr, const void* const* adapter = nullptr, int n_adapter = 0) {
+        // T2I-adapter states (reference gyre/pipeline/t2i_adapter/unet_patcher.py:21-86, fed by unet/core.py:212-216): one
+        // NCHW tensor per down level, added IN PLACE to the level's last hidden state - just before its downsampler for the
+        // cross-attention levels (so the skip connection taken there, the downsampler and everything after see it), after
+        // the whole level (downsampler included) otherwise.
+        if (adapter && n_adapter != cfg.n_levels)
+            GYRE_FAIL(GYRE_ERR_INVALID, "unet: one adapter state per down level expected (" + std::to_string(cfg.n_levels) + ")");
         const gyre_unet_cfg& c = cfg;
         const int n = c.n_levels;
         if (B < 1 || H < 1 || W < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty batch / image / context");
@@ -790,11 +796,20 @@ struct gyre_unet {
                 }
                 skips.push_back(r);
             }
+            const bool adapt_before = adapter && (c.attn_levels[i] || !down[i].has_resample);
+            auto adapt = [&]() -> int {
+                if (dry) return 0;
+                if (!adapter[i]) GYRE_FAIL(GYRE_ERR_INVALID, "unet: null adapter state");
+                const Tn& s_ = skips.back();
+                return launch_add_nchw_into_nhwc(st, adapter[i], rdt, B, s_.C, s_.H * s_.W, s_.C, s_.p);
+            };
+            if (adapt_before) TRY(adapt());
             if (down[i].has_resample) {
                 Tn d;
                 TRY(e.conv3(skips.back(), down[i].resample, 2, 1, 0, nullptr, 0, nullptr, d));
                 skips.push_back(d);
             }
+            if (adapter && !adapt_before) TRY(adapt());
             TRY(tap("down" + std::to_string(i), skips.back(), c.block_out_channels[i]));
         }
         {

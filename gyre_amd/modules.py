@@ -278,8 +278,8 @@ class GyreHipUNet(_NativeModule):
                  mid_block_additional_residual, adapter_states):
         if encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states is required")
-        if adapter_states is not None:
-            raise NotImplementedError("T2I-adapter state injection is outside the native hot path")
+        if adapter_states is not None and any(not isinstance(a, torch.Tensor) for a in adapter_states):
+            raise NotImplementedError("nested / style T2I-adapter states")
         if sample.ndim != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"expected latents [B,{self.config.in_channels},H,W], got {tuple(sample.shape)}")
         B = sample.shape[0]
@@ -314,10 +314,11 @@ class GyreHipUNet(_NativeModule):
         h, t = self._prepare(sample, timestep, encoder_hidden_states, down_block_additional_residuals,
                              mid_block_additional_residual, adapter_states)
         residuals = None
-        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None or adapter_states:
             # ControlNet outputs (reference unet/core.py:40-64): host tensors in NCHW, added natively to the skip connections
-            # the up path consumes / to the mid block's output (controlnet/unet_patcher.py:30-95)
-            residuals = (list(down_block_additional_residuals or []), mid_block_additional_residual)
+            # the up path consumes / to the mid block's output (controlnet/unet_patcher.py:30-95); T2I-adapter states
+            # (unet/core.py:212-216): one per down level, added in place inside the down path (t2i_adapter/unet_patcher.py)
+            residuals = (list(down_block_additional_residuals or []), mid_block_additional_residual, list(adapter_states or []))
         if torch.is_grad_enabled() and sample.requires_grad:
             if residuals is not None:
                 raise NotImplementedError("input gradients through ControlNet residuals (CLIP guidance + ControlNet)")
@@ -362,20 +363,23 @@ class GyreHipUNet(_NativeModule):
                                                   _lib.dtype_code(ctx), B, H, W, S, C.c_void_p(wp), need,
                                                   C.c_void_p(out.data_ptr()), _lib.dtype_code(out), augp))
             else:
-                down, mid = residuals
-                rdt = (down[0] if down else mid).dtype
+                down, mid, adapt = residuals
+                rdt = (down[0] if down else (mid if mid is not None else adapt[0])).dtype
                 keep = [r.to(dev, rdt).contiguous() for r in down]             # alive until the call has been enqueued
-                for r in keep:
+                akeep = [r.to(dev, rdt).contiguous() for r in adapt]
+                for r in keep + akeep:
                     if r.ndim != 4 or r.shape[0] != B:
-                        raise ValueError(f"down-block residuals must be [B,C,h,w] with B={B}, got {tuple(r.shape)}")
+                        raise ValueError(f"residual / adapter tensors must be [B,C,h,w] with B={B}, got {tuple(r.shape)}")
                 midk = mid.to(dev, rdt).contiguous() if mid is not None else None
                 arr = (C.c_void_p * max(len(keep), 1))(*[r.data_ptr() for r in keep])
+                aarr = (C.c_void_p * max(len(akeep), 1))(*[r.data_ptr() for r in akeep])
                 _lib.check(L.gyre_unet_forward_ctrl(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
                                                     _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None, _lib.dtype_code(ctx),
                                                     B, H, W, S, C.c_void_p(wp), need, C.c_void_p(out.data_ptr()),
-                                                    _lib.dtype_code(out), augp, arr, len(keep), _lib.dtype_code(keep[0] if keep else midk),
-                                                    C.c_void_p(midk.data_ptr()) if midk is not None else None))
-                self._residual_keep = (keep, midk)
+                                                    _lib.dtype_code(out), augp, arr, len(keep),
+                                                    _lib.dtype_code(keep[0] if keep else (midk if midk is not None else akeep[0])),
+                                                    C.c_void_p(midk.data_ptr()) if midk is not None else None, aarr, len(akeep)))
+                self._residual_keep = (keep, midk, akeep)
         return out
 
     def _vjp_begin(self, h, sample, t, encoder_hidden_states, added_cond_kwargs):

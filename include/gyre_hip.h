@@ -141,11 +141,15 @@ int gyre_unet_set_tome(gyre_unet* h, int r);
  * unet/core.py:40-64 (`down_block_additional_residuals`, `mid_block_additional_residual`) with the semantics of the in-tree
  * patcher controlnet/unet_patcher.py:30-95: down_res[k] (NCHW, dev, res_dtype; one per skip connection in production order,
  * conv_in's output first - 12 for SD1.x) is added to the skip tensor the up path consumes, mid_res to the mid block's output.
- * n_down_res == 0 / mid_res == NULL switch either off. */
+ * n_down_res == 0 / mid_res == NULL switch either off.
+ * adapter_states (T2I adapters, unet/core.py:212-216 `adapter_states=`; semantics of t2i_adapter/unet_patcher.py:21-86): one
+ * NCHW tensor (res_dtype) per down level, added in place to the level's last hidden state - before its downsampler on the
+ * cross-attention levels (skip connection, downsampler and everything downstream see it), after the level otherwise. */
 int gyre_unet_forward_ctrl(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
                            const void* ctx, int ctx_dtype, int B, int H, int W, int S,
                            void* workspace, size_t workspace_bytes, void* eps_out_nchw, int out_dtype, const float* temb_add,
-                           const void* const* down_res, int n_down_res, int res_dtype, const void* mid_res);
+                           const void* const* down_res, int n_down_res, int res_dtype, const void* mid_res,
+                           const void* const* adapter_states, int n_adapter_states);
 
 /* Input gradient (vector-Jacobian product) of the noise prediction: one call runs the forward pass, writes
  * eps_out_nchw like gyre_unet_forward, and writes dx_out_nchw[B, in_channels, H, W] = (d eps / d x)^T d_eps.

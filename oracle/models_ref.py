@@ -184,12 +184,16 @@ def added_cond_embedding(sd: SD, cfg, text_embeds: Tensor, time_ids: Tensor) -> 
 
 def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder_hidden_states: Tensor,
                  taps: Optional[dict] = None, added_cond: Optional[dict] = None, tome_r: int = 0,
-                 down_res: Optional[Sequence[Tensor]] = None, mid_res: Optional[Tensor] = None) -> Tensor:
+                 down_res: Optional[Sequence[Tensor]] = None, mid_res: Optional[Tensor] = None,
+                 adapter_states: Optional[Sequence[Tensor]] = None) -> Tensor:
     """eps = unet(latents[NCHW], t[int64 N], ctx[N,S,D]).  ``taps`` (optional dict)
     receives named intermediate activations for block-level parity tests.
     down_res / mid_res: ControlNet residuals with the semantics of the reference's in-tree patcher
     (gyre/pipeline/controlnet/unet_patcher.py:30-95): added to the skip connections as the UP path consumes them
-    (`res_sample + extra`) and to the mid block's output; the down path and the mid block see the plain activations."""
+    (`res_sample + extra`) and to the mid block's output; the down path and the mid block see the plain activations.
+    adapter_states: T2I-adapter features, one per down level, semantics of gyre/pipeline/t2i_adapter/unet_patcher.py:21-86 -
+    `hidden_states += adapter_state` in place on the level's last hidden state: before the downsampler on cross-attention
+    levels (the tensor is also the skip connection just stored), after the whole level otherwise."""
     g, eps = cfg.norm_num_groups, 1e-5
     boc = cfg.block_out_channels
     if t.ndim == 0:
@@ -212,9 +216,16 @@ def unet_forward(sd: SD, cfg: UNetRefConfig, latents: Tensor, t: Tensor, encoder
                 h = transformer_2d(h, encoder_hidden_states, sd, f"down_blocks.{i}.attentions.{j}",
                                    cfg.num_heads[i], g, cfg.transformer_depth[i], cfg.use_linear_projection, tome_r)
             skips.append(h)
+        adapt_before = adapter_states is not None and (cfg.attn_levels[i] or i == nlev - 1)
+        if adapt_before:                         # in place in the reference: the stored skip connection changes with it
+            h = h + adapter_states[i]
+            skips[-1] = h
         if i < nlev - 1:
             h = _conv(h, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
             skips.append(h)
+        if adapter_states is not None and not adapt_before:
+            h = h + adapter_states[i]
+            skips[-1] = h
         if taps is not None:
             taps[f"down{i}"] = h
 

@@ -126,27 +126,54 @@ def main():
                 hidden_states = self.upsamplers[0](hidden_states)
             return hidden_states
 
-    def trunk(down_res=None, mid_res=None, want_taps=None):
+    class Callable(torch.nn.Module):
+        def __init__(self, fn, resnets=None):
+            super().__init__()
+            self.fn = fn
+            if resnets is not None:
+                self.resnets = resnets
+
+        def forward(self, *a, **k):
+            return self.fn(*a, **k)
+
+    def trunk(down_res=None, mid_res=None, want_taps=None, adapters=None):
+        if adapters is not None:
+            from gyre.pipeline.t2i_adapter import unet_patcher as TP      # the reference's OWN T2I-adapter patcher
         h = M._conv(x, sd, "conv_in")
         skips = (h,)
         level_err = {}
         for i in range(n):
             pre = f"down_blocks.{i}"
-            down = None if i == n - 1 else [lambda hh, i=i: M._conv(hh, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)]
+            down = None if i == n - 1 else torch.nn.ModuleList(
+                [Callable(lambda hh, i=i: M._conv(hh, sd, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1))])
             resnets = [res(f"{pre}.resnets.{j}") for j in range(cfg.layers_per_block)]
             if cfg.attn_levels[i]:
                 blk = make(T.ToMeDownBlock, resnets=resnets, downsamplers=down, training=False, gradient_checkpointing=False,
                            attentions=[ref_spatial(f"{pre}.attentions.{j}", cfg.num_heads[i], cfg.transformer_depth[i])
                                        for j in range(cfg.layers_per_block)])
-                h, states, _ = T.ToMeDownBlock.forward(blk, h, temb, ctx)
+                if adapters is None:
+                    h, states, _ = T.ToMeDownBlock.forward(blk, h, temb, ctx)
+                else:
+                    # what DownBlockWrapper.forward does for a cross-attention block: hand adapter_state to the block, whose
+                    # CrossAttnDownBlock2DHook (t2i_adapter/unet_patcher.py:33-61) wraps the downsampler / adds afterwards
+                    hook = TP.CrossAttnDownBlock2DHook()
+                    args, kwargs = hook.pre_forward(blk, h, temb, ctx, adapter_state=adapters[i])
+                    hh, states, _ = T.ToMeDownBlock.forward(blk, *args, **kwargs)
+                    h, states = hook.post_forward(blk, (hh, states))
             else:                               # DownBlock2D has no vendored copy: same loop without the attentions
-                states = ()
-                for r_ in resnets:
-                    h = r_(h, temb)
-                    states += (h,)
-                if down is not None:
-                    h = down[0](h)
-                    states += (h,)
+                def plain_block(hh, te=None, **_):
+                    st_ = ()
+                    for r_ in resnets:
+                        hh = r_(hh, te)
+                        st_ += (hh,)
+                    if down is not None:
+                        hh = down[0](hh)
+                        st_ += (hh,)
+                    return hh, st_
+                if adapters is None:
+                    h, states = plain_block(h, temb)
+                else:
+                    h, states = TP.DownBlockWrapper(Callable(plain_block), adapters[i])(h, temb)
             skips += states
             if want_taps is not None:
                 level_err[f"down{i}"] = float((h - want_taps[f"down{i}"]).abs().max())
@@ -178,15 +205,6 @@ def main():
             # the reference's OWN ControlNet patcher (gyre/pipeline/controlnet/unet_patcher.py:60-95) rewires the up / mid blocks
             from gyre.pipeline.controlnet import unet_patcher as P
 
-            class Callable(torch.nn.Module):
-                def __init__(self, fn, resnets=None):
-                    super().__init__()
-                    self.fn = fn
-                    if resnets is not None:
-                        self.resnets = resnets
-
-                def forward(self, *a, **k):
-                    return self.fn(*a, **k)
             plain_mid = mid_block
             module = SimpleNamespace(up_blocks=[Callable(b, b.resnets) for b in up_blocks], mid_block=Callable(plain_mid))
             hook = P.UNet2DConditionModelHook()
@@ -224,6 +242,18 @@ def main():
     got, _, _ = trunk(down_res=list(down_res), mid_res=mid_res)
     out["controlnet_patcher_max_abs"] = float((got - want).abs().max())
     out["controlnet_effect"] = float((want - ref_out).abs().max())
+
+    # ---- T2I-adapter states: the reference's patcher (in-place adds inside the down path) vs the oracle's adapter_states -----
+    ashapes, hh, ww = [], 16, 16
+    for i, c_ in enumerate(boc):
+        ashapes.append((c_, hh, ww))
+        if i < n - 1:
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+    adapters = [torch.randn(2, *s_, generator=gen) * 0.5 for s_ in ashapes]
+    want = M.unet_forward(sd, cfg, x, t, ctx, adapter_states=adapters)
+    got, _, _ = trunk(adapters=[a.clone() for a in adapters])
+    out["t2i_patcher_max_abs"] = float((got - want).abs().max())
+    out["t2i_effect"] = float((want - ref_out).abs().max())
     print("PROBE_JSON " + json.dumps(out))
 
 

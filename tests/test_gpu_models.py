@@ -82,7 +82,7 @@ def test_unet_errors():
     out = net(randn(1, 4, 12, 12).to(DEV), 1, encoder_hidden_states=ctx).sample  # not a multiple of 8: fine (diffusers too)
     assert out.shape == (1, 4, 12, 12) and bool(torch.isfinite(out).all())
     with pytest.raises(NotImplementedError):
-        net(x, 1, encoder_hidden_states=ctx, adapter_states=[x])
+        net(x, 1, encoder_hidden_states=ctx, adapter_states=[[x]])
     with pytest.raises(RuntimeError):
         GyreHipUNet(cfg)(x.cpu(), 1, encoder_hidden_states=ctx.cpu())  # no CPU fallback
 
@@ -307,5 +307,22 @@ def test_tiny_unet_controlnet_residual_injection():
     report("tiny unet + mid residual only (bf16 residual)", only_mid.cpu(), M.unet_forward(sd, cfg, x, t, ctx, mid_res=mid), 3e-2)
     with pytest.raises(ValueError):
         net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), down_block_additional_residuals=[d.to(DEV) for d in down[:-1]])
+    # T2I-adapter states: one per down level, added in place inside the down path (t2i_adapter/unet_patcher.py:21-86)
+    ashapes, ah, aw = [], 16, 24
+    for i, c in enumerate(cfg.block_out_channels):
+        ashapes.append((c, ah, aw))
+        if i < len(cfg.block_out_channels) - 1:
+            ah, aw = (ah + 1) // 2, (aw + 1) // 2
+    adapters = [randn(2, *s, seed=50 + k) * 0.5 for k, s in enumerate(ashapes)]
+    ref = M.unet_forward(sd, cfg, x, t, ctx, adapter_states=adapters)
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[a.to(DEV) for a in adapters]).sample
+    report("tiny unet + T2I adapter states", got.cpu(), ref, 3e-2)
+    assert float((ref - plain).norm() / plain.norm()) > 0.05
+    both = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[a.to(DEV) for a in adapters],
+               down_block_additional_residuals=[d.to(DEV) for d in down], mid_block_additional_residual=mid.to(DEV)).sample
+    report("tiny unet + adapters + ControlNet residuals", both.cpu(),
+           M.unet_forward(sd, cfg, x, t, ctx, adapter_states=adapters, down_res=down, mid_res=mid), 3e-2)
+    with pytest.raises(ValueError):
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[a.to(DEV) for a in adapters[:-1]])
     with pytest.raises(NotImplementedError):
-        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[down[0]])
+        net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[[adapters[0]]])

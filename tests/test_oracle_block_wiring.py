@@ -35,3 +35,6 @@ def test_oracle_assembly_equals_the_reference_block_forwards():
     # ControlNet residual injection: the reference's own patcher (controlnet/unet_patcher.py:60-95 UNet2DConditionModelHook.pre_forward,
     # UpBlockWrapper, MidBlockWrapper) rewires that trunk; the oracle's down_res / mid_res must give the same output
     assert out["controlnet_patcher_max_abs"] <= tol and out["controlnet_effect"] > 0.1
+    # T2I-adapter states: t2i_adapter/unet_patcher.py:21-86 (DownsamplerWrapper / CrossAttnDownBlock2DHook / DownBlockWrapper, with
+    # their in-place `+=` that also changes the skip connection just stored) vs the oracle's adapter_states
+    assert out["t2i_patcher_max_abs"] <= tol and out["t2i_effect"] > 0.1
