@@ -732,11 +732,12 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     // wave-quantisation efficiency on 256 CUs with `slots` resident workgroups per CU
     auto eff = [&](long t, int slots) { long cap = 256L * slots; long waves = (t + cap - 1) / cap; return (double)t / (double)(waves * cap); };
-    // padding efficiency along N
+    // padding efficiency along N and along M (a 256-row tile on 128 rows does half its work on padding)
     auto neff = [&](int bn) { long nt = (p.N + bn - 1) / bn; return (double)p.N / (double)(nt * bn); };
+    auto meff = [&](int bm) { long mt = (p.M + bm - 1) / bm; return (double)p.M / (double)(mt * bm); };
     double best = -1; int cfg = 3;
     auto consider = [&](int id, double speed, int bm, int bn, int slots) {
-        double s = speed * eff(tiles(bm, bn), slots) * neff(bn);
+        double s = speed * eff(tiles(bm, bn), slots) * neff(bn) * meff(bm);
         if (s > best) { best = s; cfg = id; }
     };
     // relative speeds measured with tools/opbench.py on MI355X (TFLOP/s at full occupancy / 1000)
@@ -765,7 +766,7 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
                 long t = tiles(bm, bn);
                 if (t >= 160 || t < 1) return;
                 int sp = (int)(256 / t);
-                while (sp > 1 && nk / sp < 16) --sp;
+                while (sp > 1 && nk / sp < 8) --sp;      // >= 8 K steps per slice (tools/gemm_sweep.py at batch 2: 16 left 10 % on the table)
                 if (sp < 2) return;
                 // slab traffic (write + read, fp32) against the operand traffic of the GEMM itself
                 double sc = speed * eff(t * sp, 1) * neff(bn) * 0.85;
