@@ -766,7 +766,10 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
                 long t = tiles(bm, bn);
                 if (t >= 160 || t < 1) return;
                 int sp = (int)(256 / t);
-                while (sp > 1 && nk / sp < 8) --sp;      // >= 8 K steps per slice (tools/gemm_sweep.py at batch 2: 16 left 10 % on the table)
+                // K steps per slice: >= 8 for the 128-row tiles (tools/gemm_sweep.py at batch 2: 16 left 10 % on the table),
+                // >= 16 for the 256-row ones (8x8 level, K = 11520: 256x320 x16 slices 56 us vs 128x320 x8 slices 50 us)
+                const int min_steps = bm >= 256 ? 16 : 8;
+                while (sp > 1 && nk / sp < min_steps) --sp;
                 if (sp < 2) return;
                 // slab traffic (write + read, fp32) against the operand traffic of the GEMM itself
                 double sc = speed * eff(t * sp, 1) * neff(bn) * 0.85;
