@@ -5,7 +5,8 @@
      gyre_op_linear / gyre_op_conv3x3 with gyre_debug_force_gemm_cfg(cfg | splits << 8) for every valid combination
   3. prints planner time vs best time per problem and the summed headroom over the forward
 
-Usage (GPU box):  python tools/gemm_sweep.py [B] [latent]      default 16 64
+Usage (GPU box):  python tools/gemm_sweep.py [B] [latent] [sd15|sdxl|vae]     default 16 64 sd15
+(vae: one decode of B latents; sdxl: the SDXL-base topology)
 """
 import collections
 import ctypes as C
@@ -20,7 +21,8 @@ sys.path.insert(0, ROOT)
 if os.environ.get("GYRE_GEMM_DUMP") is None:
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    env = dict(os.environ, GYRE_GEMM_DUMP="1", SWEEP_B=str(B), SWEEP_LAT=str(LAT))
+    MODEL = sys.argv[3] if len(sys.argv) > 3 else "sd15"
+    env = dict(os.environ, GYRE_GEMM_DUMP="1", SWEEP_B=str(B), SWEEP_LAT=str(LAT), SWEEP_MODEL=MODEL)
     out = subprocess.run([sys.executable, __file__, "dump"], env=env, capture_output=True, text=True)
     shapes = collections.Counter()
     for line in out.stderr.splitlines():
@@ -109,13 +111,20 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
 
 import torch
 from gyre_amd import config as gcfg
-from gyre_amd.modules import GyreHipUNet
-B, H, dev = int(os.environ["SWEEP_B"]), int(os.environ["SWEEP_LAT"]), "cuda:0"
-net = GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(dev)
-net.load_synthetic(0)
-net = net.to(dev)
-x = torch.randn(B, 4, H, H, device=dev)
-t = torch.full((B,), 500, device=dev)
-ctx = torch.randn(B, 77, 768, device=dev)
-net(x, t, encoder_hidden_states=ctx)
+from gyre_amd.modules import GyreHipUNet, GyreHipVAE
+B, H, dev, model = int(os.environ["SWEEP_B"]), int(os.environ["SWEEP_LAT"]), "cuda:0", os.environ.get("SWEEP_MODEL", "sd15")
+if model == "vae":
+    vae = GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).load_synthetic(1).to(dev)
+    vae.decode(torch.randn(B, 4, H, H, device=dev))
+else:
+    cfg = gcfg.sdxl_unet() if model == "sdxl" else gcfg.sd15_unet()
+    net = GyreHipUNet(cfg).to(torch.bfloat16).load_synthetic(0).to(dev)
+    x = torch.randn(B, 4, H, H, device=dev)
+    t = torch.full((B,), 500, device=dev)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, device=dev)
+    kw = {}
+    if model == "sdxl":
+        kw = dict(added_cond_kwargs={"text_embeds": torch.randn(B, 1280, device=dev),
+                                     "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]], device=dev).expand(B, -1).contiguous()})
+    net(x, t, encoder_hidden_states=ctx, **kw)
 torch.cuda.synchronize()
