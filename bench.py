@@ -303,7 +303,11 @@ def main():
                     "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                    "share_of_step_time": round(d["ms"] * 1e-3 / elapsed, 4)}
+                    "share_of_step_time": round(d["ms"] * 1e-3 / elapsed, 4),
+                    "traffic_note": "traffic = class mean of 2*FETCH_SIZE + WRITE_SIZE (profiles/traffic.json, separate rocprofv3 --pmc "
+                                    "passes): L2 <- fabric requests of all eight XCD L2s incl. each one's own copy of the weight slice and "
+                                    "the fp32 split-K slabs; per shape the 64x64 convs move 1.18-1.23x their algorithmic bytes "
+                                    "(profiles/README.md)"}
         per_img = {"sd15": evals * 2 * UNET_TFLOP_PER_SAMPLE * (size / 512) ** 2 + VAE_DEC_TFLOP * (size / 512) ** 2}.get(args.config)
         out = {
             "metric": {"sd15": "SD1.5 512px 50-step images/sec (node)", "sdxl": "SDXL-base 1024px 30-step images/sec (node)",
