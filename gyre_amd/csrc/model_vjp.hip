@@ -235,7 +235,6 @@ int resnet_bwd(Exec& e, const Tn& x, const Tn* skip, const ResW& w, const float*
     Tn d_b, d_h1, d_a;
     ConvW c2{w.c2w, w.c2b, w.cout, w.cout};
     TRY(conv3_bwd(e, d_out, c2, pad8(w.cout), 1, 1, 0, x.H, x.W, nullptr, d_b));
-    Tn dummy;
     TRY(groupnorm_bwd(e, sv.h1, nullptr, w.n2g, w.n2b, eps, 1, d_b, nullptr, d_h1, nullptr));
     e.free(d_b);
     const int cin_tot = x.C + (skip ? skip->C : 0);
@@ -383,8 +382,7 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
     Tn h;
     TRY(e.conv3(xin, u.conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
     skips.push_back(h);
-    auto node_fwd = [&](Node& nd, int eps_dummy) -> int {
-        (void)eps_dummy;
+    auto node_fwd = [&](Node& nd) -> int {
         TRY(e.resnet(nd.x, nd.has_skip ? &nd.skip : nullptr, *nd.rw, tproj, u.temb_cols, 1e-5f, nd.r, &nd.rs));
         nd.out = nd.r;
         if (nd.tw) TRY(e.transformer(nd.r, cx, S, D, *nd.tw, nd.out, &nd.ts));
@@ -396,7 +394,7 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
             Node& nd = downs.back();
             nd.rw = &u.down[i].res[j]; nd.x = skips.back();
             if (c.attn_levels[i]) nd.tw = &u.down[i].attn[j];
-            TRY(node_fwd(nd, 0));
+            TRY(node_fwd(nd));
             skips.push_back(nd.out);
         }
         if (u.down[i].has_resample) {
@@ -408,9 +406,9 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
         }
     }
     midn.rw = &u.mid0; midn.tw = &u.mid_attn; midn.x = skips.back();
-    TRY(node_fwd(midn, 0));
+    TRY(node_fwd(midn));
     mid1n.rw = &u.mid1; mid1n.x = midn.out;
-    TRY(node_fwd(mid1n, 0));
+    TRY(node_fwd(mid1n));
     h = mid1n.out;
     size_t sp = skips.size();
     for (int i = 0; i < n; ++i) {
@@ -420,7 +418,7 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
             Node& nd = ups.back();
             nd.rw = &u.up[i].res[j]; nd.x = h; nd.skip = skips[--sp]; nd.has_skip = true;
             if (c.attn_levels[lvl]) nd.tw = &u.up[i].attn[j];
-            TRY(node_fwd(nd, 0));
+            TRY(node_fwd(nd));
             h = nd.out;
         }
         if (u.up[i].has_resample) {
