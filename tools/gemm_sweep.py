@@ -5,7 +5,7 @@
      gyre_op_linear / gyre_op_conv3x3 with gyre_debug_force_gemm_cfg(cfg | splits << 8) for every valid combination
   3. prints planner time vs best time per problem and the summed headroom over the forward
 
-Usage (GPU box):  python tools/gemm_sweep.py [B] [latent] [sd15|sdxl|vae]     default 16 64 sd15
+Usage (GPU box):  python tools/gemm_sweep.py [B] [latent] [sd15|sdxl|vae] [extra cfg ids, comma separated]     default 16 64 sd15
 (vae: one decode of B latents; sdxl: the SDXL-base topology)
 """
 import collections
@@ -22,6 +22,7 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     MODEL = sys.argv[3] if len(sys.argv) > 3 else "sd15"
+    EXTRA = tuple(int(c) for c in sys.argv[4].split(",")) if len(sys.argv) > 4 else ()      # e.g. 20,21,22,23: the 4-wave pipelined forms
     env = dict(os.environ, GYRE_GEMM_DUMP="1", SWEEP_B=str(B), SWEEP_LAT=str(LAT), SWEEP_MODEL=MODEL)
     out = subprocess.run([sys.executable, __file__, "dump"], env=env, capture_output=True, text=True)
     shapes = collections.Counter()
@@ -84,7 +85,7 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
         t_plan = timeit(call)
         best = (t_plan, "planner")
         results = {}
-        for cfg in ((1, 2, 3, 4, 5, 6, 7) if dual else (1, 2, 3, 4, 5, 6, 7, 24)):
+        for cfg in ((1, 2, 3, 4, 5, 6, 7) if dual else (1, 2, 3, 4, 5, 6, 7, 24) + EXTRA):
             for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
                 if sp > 1 and (cfg < 4 or f["geglu"] or K // 64 // sp < 4):
                     continue
