@@ -780,7 +780,9 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
             // very long reductions (3x3 convs over 1280+ channels at 32x32 / 16x16): the 256x320 tile's better
             // operand reuse outweighs the larger slabs - measured +3 % (K = 11520) to +10 % (K = 17280 / 23040)
             // (same-box A/B: UNet forward 20.56 -> 20.12 ms)
-            if (p.N % 320 == 0 && p.K >= 11000) {
+            // (cold-cache sweep, tools/gemm_sweep.py with COLD=1 - the regime inside the UNet: from K = 5120 on, e.g. the
+            //  32x32 convs 640 -> 640: 128x320 unsplit 150 us, 256x320 in 2 slices 133 us)
+            if (p.N % 320 == 0 && p.K >= 5000) {
                 tryk(4, 1.05, 256, 320);
                 // the pipelined main loop also wins with split K (tools/gemm_sweep.py, r02: 16x16 convs K = 11520 ... 23040,
                 // 4 slices: 133 -> 127, 182 -> 170, 227 -> 216 us)

@@ -41,12 +41,29 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(0)
 
+    COLD = os.environ.get("COLD") == "1"       # evict L2 / Infinity Cache before every timed launch (closer to the in-UNet regime)
+    if COLD:
+        fl_a = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
+        fl_b = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
+
     def timeit(fn, n=12):
         for _ in range(2):
             rc = fn()
             if rc:
                 return None
         torch.cuda.synchronize()
+        if COLD:
+            tot = 0.0
+            reps = max(n // 2, 4)
+            for _ in range(reps):
+                fl_a.copy_(fl_b)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                tot += a.elapsed_time(b)
+            return tot / reps * 1e3
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(n):
