@@ -41,7 +41,8 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(0)
 
-    COLD = os.environ.get("COLD") == "1"       # evict L2 / Infinity Cache before every timed launch (closer to the in-UNet regime)
+    COLD = os.environ.get("COLD") in ("1", "2")  # 1: evict L2 / Infinity Cache before every timed launch (the in-UNet regime)
+    NOFLUSH = os.environ.get("COLD") == "2"      # 2: time launches one by one like 1, but leave the caches alone
     if COLD:
         fl_a = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
         fl_b = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
@@ -56,7 +57,10 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
             tot = 0.0
             reps = max(n // 2, 4)
             for _ in range(reps):
-                fl_a.copy_(fl_b)
+                if not NOFLUSH:
+                    fl_a.copy_(fl_b)
+                else:
+                    torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 fn()
