@@ -137,10 +137,13 @@ class GyrePipeline:
 
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype: Optional[torch.dtype] = torch.bfloat16, device="cuda:0",
-                        variant: Optional[str] = None, text_encoder: Optional[Callable] = None):
+                        variant: Optional[str] = None, text_encoder: Optional[Callable] = None,
+                        inpaint_unet: Optional[str] = None, clip_model: Optional[str] = None, grafted_inpaint=False):
         """Build the pipeline from a diffusers-layout model folder (model_index.json, unet/, vae/[, text_encoder/])
         without importing diffusers - the layout the reference's manager resolves engines to (manager.py:1024-1252).
-        The CLIP text encoder is loaded through transformers when its folder is present and no callable is given."""
+        The CLIP text encoder is loaded through transformers when its folder is present and no callable is given.
+        inpaint_unet / clip_model: folders of the engine's optional overrides (reference tests/engines.clip.yaml:12-17 -
+        a 9-channel inpaint UNet, a transformers CLIPModel + its preprocessor config for CLIP guidance)."""
         import os
         from .modules import GyreHipUNet, GyreHipVAE
         if not os.path.exists(os.path.join(path, "model_index.json")) and not os.path.isdir(os.path.join(path, "unet")):
@@ -155,7 +158,24 @@ class GyrePipeline:
             from transformers import CLIPTextModel
             te = CLIPTextModel.from_pretrained(te_dir, torch_dtype=torch_dtype).to(dev).eval()
             text_encoder = lambda ids: te(input_ids=ids)[0]
-        return cls(unet, vae, text_encoder, device=dev)
+        iu = None
+        if inpaint_unet:
+            iu = GyreHipUNet.from_pretrained(inpaint_unet, torch_dtype=torch_dtype, variant=variant)
+            iu = iu.to(dev) if dev.type == "cuda" else iu
+        cm = fe = None
+        if clip_model:
+            import json
+            from types import SimpleNamespace
+            from transformers import CLIPModel
+            from .clipguided import patch_embedding_as_matmul
+            cm = patch_embedding_as_matmul(CLIPModel.from_pretrained(clip_model).to(dev).eval().requires_grad_(False))
+            pj = os.path.join(clip_model, "preprocessor_config.json")
+            pc = json.load(open(pj)) if os.path.exists(pj) else {}
+            fe = SimpleNamespace(image_mean=pc.get("image_mean", [0.48145466, 0.4578275, 0.40821073]),
+                                 image_std=pc.get("image_std", [0.26862954, 0.26130258, 0.27577711]),
+                                 size=pc.get("size", {"shortest_edge": 224}))
+        return cls(unet, vae, text_encoder, device=dev, inpaint_unet=iu, grafted_inpaint=grafted_inpaint, clip_model=cm,
+                   feature_extractor=fe)
 
     # -- text ---------------------------------------------------------------------------------
     def encode_ids(self, input_ids: Tensor) -> Tensor:

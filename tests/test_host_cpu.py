@@ -141,6 +141,32 @@ def test_from_pretrained_reads_diffusers_layout(tmp_path):
     assert isinstance(pipe.unet, GyreHipUNet) and isinstance(pipe.vae, GyreHipVAE) and pipe.text_encoder is None
     with pytest.raises(FileNotFoundError):
         GyrePipeline.from_pretrained(str(tmp_path / "nope"))
+    # the engine's optional overrides (reference tests/engines.clip.yaml:12-17): 9-channel inpaint UNet + CLIP model folders
+    import dataclasses
+    from transformers import CLIPConfig, CLIPModel
+    icfg = dataclasses.replace(ucfg, in_channels=9)
+    (root / "inpaint_unet").mkdir()
+    (root / "inpaint_unet" / "config.json").write_text(json.dumps({
+        "_class_name": "UNet2DConditionModel", "in_channels": 9, "out_channels": 4, "sample_size": 16,
+        "block_out_channels": [32, 64, 128, 128], "layers_per_block": 2, "cross_attention_dim": 64,
+        "attention_head_dim": [2, 2, 4, 4], "norm_num_groups": 32,
+        "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]}))
+    isd = weights.synthetic_state_dict(weights.unet_param_shapes(icfg))
+    save_file({k: v.contiguous() for k, v in isd.items()}, str(root / "inpaint_unet" / "diffusion_pytorch_model.safetensors"))
+    small = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2)
+    clip = CLIPModel(CLIPConfig(text_config=dict(small, vocab_size=64, max_position_embeddings=16),
+                                vision_config=dict(small, image_size=32, patch_size=8), projection_dim=16))
+    clip.save_pretrained(str(root / "clip_model"))
+    (root / "clip_model" / "preprocessor_config.json").write_text(json.dumps({
+        "image_mean": [0.5, 0.5, 0.5], "image_std": [0.25, 0.25, 0.25], "size": {"shortest_edge": 32}}))
+    full = GyrePipeline.from_pretrained(str(root), device="cpu", inpaint_unet=str(root / "inpaint_unet"),
+                                        clip_model=str(root / "clip_model"))
+    assert full.inpaint_unet.config.in_channels == 9 and full.clip_model is not None
+    assert full.feature_extractor.image_mean == [0.5, 0.5, 0.5] and full.feature_extractor.size == {"shortest_edge": 32}
+    px = torch.rand(2, 3, 32, 32)
+    want = clip.eval().vision_model.embeddings(px)
+    got = full.clip_model.vision_model.embeddings(px)           # patch embedding replaced by its matmul form: same values
+    assert torch.allclose(got, want, atol=1e-5)
     # SDXL-style config keys
     xl = GyreHipUNet._config_from_json({
         "block_out_channels": [320, 640, 1280], "down_block_types": ["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
