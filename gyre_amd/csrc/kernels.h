@@ -37,6 +37,8 @@ bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch p
 int launch_groupnorm_small(hipStream_t st, const GnParams& p);
 int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
                      bf16_t* y);
+// stats[m] = (rstd, rstd * mean) of row m: the input of a GEMM with the LayerNorm folded in (GemmParams::ln_stats)
+int launch_layernorm_stats(hipStream_t st, const bf16_t* x, int M, int C, float eps, float* stats);
 
 // weight repack: OIHW (any dtype) -> [O][KH][KW][Ipad] bf16 ; linear [O][I] -> bf16 (optionally GEGLU-interleaved)
 int launch_nhwc_to_nchw_f32(hipStream_t st, const bf16_t* x, int B, int C, int HW, int Cpad, float* y);
@@ -78,7 +80,21 @@ struct GemmParams {
     // batched form (4-wave kernels only): problem b uses A + b*bsA, W + b*bsW, out + b*bsC (element strides); no bias /
     // residual / split-K.  Used for the per-sample token-similarity matrix of ToMe.
     int batch = 1; size_t bsA = 0, bsW = 0, bsC = 0;
+    // LayerNorm folded into the GEMM (8-wave kernels, linear mode, one source, no split-K): A holds the RAW rows, W the
+    // gamma-scaled weights W'[n][k] = W[n][k] * gamma[k], bias[n] = sum_k beta[k] W[n][k] (+ the layer's bias),
+    // ln_colsum[n] = sum_k W'[n][k] (launch_ln_fold) and ln_stats[m] = (rstd, rstd * mean) of row m
+    // (launch_layernorm_stats, one streaming read of the rows).  The epilogue applies
+    // out = rstd * acc - rstd * mean * colsum + bias: the normalised tensor is never written or re-read.
+    // (Accumulating the row sums inside the K loop from the operand fragments - v_dot2c_f32_bf16, no extra pass - was built
+    // and measured: every N tile repeats the sums at ~20 cycles per packed pair, slower than the separate statistics pass
+    // for every layer of the UNet; profiles/README.md.)
+    const float* ln_colsum = nullptr; const float* ln_stats = nullptr;
 };
+// true when launch_gemm would run `p` (ln_colsum set or not) on a kernel that supports the folded LayerNorm
+bool gemm_ln_fusable(const GemmParams& p);
+// W'[n][k] = bf16(W[n][k] * gamma[k]); colsum[n] = sum_k W'[n][k]; bias_out[n] = sum_k beta[k] * W[n][k] + (bias ? bias[n] : 0)
+int launch_ln_fold(hipStream_t st, const bf16_t* W, int N, int K, const float* gamma, const float* beta, const float* bias,
+                   bf16_t* Wf, float* colsum, float* bias_out);
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
 struct GemmPlan { int cfg; int splits; size_t ws_bytes; };

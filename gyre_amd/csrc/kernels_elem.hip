@@ -425,9 +425,12 @@ int launch_groupnorm_small(hipStream_t st, const GnParams& p) {
 // (mean, then centred sum of squares - same arithmetic order class as ATen's).
 // ------------------------------------------------------------------------------
 #define LN_MAXV 4  // C <= 8*64*4 = 2048
+// STATS: only the row statistics (rstd, rstd * mean) leave the kernel - the consuming GEMM normalises in its epilogue
+// (GemmParams::ln_stats)
+template <bool STATS>
 __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x, int M, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float eps, bf16_t* __restrict__ y) {
+                                                   float eps, bf16_t* __restrict__ y, float* __restrict__ stats) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     size_t row = (size_t)blockIdx.x * 4 + wave;
     if (row >= (size_t)M) return;
@@ -459,6 +462,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
     const float rstd = rsqrtf(q / (float)C + eps);
+    if (STATS) {
+        if (lane == 0) *(float2*)(stats + row * 2) = make_float2(rstd, rstd * mean);
+        return;
+    }
 #pragma unroll
     for (int v = 0; v < LN_MAXV; ++v) {
         int cv = lane + v * 64;
@@ -476,7 +483,15 @@ int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float*
                      bf16_t* y) {
     if (C % 8 || C > 8 * 64 * LN_MAXV) GYRE_FAIL(-6, "layernorm: C must be a multiple of 8 and <= 2048");
     GyreProfScope prof_(KC_LAYERNORM, st, 0.0, (double)M * C * 4.0);
-    hipLaunchKernelGGL(k_layernorm, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, gamma, beta, eps, y);
+    hipLaunchKernelGGL(k_layernorm<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, gamma, beta, eps, y, (float*)nullptr);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_layernorm_stats(hipStream_t st, const bf16_t* x, int M, int C, float eps, float* stats) {
+    if (C % 8 || C > 8 * 64 * LN_MAXV) GYRE_FAIL(-6, "layernorm: C must be a multiple of 8 and <= 2048");
+    GyreProfScope prof_(KC_LAYERNORM, st, 0.0, (double)M * C * 2.0);
+    hipLaunchKernelGGL(k_layernorm<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, M, C, (const float*)nullptr, (const float*)nullptr,
+                       eps, (bf16_t*)nullptr, stats);
     GYRE_LAUNCH_CHECK();
     return 0;
 }

@@ -103,9 +103,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 // measured, that epilogue cost ~20 us per 42 MB output.  Here each wave parks one 16-row slab of its tile in
 // LDS as fp32 (bias / time-embedding bias / GEGLU already applied), reads it back as whole rows and issues
 // 16-byte coalesced residual loads and stores.  One rounding, after the residual add - same as the direct path.
-template <int MI, int NI, int TN, bool GG>
+// Folded LayerNorm (GemmParams::ln_colsum): out = rstd * acc - (rstd * mean) * colsum[n] + bias[n]
+template <bool LNF>
+__device__ __forceinline__ float4 ep_affine(const f32x4_t& a, const float4& b, const float4& c, float rstd, float rmu) {
+    if (LNF) return make_float4(fmaf(a[0], rstd, fmaf(-rmu, c.x, b.x)), fmaf(a[1], rstd, fmaf(-rmu, c.y, b.y)),
+                                fmaf(a[2], rstd, fmaf(-rmu, c.z, b.z)), fmaf(a[3], rstd, fmaf(-rmu, c.w, b.w)));
+    return make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+}
+
+template <int MI, int NI, int TN, bool GG, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
-                                                     int fr, int fq, int lane, float* my) {
+                                                     int fr, int fq, int lane, float* my, const float* lrstd = nullptr,
+                                                     const float* lrmu = nullptr, const float* lcs = nullptr,
+                                                     const float* lbb = nullptr) {
     constexpr int TNO_FULL = TN;                 // staged columns per wave without GEGLU
     constexpr bool gg = GG;
     constexpr int tno = gg ? TNO_FULL / 2 : TNO_FULL;    // output columns this wave produces
@@ -131,17 +141,27 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
         }
         const int m = m_base + i * 16 + fr;
         const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        // folded LayerNorm: the column constants are re-read from LDS for every slab.  The opaque zero keeps the compiler from
+        // merging the reads of all slabs into one set held in registers next to the live accumulators (measured: it spilled
+        // every accumulator of the 256-row tiles to scratch).
+        int lz = 0;
+        if (LNF) asm volatile("" : "+v"(lz));
         if (gg) {
 #pragma unroll
             for (int j = 0; j + 1 < NI; j += 2) {
                 const int nin = n_base + j * 16 + 4 * fq;
-                float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0);
-                if (p.bias && nin < p.N) { bv = *(const float4*)(p.bias + nin); bg = *(const float4*)(p.bias + nin + 16); }
+                float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0), cv = bv, cg = bv;
+                if (LNF) {      // column constants of this wave's tile staged in LDS by the kernel (zeros past N)
+                    bv = *(const float4*)(lbb + lz + j * 16 + 4 * fq); bg = *(const float4*)(lbb + lz + j * 16 + 16 + 4 * fq);
+                    cv = *(const float4*)(lcs + lz + j * 16 + 4 * fq); cg = *(const float4*)(lcs + lz + j * 16 + 16 + 4 * fq);
+                } else if (p.bias && nin < p.N) { bv = *(const float4*)(p.bias + nin); bg = *(const float4*)(p.bias + nin + 16); }
+                const float4 val = ep_affine<LNF>(acc[i][j], bv, cv, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
+                const float4 gate = ep_affine<LNF>(acc[i][j + 1], bg, cg, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
                 float4 o;
-                o.x = (acc[i][j][0] + bv.x) * gelu_erf_f(acc[i][j + 1][0] + bg.x);
-                o.y = (acc[i][j][1] + bv.y) * gelu_erf_f(acc[i][j + 1][1] + bg.y);
-                o.z = (acc[i][j][2] + bv.z) * gelu_erf_f(acc[i][j + 1][2] + bg.z);
-                o.w = (acc[i][j][3] + bv.w) * gelu_erf_f(acc[i][j + 1][3] + bg.w);
+                o.x = val.x * gelu_erf_f(gate.x);
+                o.y = val.y * gelu_erf_f(gate.y);
+                o.z = val.z * gelu_erf_f(gate.z);
+                o.w = val.w * gelu_erf_f(gate.w);
                 *(float4*)(my + fr * rowf + (j / 2) * 16 + 4 * fq) = o;
             }
         } else {
@@ -150,7 +170,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 const int n = n_base + j * 16 + 4 * fq;
                 float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 if (n < p.N) {
-                    if (p.bias) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                    if (LNF) {
+                        o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + lz + j * 16 + 4 * fq),
+                                            *(const float4*)(lcs + lz + j * 16 + 4 * fq), lrstd[i], lrmu[i]);
+                    } else if (p.bias) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
                     if (rbias) { float4 tv = *(const float4*)(rbias + n); o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w; }
                 }
                 *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
@@ -181,18 +204,25 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
 
 // Transposed variant for the V columns of a fused Q|K|V projection: the 16-row slab is read back column-wise, 8
 // consecutive tokens of one channel per lane -> one 16-byte store into V^T[b][channel][token].
-template <int MI, int NI, int TN>
+template <int MI, int NI, int TN, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
-                                                       int fr, int fq, int lane, float* my) {
+                                                       int fr, int fq, int lane, float* my, const float* lrstd = nullptr,
+                                                       const float* lrmu = nullptr, const float* lcs = nullptr,
+                                                       const float* lbb = nullptr) {
     constexpr int rowf = TN + 4;
     const int cv_total = p.N - p.vt_col0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        int lz = 0;
+        if (LNF) asm volatile("" : "+v"(lz));     // see gemm_epilogue_staged
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n_base + j * 16 + 4 * fq;
             float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (p.bias && n < p.N) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+            if (LNF) {
+                o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + lz + j * 16 + 4 * fq), *(const float4*)(lcs + lz + j * 16 + 4 * fq),
+                                    lrstd[i], lrmu[i]);
+            } else if (p.bias && n < p.N) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
             *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
         }
 #pragma unroll
@@ -224,7 +254,8 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
 // 128 B), so the XOR swizzle is applied to the per-lane SOURCE address and mirrored on the ds_read
 // (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP>
+// LNF: folded LayerNorm (GemmParams::ln_colsum / ln_stats) applied by the staged epilogue
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false>
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -366,7 +397,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (splits > 1) {
+    if (!LNF && splits > 1) {     // (the folded-LayerNorm form is launched unsplit, with the staged epilogue only)
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -381,7 +412,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
         return;
     }
-    if (p.debug & 4) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+    if (!LNF && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -392,20 +423,41 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     }
     // coalesced LDS-staged epilogue when every 8-channel group is 16-byte addressable, else the direct one
     const int n_out = p.geglu ? p.N / 2 : p.N;
-    if (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
-        (((size_t)p.out | (size_t)p.residual) & 15) == 0) {
+    if (LNF || (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+                (((size_t)p.out | (size_t)p.residual) & 15) == 0)) {
         float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
+        float lrstd[MI], lrmu[MI];
+        const float *lcs = nullptr, *lbb = nullptr;
+        if constexpr (LNF) {
+            // column constants of the tile (colsum, folded bias) go to LDS behind the epilogue slabs: the epilogue reads them
+            // with ds_read_b128 instead of holding dozens of global loads in flight next to 160 live accumulators
+            float* colc = (float*)smem_raw + 8 * 16 * (TN + 4);
+            for (int t = tid; t < BN; t += 512) {
+                const int n = n0 + t;
+                colc[t] = n < p.N ? p.ln_colsum[n] : 0.f;
+                colc[BN + t] = n < p.N ? p.bias[n] : 0.f;
+            }
+            __syncthreads();
+            lcs = colc + wn * TN; lbb = colc + BN + wn * TN;
+            // per-row statistics of the rows this lane's accumulators belong to (launch_layernorm_stats)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * TM + i * 16 + fr;
+                const float2 rs = m < p.M ? ((const float2*)p.ln_stats)[m] : make_float2(1.f, 0.f);
+                lrstd[i] = rs.x; lrmu[i] = rs.y;
+            }
+        }
         if (p.vt_out && n0 + wn * TN >= p.vt_col0) {             // V columns of a fused Q|K|V projection (wave-uniform)
-            gemm_epilogue_staged_t<MI, NI, TN>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+            gemm_epilogue_staged_t<MI, NI, TN, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
             return;
         }
         if constexpr (NI % 2 == 0) {
-            if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my); return; }
+            if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb); return; }
         }
-        gemm_epilogue_staged<MI, NI, TN, false>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my);
+        gemm_epilogue_staged<MI, NI, TN, false, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
         return;
     }
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+    if constexpr (!LNF) gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
 }
 
 // out = bf16( sum_s slab[s] + bias + rowbias + residual ), fixed summation order (deterministic)
@@ -434,6 +486,43 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits)
 int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits) {
     const size_t nthreads = (size_t)p.M * (p.N / 4);
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight side of the folded LayerNorm (GemmParams::ln_colsum): one wave per output row, fixed summation order.
+__global__ __launch_bounds__(256) void k_ln_fold(const bf16_t* __restrict__ W, int N, int K, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ bias,
+                                                 bf16_t* __restrict__ Wf, float* __restrict__ colsum, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const bf16_t* wrow = W + (size_t)n * K;
+    bf16_t* frow = Wf + (size_t)n * K;
+    float cs = 0.f, bb = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        float w[8], f[8];
+        unpack8(*(const uint4*)(wrow + k), w);
+        const float4 g0 = *(const float4*)(gamma + k), g1 = *(const float4*)(gamma + k + 4);
+        const float4 b0 = *(const float4*)(beta + k), b1 = *(const float4*)(beta + k + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[j] = w[j] * g[j]; bb = fmaf(b[j], w[j], bb); }
+        const uint4 pk = pack8(f);
+        *(uint4*)(frow + k) = pk;
+        unpack8(pk, f);                       // the column sum is taken over the ROUNDED folded weights the GEMM multiplies by
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs += f[j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { cs += __shfl_xor(cs, off); bb += __shfl_xor(bb, off); }
+    if (lane == 0) { colsum[n] = cs; bias_out[n] = bb + (bias ? bias[n] : 0.f); }
+}
+int launch_ln_fold(hipStream_t st, const bf16_t* W, int N, int K, const float* gamma, const float* beta, const float* bias,
+                   bf16_t* Wf, float* colsum, float* bias_out) {
+    if (K % 8) GYRE_FAIL(-1, "ln_fold: K must be a multiple of 8");
+    hipLaunchKernelGGL(k_ln_fold, dim3((N + 3) / 4), dim3(256), 0, st, W, N, K, gamma, beta, bias, Wf, colsum, bias_out);
     GYRE_LAUNCH_CHECK();
     return 0;
 }
@@ -708,7 +797,13 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
-    if (p.mode == GEMM_LINEAR) {
+    if (p.mode == GEMM_LINEAR && p.ln_colsum) {
+        auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, true>;
+        static std::atomic<unsigned long long> attr_done{0};
+        if (gyre_lds_attr_needed(attr_done))
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);
+    } else if (p.mode == GEMM_LINEAR) {
         GYRE_GEMM8_GO(GEMM_LINEAR, true);
     } else {
         const bool uni = (p.Cin % BK == 0) && (p.C1 % BK == 0);
@@ -830,6 +925,32 @@ static int plan_cfg(const GemmParams& p, int* splits) {
     return pick_cfg(p, splits);
 }
 
+// the condition under which k_gemm8 takes its LDS-staged epilogue (the only one that knows the folded LayerNorm)
+static bool gemm_staged_epilogue_ok(const GemmParams& p) {
+    const int n_out = p.geglu ? p.N / 2 : p.N;
+    return p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+           (((size_t)p.out | (size_t)p.residual) & 15) == 0;
+}
+bool gemm_ln_fusable(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    if (g_force_cfg || p.force_cfg || (p.debug & 0x800)) return false;      // tuning runs keep the separate LayerNorm (bit 11: off)
+    // batch-invariant planning: whether a shape gets an 8-wave tile depends on M = batch x rows, and the folded and the
+    // separate LayerNorm round differently - so that mode keeps the separate pass for every batch size
+    if (g_invariant_batch > 0) return false;
+    if (p.mode != GEMM_LINEAR || p.A2 || p.rowbias || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 4) return false;
+    if (!gemm_staged_epilogue_ok(p)) return false;
+    int splits = 1;
+    const int cfg = plan_cfg(p, &splits);
+    if (cfg < 4 || cfg > 7 || splits > 1) return false;
+    if (p.geglu && (cfg == 4 || cfg == 5)) return false;
+    if (p.vt_out) {
+        const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : 64;
+        if (p.vt_col0 % tn) return false;
+    }
+    return true;
+}
+
 GemmPlan gemm_plan(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;      // same planner inputs as launch_gemm
@@ -863,6 +984,8 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             p.vt_col0 <= 0 || p.vt_col0 >= p.N || p.N % 8)
             GYRE_FAIL(-1, "gemm: bad fused Q|K|V arguments");
     }
+    if (p.ln_colsum && (p.mode != GEMM_LINEAR || p0.A2 || !p.bias || !p.ln_stats || p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
+        GYRE_FAIL(-1, "gemm: the folded LayerNorm needs a single-source linear problem with row statistics, bias and bf16 row-major output");
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
     {   // tuning aid (tools/gemm_sweep.py): GYRE_GEMM_DUMP=1 prints every problem shape with the planner's choice
@@ -885,6 +1008,8 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
+    if (p.ln_colsum && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
+        GYRE_FAIL(-6, "gemm: the folded LayerNorm needs an unsplit 8-wave tile config with the staged epilogue (see gemm_ln_fusable)");
     if (cfg >= 4) {
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
         if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");

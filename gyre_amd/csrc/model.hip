@@ -402,6 +402,37 @@ int gyre_op_qkv(void* st, const void* x, int M, int C, const void* w_qkv, int to
     p.vt_out = (bf16_t*)vt_out; p.vt_col0 = 2 * C; p.tokens_per_batch = tokens; p.ldt = ldt;
     return launch_gemm((hipStream_t)st, p);
 }
+// LayerNorm folded into the consuming GEMM (kernels.h GemmParams::ln_colsum).  qkv_tokens > 0: w holds [3K][K] rows Q | K | V,
+// y receives Q | K ([M][2K]) and vt_out V^T as in gyre_op_qkv; else a plain / GEGLU linear as in gyre_op_linear.
+size_t gyre_op_ln_linear_workspace(int w_rows, int K, int M) {
+    return align_up((size_t)w_rows * K * 2, 256) + 2 * align_up((size_t)w_rows * 4, 256) + align_up((size_t)M * 8, 256);
+}
+int gyre_op_ln_linear(void* st, const void* x, int M, int K, const float* gamma, const float* beta, float eps, const void* w,
+                      int N, const float* bias, int geglu, int qkv_tokens, void* vt_out, int ldt, void* ws,
+                      size_t ws_bytes, void* y) {
+    if (!x || !w || !y || !gamma || !beta || !ws) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K; p.M = M; p.bias = bias;
+    p.out = y; p.out_mode = OUT_BF16;
+    if (qkv_tokens > 0) {
+        if (!vt_out || M % qkv_tokens || N != 3 * K || geglu) GYRE_FAIL(GYRE_ERR_INVALID, "bad fused Q|K|V arguments");
+        p.N = 3 * K; p.ldc = 2 * K; p.samples = M / qkv_tokens;
+        p.vt_out = (bf16_t*)vt_out; p.vt_col0 = 2 * K; p.tokens_per_batch = qkv_tokens; p.ldt = ldt;
+    } else {
+        p.N = geglu ? 2 * N : N; p.ldc = N; p.geglu = geglu;
+    }
+    if (ws_bytes < gyre_op_ln_linear_workspace(p.N, K, M)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "ln_linear: workspace too small");
+    if (!gemm_ln_fusable(p)) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "ln_linear: the planner's kernel for this shape cannot fold the LayerNorm");
+    bf16_t* wf = (bf16_t*)ws;
+    float* cs = (float*)((char*)ws + align_up((size_t)p.N * K * 2, 256));
+    float* bb = (float*)((char*)cs + align_up((size_t)p.N * 4, 256));
+    TRY(launch_ln_fold((hipStream_t)st, p.W, p.N, K, gamma, beta, bias, wf, cs, bb));
+    float* stats = (float*)((char*)bb + align_up((size_t)p.N * 4, 256));
+    TRY(launch_layernorm_stats((hipStream_t)st, p.A, M, K, eps, stats));
+    p.ln_stats = stats;
+    p.W = wf; p.bias = bb; p.ln_colsum = cs;
+    return launch_gemm((hipStream_t)st, p);
+}
 int gyre_op_attention_ex(void* st, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int B,
                          int heads, int Nq, int Nk, int D, void* o, int ldo, int k_prescaled) {
     if (!q || !k || !vt || !o) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");

@@ -89,6 +89,23 @@ struct Store {
     struct WtEntry { bf16_t* p = nullptr; size_t bytes = 0; uint64_t version = 0; };
     std::unordered_map<const void*, WtEntry> wt_cache;
     uint64_t weights_version = 1;
+    // gamma-folded copies of the weights that follow a LayerNorm (GemmParams::ln_colsum), same lifetime rules
+    struct LnEntry { bf16_t* wf = nullptr; float* cs = nullptr; float* bb = nullptr; size_t elems = 0; uint64_t version = 0; };
+    std::unordered_map<const void*, LnEntry> ln_cache;
+    LnEntry* ln_lookup(const void* w, int N, int K, bool* fresh) {
+        LnEntry& en = ln_cache[w];
+        const size_t elems = (size_t)N * K;
+        if (!en.wf || en.elems < elems) {
+            const size_t wbytes = (elems * 2 + 255) / 256 * 256, vbytes = ((size_t)N * 4 + 255) / 256 * 256;
+            char* base = (char*)dmalloc(wbytes + 2 * vbytes, false);
+            if (!base) return nullptr;
+            en.wf = (bf16_t*)base; en.cs = (float*)(base + wbytes); en.bb = (float*)(base + wbytes + vbytes);
+            en.elems = elems; en.version = 0;
+        }
+        *fresh = en.version == weights_version;
+        en.version = weights_version;
+        return &en;
+    }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
     // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
     bf16_t* wt_lookup(const void* w, size_t bytes, bool* fresh) {
@@ -348,15 +365,63 @@ struct Exec {
         if (dry()) return 0;
         return launch_layernorm(st, x.p, x.rows(), x.C, g, b, 1e-5f, y.p);
     }
+    // LayerNorm folded into the GEMM that consumes it (kernels.h GemmParams::ln_colsum): `p` describes the product of the RAW
+    // rows with the layer's own weights / bias; on return it points at the gamma-folded copies (made on first use per handle,
+    // refreshed after any gyre_*_set_weight) and the launch normalises on the fly - the normalised tensor never exists.
+    struct LnFold { const float* g; const float* b; };
+    bool ln_fusable(const GemmParams& p) const { return store && gemm_ln_fusable(p); }
+    // `stats`: arena scratch for the per-row statistics (one streaming pass over the rows); freed by the caller after the launch
+    int ln_fold_into(GemmParams& p, const LnFold& ln, Tn& stats) {
+        TRY(alloc_raw(stats, (size_t)p.M * 2 * sizeof(float)));
+        if (!dry()) {
+            TRY(launch_layernorm_stats(st, p.A, p.M, p.K, 1e-5f, (float*)stats.p));
+            p.ln_stats = (const float*)stats.p;
+        }
+        if (dry()) return 0;
+        bool fresh = false;
+        Store::LnEntry* e = store->ln_lookup(p.W, p.N, p.K, &fresh);
+        if (!e) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the LayerNorm-folded weight copy");
+        if (!fresh) TRY(launch_ln_fold(st, p.W, p.N, p.K, ln.g, ln.b, p.bias, e->wf, e->cs, e->bb));
+        p.W = e->wf; p.bias = e->bb; p.ln_colsum = e->cs;
+        return 0;
+    }
+    // y = LayerNorm(x) @ w^T + bias (geglu halves N): one launch when the planner's kernel can fold the norm, else two
+    int ln_linear(const Tn& x, const LnFold& ln, const bf16_t* w, int N, const float* bias, int geglu, bf16_t* y, int ldc) {
+        GemmParams p;
+        p.A = x.p; p.lda = x.C; p.mode = GEMM_LINEAR; p.W = w; p.K = x.C; p.N = N; p.M = x.rows(); p.bias = bias; p.geglu = geglu;
+        p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16; p.samples = batch;
+        if (ln_fusable(p)) {
+            Tn stats;
+            TRY(ln_fold_into(p, ln, stats));
+            int rc = run_gemm(p);
+            free(stats);
+            return rc;
+        }
+        Tn n;
+        TRY(layernorm(x, ln.g, ln.b, n));
+        p.A = n.p;
+        int rc = run_gemm(p);
+        free(n);
+        return rc;
+    }
     // multi-head attention of tokens x against kv source (self: kv == nullptr); out = proj(attn) + residual
-    int mha(const Tn& xq, bool cross, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w,
-            const Tn& residual, Tn& out, MhaSave* sv = nullptr) {
-        const int B = xq.B, Nq = xq.H * xq.W, C = w.c, D = C / w.heads;
-        Tn q, k, vt, ao;
+    // ln != nullptr: xq_in holds the rows BEFORE the block's LayerNorm; the projections fold it where they can
+    int mha(const Tn& xq_in, bool cross, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w,
+            const Tn& residual, Tn& out, MhaSave* sv = nullptr, const LnFold* ln = nullptr) {
+        const int B = xq_in.B, Nq = xq_in.H * xq_in.W, C = w.c, D = C / w.heads;
+        Tn q, k, vt, ao, nrm;
+        Tn xq = xq_in;
+        auto normalise = [&]() -> int {          // fallback: the separate LayerNorm pass
+            if (!ln) return 0;
+            TRY(layernorm(xq_in, ln->g, ln->b, nrm));
+            xq = nrm; ln = nullptr;
+            return 0;
+        };
         const bf16_t *qp, *kp, *vtp = nullptr; int ldq, ldk, Nk, ldvt;
         Tn km, vrow, tws;
         const int tr = (!cross && tome_r > 0 && Nq % 16 == 0) ? tome_effective_r(Nq, tome_r) : 0;
         if (!cross && tr > 0) {
+            TRY(normalise());
             // ToMe (nonfree/tome_unet.py:138-182): K and V of a self-attention are projected row-major, the r most
             // redundant even-position keys are averaged into their best odd-position match (values follow the same
             // assignment), and the attention runs against N - r keys.  Queries are untouched.
@@ -392,10 +457,20 @@ struct Exec {
                 const int tn = pl.cfg == 4 ? 160 : pl.cfg == 5 ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
                 if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
                     fused = true;
+                    Tn stats;
+                    if (ln && ln_fusable(p)) {
+                        TRY(ln_fold_into(p, *ln, stats));
+                        ln = nullptr;
+                    } else {
+                        TRY(normalise());
+                        p.A = xq.p;
+                    }
                     if (!dry()) TRY(launch_gemm(st, p));
+                    free(stats);
                 }
             }
             if (!fused) {
+                TRY(normalise());
                 TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wqk, 2 * C, w.bqk, nullptr, 0, 0, q.p, 2 * C));
                 TRY(linear_t(xq.p, C, B * Nq, C, w.wv, C, w.bv, Nq, ldvt, vt.p));
             }
@@ -403,7 +478,12 @@ struct Exec {
         } else {
             Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
             TRY(alloc(q, B, xq.H, xq.W, C));
-            TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wq, C, w.bq, nullptr, 0, 0, q.p, C));
+            if (ln) {
+                TRY(ln_linear(xq_in, *ln, w.wq, C, w.bq, 0, q.p, C));
+                ln = nullptr;
+            } else {
+                TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wq, C, w.bq, nullptr, 0, 0, q.p, C));
+            }
             if (ctx_cache) {  // K / V^T of this layer were projected when the context was set
                 if (ctx_layer >= ctx_cache->size()) GYRE_FAIL(GYRE_ERR_INVALID, "internal: context cache layer overflow");
                 kp = (*ctx_cache)[ctx_layer].k; vtp = (*ctx_cache)[ctx_layer].vt;
@@ -424,7 +504,7 @@ struct Exec {
             a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = w.k_prescaled;
             TRY(launch_attention(st, a));
         }
-        free(q); free(k); free(vt); free(km);
+        free(q); free(k); free(vt); free(km); free(nrm);
         TRY(alloc(out, B, xq.H, xq.W, C));
         TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C));
         if (sv) sv->ao = ao; else free(ao);
@@ -465,6 +545,21 @@ struct Exec {
             const TBlockW& bw = w.blocks[bi];
             TBlockSave* bs = sv ? &sv->blocks[bi] : nullptr;
             Tn n, h2, ff;
+            if (!bs) {
+                // inference: the three LayerNorms ride inside the GEMMs that consume them (Q|K|V, cross to_q, GEGLU FF1)
+                const LnFold l1{bw.ln1g, bw.ln1b}, l2{bw.ln2g, bw.ln2b}, l3{bw.ln3g, bw.ln3b};
+                TRY(mha(h, false, nullptr, 0, 0, bw.a1, h, h2, nullptr, &l1));
+                free(h); h = h2;
+                TRY(mha(h, true, ctx.p, S, ctx_dim, bw.a2, h, h2, nullptr, &l2));
+                free(h); h = h2;
+                TRY(alloc(ff, B, x.H, x.W, 4 * C));
+                TRY(ln_linear(h, l3, bw.ff1, 8 * C, bw.ff1b, 1, ff.p, 4 * C));
+                TRY(alloc(h2, B, x.H, x.W, C));
+                TRY(linear(ff.p, 4 * C, nullptr, 0, 0, M, 4 * C, bw.ff2, C, bw.ff2b, h.p, C, 0, h2.p, C));
+                free(ff); free(h);
+                h = h2;
+                continue;
+            }
             TRY(layernorm(h, bw.ln1g, bw.ln1b, n));
             TRY(mha(n, false, nullptr, 0, 0, bw.a1, h, h2, bs ? &bs->a1 : nullptr));
             if (bs) { bs->h0 = h; bs->n1 = n; } else { free(n); free(h); }

@@ -252,6 +252,18 @@ int gyre_op_layernorm(void* stream, const void* x, int M, int C, const float* ga
 /* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (+residual); geglu!=0: w holds [2N,K], y = val*gelu(gate) */
 int gyre_op_linear(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N,
                    const float* bias, const void* residual, int geglu, void* y);
+/* y = LayerNorm(x; gamma, beta, eps) @ w^T (+bias) with the normalisation folded into the GEMM: one streaming pass writes each
+ * row's (rstd, rstd * mean), the GEMM multiplies the RAW rows by gamma-scaled weights and its epilogue applies
+ * rstd * acc - rstd * mean * colsum[n] + bias'[n]; the normalised tensor is never written or re-read.  Folded weights,
+ * column constants and row statistics live in `workspace` (gyre_op_ln_linear_workspace(rows of w, K, M) bytes).  This is how
+ * the UNet's transformer blocks run norm1 -> Q|K|V, norm2 -> to_q and norm3 -> GEGLU (third-party BasicTransformerBlock,
+ * reached from gyre/pipeline/unet/core.py:274).  qkv_tokens > 0: w = [3K][K] rows Q | K | V, y = Q | K ([M][2K]), vt_out = V^T
+ * as in gyre_op_qkv.  GYRE_ERR_UNSUPPORTED when the planner's tile configuration for the shape has no folded form (the model
+ * then runs the separate gyre_op_layernorm pass). */
+size_t gyre_op_ln_linear_workspace(int w_rows, int K, int M);
+int gyre_op_ln_linear(void* stream, const void* x, int M, int K, const float* gamma, const float* beta, float eps,
+                      const void* w_bf16_rowmajor, int N, const float* bias, int geglu, int qkv_tokens, void* vt_out, int ldt,
+                      void* workspace, size_t workspace_bytes, void* y);
 /* V^T form used by attention: y[(b*N + n)*ldt + tok] = (x @ w^T + bias)[b*tokens + tok][n] */
 int gyre_op_linear_t(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N,
                      const float* bias, int tokens_per_batch, int ldt, void* y);

@@ -523,6 +523,98 @@ def test_fused_qkv_rejects_unaligned_configs():
 
 
 
+# ---- LayerNorm folded into the consuming GEMM (GemmParams::ln_colsum; gyre_op_ln_linear) -----------------------------------
+def _ln_inputs(M, K, seed, offset=0.3, scale=2.0):
+    x = bf16_round(randn(M, K, seed=seed) * scale + offset)
+    g, b = randn(K, seed=seed + 1) * 0.2 + 1, randn(K, seed=seed + 2) * 0.2
+    return x, g, b
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(65536, 320, 320, True), (16384, 640, 640, False), (4096, 1280, 1280, True),
+                                        (40000, 320, 640, True), (65536, 320, 960, False), (16384 + 56, 640, 1280, True)])
+def test_ln_linear(M, K, N, bias):
+    """y = LayerNorm(x) @ W^T + b without the normalised tensor (row statistics from one streaming pass, gamma folded into the
+    weights, normalisation in the GEMM epilogue): against the fp32 reference and against the HIP path it replaces."""
+    L = _lib.lib()
+    x, g, b = _ln_inputs(M, K, 90)
+    w = bf16_round(randn(N, K, seed=93) / math.sqrt(K))
+    bias_t = randn(N, seed=94) if bias else None
+    ref = F.linear(F.layer_norm(x, (K,), g, b, 1e-5), w, bias_t)
+    xd, wd = to_dev_bf16(x), repack_linear(w)
+    gd, bd = g.to(DEV), b.to(DEV)
+    bias_d = bias_t.to(DEV) if bias else None
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
+    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_ln_linear(st(), vp(xd), M, K, vp(gd), vp(bd), 1e-5, vp(wd), N, vp(bias_d) if bias else None, 0, 0, None, 0,
+                                   vp(ws), ws.numel(), vp(y)))
+    report(f"ln_linear M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
+    n = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_layernorm(st(), vp(xd), M, K, vp(gd), vp(bd), 1e-5, vp(n)))
+    _lib.check(L.gyre_op_linear(st(), vp(n), M, K, vp(wd), N, vp(bias_d) if bias else None, None, 0, vp(y2)))
+    e_fused, e_two = rel_l2(y.float().cpu(), ref), rel_l2(y2.float().cpu(), ref)
+    assert e_fused <= 1.25 * e_two + 1e-4, (e_fused, e_two)          # no worse than the path it replaces
+    # rows are independent: the same rows inside a smaller problem give the same bits
+    Ms = 4096
+    if M > Ms and L.gyre_op_ln_linear(st(), vp(xd), Ms, K, vp(gd), vp(bd), 1e-5, vp(wd), N, vp(bias_d) if bias else None, 0, 0, None,
+                                      0, vp(ws), ws.numel(), vp(y2)) == 0:
+        assert torch.equal(y2[:Ms], y[:Ms])
+
+
+@pytest.mark.parametrize("M,K,F_", [(65536, 320, 1280), (16384, 640, 2560), (4096, 1280, 5120)])
+def test_ln_linear_geglu(M, K, F_):
+    L = _lib.lib()
+    x, g, b = _ln_inputs(M, K, 95)
+    w = bf16_round(randn(2 * F_, K, seed=98) / math.sqrt(K))
+    bias_t = randn(2 * F_, seed=99) * 0.5
+    val, gate = F.linear(F.layer_norm(x, (K,), g, b, 1e-5), w, bias_t).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(2 * F_, K, M), dtype=torch.uint8, device=DEV)
+    y = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w, geglu=True)), F_,
+                                   vp(repack_bias(bias_t, geglu=True)), 1, 0, None, 0, vp(ws), ws.numel(), vp(y)))
+    report(f"ln_geglu M{M} K{K} F{F_}", y.float().cpu(), ref, TOL)
+
+
+@pytest.mark.parametrize("B,tokens,C", [(16, 4096, 320), (16, 1024, 640), (16, 256, 1280), (3, 1032, 320)])
+def test_ln_fused_qkv(B, tokens, C):
+    """norm1 -> Q | K | V of a self-attention as one launch, V leaving through the transposing epilogue."""
+    L = _lib.lib()
+    M = B * tokens
+    x, g, b = _ln_inputs(M, C, 100)
+    w = bf16_round(randn(3 * C, C, seed=103) / math.sqrt(C))
+    ref = F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w)
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(3 * C, C, M), dtype=torch.uint8, device=DEV)
+    qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), 3 * C, None, 0,
+                             tokens, vp(vt), tokens, vp(ws), ws.numel(), vp(qk))
+    if rc == -6:
+        pytest.skip("planner picks a tile config without the folded form for this shape")
+    _lib.check(rc)
+    report(f"ln_qkv QK part B{B} T{tokens} C{C}", qk.float().cpu(), ref[:, :2 * C], TOL)
+    report(f"ln_qkv V^T part", vt.float().cpu(), ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1), TOL)
+
+
+def test_ln_linear_large_mean_and_small_shapes():
+    """|mean| = 8 sigma (the epilogue subtracts rstd * mean * colsum from rstd * acc in fp32); shapes the planner gives to a 4-wave kernel are
+    refused (GYRE_ERR_UNSUPPORTED) - the model then runs the separate LayerNorm."""
+    L = _lib.lib()
+    M, K, N = 65536, 320, 320
+    x, g, b = _ln_inputs(M, K, 105, offset=8.0, scale=1.0)
+    w = bf16_round(randn(N, K, seed=108) / math.sqrt(K))
+    ref = F.linear(F.layer_norm(x, (K,), g, b, 1e-5), w)
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), N, None, 0, 0,
+                                   None, 0, vp(ws), ws.numel(), vp(y)))
+    report("ln_linear mean = 8 sigma", y.float().cpu(), ref, 2 * TOL)
+    xs = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV); wsm = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    gs = torch.ones(64, device=DEV); ys = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, vp(ws), ws.numel(), vp(ys)) == -6
+    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, vp(ws), 16, vp(ys)) == -4
+
+
 # ---- pipelined 32x32x16 tile configs (kernels_gemm4s.hip): 4 waves 20 = 192x320, 21 = 256x256, 22 = 128x320, 23 = 128x256;
 # 8 waves 24 = 256x320 ----------
 def _ablation(bits):

@@ -7,10 +7,10 @@ single UNet call rel-L2 <= 3e-2, VAE <= 3e-2.
 import pytest
 import torch
 
-from gyre_amd import config as gcfg
+from gyre_amd import _lib, config as gcfg
 from gyre_amd import weights
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
-from gpu_util import DEV, randn, report
+from gpu_util import DEV, randn, rel_l2, report
 from oracle import models_ref as M
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +114,17 @@ def test_sd15_unet_parity_full_size():
     ref = M.unet_forward(sd, cfg, x, t, ctx)
     got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
     report("SD1.5 unet 2x4x64x64", got.cpu(), ref, 3e-2)
+    # the same call with the transformer blocks' LayerNorms as separate passes instead of folded into their GEMMs
+    # (planner debug bit 11): both forms sit at the same distance from the oracle
+    L = _lib.lib()
+    old = L.gyre_debug_gemm_ablation(0x800)
+    try:
+        plain = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    finally:
+        L.gyre_debug_gemm_ablation(old)
+    report("SD1.5 unet 2x4x64x64, separate LayerNorm passes", plain.cpu(), ref, 3e-2)
+    e_f, e_p = rel_l2(got.cpu(), ref), rel_l2(plain.cpu(), ref)
+    assert e_f < 1.3 * e_p + 1e-3, (e_f, e_p)
 
 
 def test_sd15_vae_decode_full_size():

@@ -160,3 +160,41 @@ def test_batch_invariant_mode_makes_any_split_bit_exact_full_size():
     finally:
         set_batch_invariant(prev)
     assert _lib.lib().gyre_get_batch_invariant() == prev
+
+
+def test_folded_layernorm_full_size_matches_the_separate_pass_and_follows_weight_updates():
+    """The transformer blocks' LayerNorms ride in the epilogue of the GEMMs that consume them (GemmParams::ln_colsum, folded
+    weight copies cached per handle).  Full SD1.5 UNet at batch 16: same result as with the separate LayerNorm pass
+    (planner debug bit 11) up to bf16 rounding; the cached copies are rebuilt when a weight is re-uploaded (per-request
+    LoRA merge), LayerNorm affine parameters included."""
+    L = _lib.lib()
+    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
+    ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
+    t = torch.full((16,), 500, device=DEV)
+
+    def both():
+        fused = net(x, t, encoder_hidden_states=ctx).sample.float()
+        old = L.gyre_debug_gemm_ablation(0x800)
+        try:
+            plain = net(x, t, encoder_hidden_states=ctx).sample.float()
+        finally:
+            L.gyre_debug_gemm_ablation(old)
+        return fused, plain
+    fused, plain = both()
+    assert not torch.equal(fused, plain)                       # the folded path really ran
+    err = float((fused - plain).norm() / plain.norm())
+    print(f"folded vs separate LayerNorm, full UNet: rel-L2 {err:.2e}")
+    assert err < 2.5e-2          # two bf16 evaluation orders of a 16-block network (each ~1e-2 from the fp32 oracle)
+    assert torch.equal(fused, net(x, t, encoder_hidden_states=ctx).sample.float())     # deterministic
+    with torch.no_grad():
+        params = dict(net.named_parameters())
+        blk = "down_blocks.0.attentions.0.transformer_blocks.0."
+        params[blk + "norm1.weight"].mul_(1.5); params[blk + "norm3.bias"].add_(0.25)
+        params[blk + "attn2.to_q.weight"].mul_(-1.0); params[blk + "ff.net.0.proj.weight"].mul_(0.5)
+    net._invalidate()
+    fused2, plain2 = both()
+    assert float((plain2 - plain).norm() / plain.norm()) > 1e-3          # the update changes the output ...
+    err2 = float((fused2 - plain2).norm() / plain2.norm())
+    assert err2 < 2.5e-2, err2                                             # ... and the folded copies followed it

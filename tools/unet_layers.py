@@ -11,18 +11,19 @@ if os.environ.get("GYRE_PROF_DUMP") is None:
         key = (name, fl, by)
         rows.setdefault(key, []).append(float(us.split()[0]))
     tot = sum(sum(v) for v in rows.values())
-    print(out.stdout[-400:])
+    print(out.stdout[-400:], out.stderr[-600:] if out.returncode else '')
     print(f"total timed {tot / 1e3:.2f} ms")
     for (name, fl, by), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
         mf = float(fl.split()[0]); kb = float(by.split()[0]); t = sum(v) / len(v)
-        print(f"{name:30s} x{len(v):3d}  {sum(v):8.1f} us tot  {t:7.1f} us each  {mf / t / 1e0 / 1e6 * 1e6 / 1e6:7.0f} TF  {kb / t / 1e3:6.2f} TB/s  [{fl}, {by}]")
+        print(f"{name:30s} x{len(v):3d}  {sum(v):8.1f} us tot  {t:7.1f} us each  {mf / t:7.0f} TF  {kb / t / 1e3:6.2f} TB/s  [{fl}, {by}]")
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gyre_amd import config as gcfg, _lib
-from gyre_amd.modules import GyreHipUNet
+from gyre_amd.modules import GyreHipUNet, GyreHipVAE
 B = int(os.environ.get("B", "16")); H = int(os.environ.get("LAT", "64")); dev = "cuda:0"; L = _lib.lib()
-net = GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(dev)
+VAE = os.environ.get("MODEL") == "vae"                      # MODEL=vae B=8: one decode of B latents instead of the UNet
+net = (GyreHipVAE(gcfg.sd15_vae()) if VAE else GyreHipUNet(gcfg.sd15_unet())).to(torch.bfloat16).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 with torch.no_grad():
     for k, p in net.named_parameters():
@@ -32,8 +33,13 @@ with torch.no_grad():
 net._invalidate()
 x = torch.randn(B, 4, H, H, device=dev); t = torch.full((B,), 500, device=dev); ctx = torch.randn(B, 77, 768, device=dev)
 L.gyre_debug_gemm_ablation(int(sys.argv[1], 0) if len(sys.argv) > 1 else 0)
-for _ in range(2): net(x, t, encoder_hidden_states=ctx)
-torch.cuda.synchronize(); _lib.prof_enable(None)
-net(x, t, encoder_hidden_states=ctx); torch.cuda.synchronize()
+run = (lambda: net.decode(x)) if VAE else (lambda: net(x, t, encoder_hidden_states=ctx))
+for _ in range(2): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+print(f"uninstrumented call: {e0.elapsed_time(e1):.2f} ms")
+_lib.prof_enable(None)
+run(); torch.cuda.synchronize()
 _lib.prof_collect()
 print("done")
