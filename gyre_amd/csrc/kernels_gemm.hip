@@ -853,6 +853,9 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         const int nk_ = (p.K + BK - 1) / BK;
         if (!(p.debug & 0x400) && p.N % 320 == 0 && (p.mode == GEMM_CONV3 ? nk_ >= 20 : nk_ >= 32) && gemm4s_supports(p, 24))
             big(24, 1.00, 256, 320);
+        // (GEGLU FF1 on the pipelined tile: wins a cache-evicting isolated comparison - COLD=1 tools/geglu_compare.py: 64x64
+        //  202 -> 190 us, 32x32 141 -> 131, 16x16 140 -> 109 - and LOSES in the UNet, forward 19.56 -> 19.83 ms same-box A/B:
+        //  not taken, like the other short-K shapes)
         // few output tiles but a long reduction (the 8x8 / 16x16 UNet levels: K = 9*Cin up to 23040): cut K into
         // slices so that tiles x slices covers the chip; fp32 slabs are reduced by k_splitk_reduce
         const int nk = (p.K + BK - 1) / BK;

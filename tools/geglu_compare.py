@@ -8,9 +8,20 @@ vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 rnd = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
 cfgs = [int(a, 0) for a in sys.argv[1:]] or [0, 6, 7, 10]
+COLD = os.environ.get("COLD") == "1"      # evict L2 / Infinity Cache before every timed launch (the in-UNet regime)
+if COLD:
+    fl_a = torch.empty(384 << 20, dtype=torch.uint8, device=DEV); fl_b = torch.empty(384 << 20, dtype=torch.uint8, device=DEV)
 def timeit(fn, iters=10):
     for _ in range(2): fn()
     torch.cuda.synchronize()
+    if COLD:
+        tot = 0.0
+        for _ in range(6):
+            fl_a.copy_(fl_b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / 6 * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): fn()
