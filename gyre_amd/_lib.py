@@ -88,7 +88,9 @@ _SIGS = {
     "gyre_op_linear": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "gyre_op_linear_t": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "gyre_op_ln_linear_workspace": (_sz, [_i, _i, _i]),
-    "gyre_op_ln_linear": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "gyre_op_ln_linear": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "gyre_op_linear_rowstats_parts": (_i, [_i, _i, _i, _i]),
+    "gyre_op_linear_rowstats": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "gyre_op_conv3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "gyre_op_repack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gyre_op_repack_linear_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -89,7 +89,16 @@ struct GemmParams {
     // and measured: every N tile repeats the sums at ~20 cycles per packed pair, slower than the separate statistics pass
     // for every layer of the UNet; profiles/README.md.)
     const float* ln_colsum = nullptr; const float* ln_stats = nullptr;
+    // Statistics straight from the kernel that PRODUCED the rows: rowstat_out (8-wave kernels, staged epilogue, no GEGLU /
+    // split-K / fused V^T; gemm_rowstat_parts() > 0) receives [tiles_n][M][2] = per row the sum and the sum of squares of the
+    // bf16-rounded outputs of each N tile, reduced in a fixed order (lanes -> waves -> tile).  A consumer with the folded
+    // LayerNorm takes them as ln_parts / ln_nparts instead of ln_stats and finishes mean / rstd in its epilogue
+    // (variance as E[x^2] - mean^2 in fp32): the separate statistics pass disappears.
+    float* rowstat_out = nullptr;
+    const float* ln_parts = nullptr; int ln_nparts = 0; float ln_eps = 1e-5f;
 };
+// number of N tiles (= partial sums per row) launch_gemm would emit into rowstat_out for `p`; 0: this problem cannot
+int gemm_rowstat_parts(const GemmParams& p);
 // true when launch_gemm would run `p` (ln_colsum set or not) on a kernel that supports the folded LayerNorm
 bool gemm_ln_fusable(const GemmParams& p);
 // W'[n][k] = bf16(W[n][k] * gamma[k]); colsum[n] = sum_k W'[n][k]; bias_out[n] = sum_k beta[k] * W[n][k] + (bias ? bias[n] : 0)

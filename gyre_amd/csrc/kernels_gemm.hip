@@ -111,11 +111,14 @@ __device__ __forceinline__ float4 ep_affine(const f32x4_t& a, const float4& b, c
     return make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
 }
 
-template <int MI, int NI, int TN, bool GG, bool LNF = false>
+// RS: per-row (sum, sum of squares) of this wave tile's rounded outputs -> rs_row[row of the wave tile] (LDS); rs_part = per-wave
+// LDS scratch of 16 x (TN / 8) float2 (GemmParams::rowstat_out)
+template <int MI, int NI, int TN, bool GG, bool LNF = false, bool RS = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
                                                      int fr, int fq, int lane, float* my, const float* lrstd = nullptr,
                                                      const float* lrmu = nullptr, const float* lcs = nullptr,
-                                                     const float* lbb = nullptr) {
+                                                     const float* lbb = nullptr, float2* rs_part = nullptr,
+                                                     float2* rs_row = nullptr) {
     constexpr int TNO_FULL = TN;                 // staged columns per wave without GEGLU
     constexpr bool gg = GG;
     constexpr int tno = gg ? TNO_FULL / 2 : TNO_FULL;    // output columns this wave produces
@@ -188,6 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
             const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
             const float4 lo = *(const float4*)(my + row * rowf + c8 * 8);
             const float4 hi = *(const float4*)(my + row * rowf + c8 * 8 + 4);
+            float rs_s = 0.f, rs_q = 0.f;
             if (mm < p.M && nn < n_out) {
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (p.residual) {
@@ -196,8 +200,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += r[e];
                 }
-                *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pack8(f);
+                const uint4 pk = pack8(f);
+                *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pk;
+                if (RS) {           // statistics of what the consumer will read: the rounded values
+                    unpack8(pk, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { rs_s += f[e]; rs_q = fmaf(f[e], f[e], rs_q); }
+                }
             }
+            if (RS) rs_part[v] = make_float2(rs_s, rs_q);       // v = row * vec_per_row + c8
+        }
+        if (RS) {
+            // LDS operations of one wave complete in order: the 16 row sums below see this slab's partials
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) {
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < vec_per_row; ++c) { const float2 t = rs_part[lane * vec_per_row + c]; su += t.x; sq += t.y; }
+                rs_row[i * 16 + lane] = make_float2(su, sq);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -255,7 +277,8 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
 // (guide rule 21).  Zero padding (conv halo, M/N/K tails) is fetched from a 256-byte zero page.
 // ------------------------------------------------------------------------------------------------
 // LNF: folded LayerNorm (GemmParams::ln_colsum / ln_stats) applied by the staged epilogue
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false>
+// RS: also emit per-row partial statistics of the output tile (GemmParams::rowstat_out)
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false, bool RS = false>
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -397,7 +420,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (!LNF && splits > 1) {     // (the folded-LayerNorm form is launched unsplit, with the staged epilogue only)
+    if (!LNF && !RS && splits > 1) {     // (the folded-LayerNorm / row-statistics forms are launched unsplit, staged epilogue only)
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
         return;
     }
-    if (!LNF && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+    if (!LNF && !RS && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     }
     // coalesced LDS-staged epilogue when every 8-channel group is 16-byte addressable, else the direct one
     const int n_out = p.geglu ? p.N / 2 : p.N;
-    if (LNF || (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+    if (LNF || RS || (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
                 (((size_t)p.out | (size_t)p.residual) & 15) == 0)) {
         float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
         float lrstd[MI], lrmu[MI];
@@ -439,13 +462,45 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
             }
             __syncthreads();
             lcs = colc + wn * TN; lbb = colc + BN + wn * TN;
-            // per-row statistics of the rows this lane's accumulators belong to (launch_layernorm_stats)
+            // per-row statistics of the rows this lane's accumulators belong to: from the separate pass
+            // (launch_layernorm_stats) or from the partial sums the producing GEMM left (rowstat_out of that launch)
+            const float invk = 1.0f / (float)p.K;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = m0 + wm * TM + i * 16 + fr;
-                const float2 rs = m < p.M ? ((const float2*)p.ln_stats)[m] : make_float2(1.f, 0.f);
+                float2 rs = make_float2(1.f, 0.f);
+                if (m < p.M) {
+                    if (p.ln_nparts > 0) {
+                        float su = 0.f, sq = 0.f;
+                        for (int t = 0; t < p.ln_nparts; ++t) {
+                            const float2 v = ((const float2*)p.ln_parts)[(size_t)t * p.M + m];
+                            su += v.x; sq += v.y;
+                        }
+                        const float mean = su * invk;
+                        const float rstd = 1.0f / sqrtf(fmaxf(sq * invk - mean * mean, 0.f) + p.ln_eps);
+                        rs = make_float2(rstd, rstd * mean);
+                    } else {
+                        rs = ((const float2*)p.ln_stats)[m];
+                    }
+                }
                 lrstd[i] = rs.x; lrmu[i] = rs.y;
             }
+        }
+        if constexpr (RS) {
+            // wave tile rows -> LDS [WN][BM] behind the slabs and the per-wave scratch; after the block barrier one thread per
+            // row adds the WN wave tiles in order and writes the tile's partial
+            float2* rs_part = (float2*)((float*)smem_raw + 8 * 16 * (TN + 4)) + wave * (16 * (TN / 8));
+            float2* rs_all = (float2*)((float*)smem_raw + 8 * 16 * (TN + 4)) + 8 * (16 * (TN / 8));
+            gemm_epilogue_staged<MI, NI, TN, false, false, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, nullptr, nullptr,
+                                                                   nullptr, nullptr, rs_part, rs_all + wn * BM + wm * TM);
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { const float2 t = rs_all[w * BM + tid]; su += t.x; sq += t.y; }
+                ((float2*)p.rowstat_out)[(size_t)tn * p.M + m0 + tid] = make_float2(su, sq);
+            }
+            return;
         }
         if (p.vt_out && n0 + wn * TN >= p.vt_col0) {             // V columns of a fused Q|K|V projection (wave-uniform)
             gemm_epilogue_staged_t<MI, NI, TN, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
@@ -457,7 +512,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         gemm_epilogue_staged<MI, NI, TN, false, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
         return;
     }
-    if constexpr (!LNF) gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+    if constexpr (!LNF && !RS) gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
 }
 
 // out = bf16( sum_s slab[s] + bias + rowbias + residual ), fixed summation order (deterministic)
@@ -797,7 +852,13 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
-    if (p.mode == GEMM_LINEAR && p.ln_colsum) {
+    if (p.mode == GEMM_LINEAR && p.rowstat_out) {
+        auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, false, true>;
+        static std::atomic<unsigned long long> attr_done{0};
+        if (gyre_lds_attr_needed(attr_done))
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);
+    } else if (p.mode == GEMM_LINEAR && p.ln_colsum) {
         auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, true>;
         static std::atomic<unsigned long long> attr_done{0};
         if (gyre_lds_attr_needed(attr_done))
@@ -954,6 +1015,20 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     return true;
 }
 
+int gemm_rowstat_parts(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    if (g_force_cfg || p.force_cfg || (p.debug & 0x8800) || g_invariant_batch > 0) return 0;    // bit 15: separate statistics pass
+    if (p.mode != GEMM_LINEAR || p.A2 || p.rowbias || p.geglu || p.vt_out || p.ln_colsum || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 8)
+        return 0;
+    if (!gemm_staged_epilogue_ok(p)) return 0;
+    int splits = 1;
+    const int cfg = plan_cfg(p, &splits);
+    if (cfg < 4 || cfg > 7 || splits > 1) return 0;
+    const int bn = (cfg == 4 || cfg == 5) ? 320 : 256;
+    return (p.N + bn - 1) / bn;
+}
+
 GemmPlan gemm_plan(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;      // same planner inputs as launch_gemm
@@ -987,7 +1062,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             p.vt_col0 <= 0 || p.vt_col0 >= p.N || p.N % 8)
             GYRE_FAIL(-1, "gemm: bad fused Q|K|V arguments");
     }
-    if (p.ln_colsum && (p.mode != GEMM_LINEAR || p0.A2 || !p.bias || !p.ln_stats || p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
+    if (p.rowstat_out && (p.ln_colsum || p.mode != GEMM_LINEAR || p0.A2 || p.geglu || p.vt_out || p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
+        GYRE_FAIL(-1, "gemm: row statistics come from a plain single-source linear problem with bf16 row-major output");
+    if (p.ln_colsum && (p.mode != GEMM_LINEAR || p0.A2 || !p.bias || (!p.ln_stats && p.ln_nparts <= 0) || (p.ln_nparts > 0 && !p.ln_parts) ||
+                        p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
         GYRE_FAIL(-1, "gemm: the folded LayerNorm needs a single-source linear problem with row statistics, bias and bf16 row-major output");
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
@@ -1011,6 +1089,8 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
+    if (p.rowstat_out && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
+        GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");
     if (p.ln_colsum && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: the folded LayerNorm needs an unsplit 8-wave tile config with the staged epilogue (see gemm_ln_fusable)");
     if (cfg >= 4) {

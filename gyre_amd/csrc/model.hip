@@ -407,9 +407,29 @@ int gyre_op_qkv(void* st, const void* x, int M, int C, const void* w_qkv, int to
 size_t gyre_op_ln_linear_workspace(int w_rows, int K, int M) {
     return align_up((size_t)w_rows * K * 2, 256) + 2 * align_up((size_t)w_rows * 4, 256) + align_up((size_t)M * 8, 256);
 }
+// y = x @ w^T (+bias) (+residual) as gyre_op_linear, and per row the partial (sum, sum of squares) of the rounded outputs of
+// every N tile: stats_out [parts][M][2] with parts = gyre_op_linear_rowstats_parts(M, K, N, residual != 0) (0: not available
+// for this shape).  Input of gyre_op_ln_linear's row_parts.
+int gyre_op_linear_rowstats_parts(int M, int K, int N, int has_residual) {
+    GemmParams p;
+    p.lda = K; p.mode = GEMM_LINEAR; p.K = K; p.N = N; p.M = M; p.ldr = N; p.ldc = N; p.out_mode = OUT_BF16;
+    if (has_residual) p.residual = (const bf16_t*)(uintptr_t)256;      // shape query only: any aligned non-null value
+    return gemm_rowstat_parts(p);
+}
+int gyre_op_linear_rowstats(void* st, const void* x, int M, int K, const void* w, int N, const float* bias, const void* residual,
+                            void* y, float* stats_out) {
+    if (!x || !w || !y || !stats_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K;
+    p.N = N; p.M = M; p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = N;
+    p.out = y; p.ldc = N; p.out_mode = OUT_BF16;
+    if (gemm_rowstat_parts(p) <= 0) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "linear_rowstats: the planner's kernel for this shape cannot emit row statistics");
+    p.rowstat_out = stats_out;
+    return launch_gemm((hipStream_t)st, p);
+}
 int gyre_op_ln_linear(void* st, const void* x, int M, int K, const float* gamma, const float* beta, float eps, const void* w,
-                      int N, const float* bias, int geglu, int qkv_tokens, void* vt_out, int ldt, void* ws,
-                      size_t ws_bytes, void* y) {
+                      int N, const float* bias, int geglu, int qkv_tokens, void* vt_out, int ldt, const float* row_parts,
+                      int n_parts, void* ws, size_t ws_bytes, void* y) {
     if (!x || !w || !y || !gamma || !beta || !ws) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     GemmParams p;
     p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K; p.M = M; p.bias = bias;
@@ -427,9 +447,13 @@ int gyre_op_ln_linear(void* st, const void* x, int M, int K, const float* gamma,
     float* cs = (float*)((char*)ws + align_up((size_t)p.N * K * 2, 256));
     float* bb = (float*)((char*)cs + align_up((size_t)p.N * 4, 256));
     TRY(launch_ln_fold((hipStream_t)st, p.W, p.N, K, gamma, beta, bias, wf, cs, bb));
-    float* stats = (float*)((char*)bb + align_up((size_t)p.N * 4, 256));
-    TRY(launch_layernorm_stats((hipStream_t)st, p.A, M, K, eps, stats));
-    p.ln_stats = stats;
+    if (row_parts && n_parts > 0) {      // partial sums left by the GEMM that produced x (gyre_op_linear_rowstats)
+        p.ln_parts = row_parts; p.ln_nparts = n_parts; p.ln_eps = eps;
+    } else {
+        float* stats = (float*)((char*)bb + align_up((size_t)p.N * 4, 256));
+        TRY(launch_layernorm_stats((hipStream_t)st, p.A, M, K, eps, stats));
+        p.ln_stats = stats;
+    }
     p.W = wf; p.bias = bb; p.ln_colsum = cs;
     return launch_gemm((hipStream_t)st, p);
 }

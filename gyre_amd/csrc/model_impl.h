@@ -344,12 +344,26 @@ struct Exec {
         return launch_gemm(st, p);
     }
     // y[M][N] = x[M][K] (|| x2) @ w^T + bias (+ residual); geglu halves N
+    // Per-row partial statistics of a linear layer's output, left by its epilogue for the folded LayerNorm of the next GEMM
+    // (GemmParams::rowstat_out -> ln_parts).  nparts == 0: the producer could not (4-wave tile, split K, ...): the consumer
+    // runs the separate statistics pass.
+    struct RowStatBuf { Tn t; int nparts = 0; };
+    // rs: the caller wants the row statistics of y (and frees rs->t after the consumer ran)
     int linear(const bf16_t* x, int lda, const bf16_t* x2, int lda2, int C1, int M, int K, const bf16_t* w, int N,
-               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc) {
+               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc, RowStatBuf* rs = nullptr) {
         GemmParams p;
         p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
         p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
         p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
+        if (rs) {
+            if (!p.samples) p.samples = batch;
+            rs->nparts = store ? gemm_rowstat_parts(p) : 0;
+            if (rs->nparts > 0) {
+                TRY(alloc_raw(rs->t, (size_t)rs->nparts * M * 2 * sizeof(float)));
+                p.rowstat_out = (float*)rs->t.p;
+                if (dry()) p.rowstat_out = nullptr;
+            }
+        }
         return run_gemm(p);
     }
     int linear_t(const bf16_t* x, int lda, int M, int K, const bf16_t* w, int N, const float* bias, int tokens, int ldt,
@@ -368,14 +382,18 @@ struct Exec {
     // LayerNorm folded into the GEMM that consumes it (kernels.h GemmParams::ln_colsum): `p` describes the product of the RAW
     // rows with the layer's own weights / bias; on return it points at the gamma-folded copies (made on first use per handle,
     // refreshed after any gyre_*_set_weight) and the launch normalises on the fly - the normalised tensor never exists.
-    struct LnFold { const float* g; const float* b; };
+    struct LnFold { const float* g; const float* b; const RowStatBuf* have = nullptr; };
     bool ln_fusable(const GemmParams& p) const { return store && gemm_ln_fusable(p); }
     // `stats`: arena scratch for the per-row statistics (one streaming pass over the rows); freed by the caller after the launch
     int ln_fold_into(GemmParams& p, const LnFold& ln, Tn& stats) {
-        TRY(alloc_raw(stats, (size_t)p.M * 2 * sizeof(float)));
-        if (!dry()) {
-            TRY(launch_layernorm_stats(st, p.A, p.M, p.K, 1e-5f, (float*)stats.p));
-            p.ln_stats = (const float*)stats.p;
+        if (ln.have && ln.have->nparts > 0) {           // the producer of these rows left their partial sums
+            p.ln_parts = (const float*)ln.have->t.p; p.ln_nparts = ln.have->nparts; p.ln_eps = 1e-5f;
+        } else {
+            TRY(alloc_raw(stats, (size_t)p.M * 2 * sizeof(float)));
+            if (!dry()) {
+                TRY(launch_layernorm_stats(st, p.A, p.M, p.K, 1e-5f, (float*)stats.p));
+                p.ln_stats = (const float*)stats.p;
+            }
         }
         if (dry()) return 0;
         bool fresh = false;
@@ -407,7 +425,7 @@ struct Exec {
     // multi-head attention of tokens x against kv source (self: kv == nullptr); out = proj(attn) + residual
     // ln != nullptr: xq_in holds the rows BEFORE the block's LayerNorm; the projections fold it where they can
     int mha(const Tn& xq_in, bool cross, const bf16_t* kvsrc, int kv_rows_per_batch, int kv_dim, const AttnW& w,
-            const Tn& residual, Tn& out, MhaSave* sv = nullptr, const LnFold* ln = nullptr) {
+            const Tn& residual, Tn& out, MhaSave* sv = nullptr, const LnFold* ln = nullptr, RowStatBuf* rs_out = nullptr) {
         const int B = xq_in.B, Nq = xq_in.H * xq_in.W, C = w.c, D = C / w.heads;
         Tn q, k, vt, ao, nrm;
         Tn xq = xq_in;
@@ -506,7 +524,7 @@ struct Exec {
         }
         free(q); free(k); free(vt); free(km); free(nrm);
         TRY(alloc(out, B, xq.H, xq.W, C));
-        TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C));
+        TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C, rs_out));
         if (sv) sv->ao = ao; else free(ao);
         return 0;
     }
@@ -538,7 +556,8 @@ struct Exec {
         Tn a, h;
         TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
         TRY(alloc(h, B, x.H, x.W, C));
-        TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C));
+        RowStatBuf rs_h;                 // statistics of the current block input, when its producer could leave them
+        TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C, sv ? nullptr : &rs_h));
         free(a);
         if (sv) sv->blocks.assign(w.blocks.size(), TBlockSave());
         for (size_t bi = 0; bi < w.blocks.size(); ++bi) {
@@ -547,15 +566,23 @@ struct Exec {
             Tn n, h2, ff;
             if (!bs) {
                 // inference: the three LayerNorms ride inside the GEMMs that consume them (Q|K|V, cross to_q, GEGLU FF1)
-                const LnFold l1{bw.ln1g, bw.ln1b}, l2{bw.ln2g, bw.ln2b}, l3{bw.ln3g, bw.ln3b};
-                TRY(mha(h, false, nullptr, 0, 0, bw.a1, h, h2, nullptr, &l1));
-                free(h); h = h2;
-                TRY(mha(h, true, ctx.p, S, ctx_dim, bw.a2, h, h2, nullptr, &l2));
-                free(h); h = h2;
+                // each producer of a block-internal tensor (proj_in / FF2 of the previous block, the two to_out) leaves the
+                // row sums its consumer's LayerNorm needs, so no statistics pass runs in between
+                RowStatBuf rs1, rs2, rs3;
+                const LnFold l1{bw.ln1g, bw.ln1b, &rs_h};
+                TRY(mha(h, false, nullptr, 0, 0, bw.a1, h, h2, nullptr, &l1, &rs1));
+                free(rs_h.t); rs_h.nparts = 0; free(h); h = h2;
+                const LnFold l2{bw.ln2g, bw.ln2b, &rs1};
+                TRY(mha(h, true, ctx.p, S, ctx_dim, bw.a2, h, h2, nullptr, &l2, &rs2));
+                free(rs1.t); free(h); h = h2;
+                const LnFold l3{bw.ln3g, bw.ln3b, &rs2};
                 TRY(alloc(ff, B, x.H, x.W, 4 * C));
                 TRY(ln_linear(h, l3, bw.ff1, 8 * C, bw.ff1b, 1, ff.p, 4 * C));
+                free(rs2.t);
                 TRY(alloc(h2, B, x.H, x.W, C));
-                TRY(linear(ff.p, 4 * C, nullptr, 0, 0, M, 4 * C, bw.ff2, C, bw.ff2b, h.p, C, 0, h2.p, C));
+                const bool more = bi + 1 < w.blocks.size();
+                TRY(linear(ff.p, 4 * C, nullptr, 0, 0, M, 4 * C, bw.ff2, C, bw.ff2b, h.p, C, 0, h2.p, C, more ? &rs3 : nullptr));
+                if (more) rs_h = rs3;
                 free(ff); free(h);
                 h = h2;
                 continue;
@@ -578,6 +605,7 @@ struct Exec {
             if (bs) bs->h2 = h; else free(h);
             h = h2;
         }
+        free(rs_h.t);
         TRY(alloc(out, B, x.H, x.W, C));
         TRY(linear(h.p, C, nullptr, 0, 0, M, C, w.pout, C, w.poutb, x.p, C, 0, out.p, C));
         if (sv) sv->hlast = h; else free(h);

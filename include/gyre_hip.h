@@ -261,9 +261,18 @@ int gyre_op_linear(void* stream, const void* x, int M, int K, const void* w_bf16
  * as in gyre_op_qkv.  GYRE_ERR_UNSUPPORTED when the planner's tile configuration for the shape has no folded form (the model
  * then runs the separate gyre_op_layernorm pass). */
 size_t gyre_op_ln_linear_workspace(int w_rows, int K, int M);
+/* row_parts / n_parts: instead of the streaming statistics pass, take the partial row sums the PRODUCER of x left
+ * (gyre_op_linear_rowstats); NULL / 0: run the pass. */
 int gyre_op_ln_linear(void* stream, const void* x, int M, int K, const float* gamma, const float* beta, float eps,
                       const void* w_bf16_rowmajor, int N, const float* bias, int geglu, int qkv_tokens, void* vt_out, int ldt,
-                      void* workspace, size_t workspace_bytes, void* y);
+                      const float* row_parts, int n_parts, void* workspace, size_t workspace_bytes, void* y);
+/* gyre_op_linear that also leaves, per row, the (sum, sum of squares) of the bf16-rounded outputs of each of its N tiles:
+ * stats_out [parts][M][2] f32, parts = gyre_op_linear_rowstats_parts(...) (0 = the planner's kernel for the shape has no such
+ * epilogue -> GYRE_ERR_UNSUPPORTED).  In the UNet the producers of a transformer block's internal tensors (proj_in, the two
+ * attention to_out projections, FF2 of a previous block) hand these to the LayerNorm folded into the next GEMM. */
+int gyre_op_linear_rowstats_parts(int M, int K, int N, int has_residual);
+int gyre_op_linear_rowstats(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N, const float* bias,
+                            const void* residual, void* y, float* stats_out);
 /* V^T form used by attention: y[(b*N + n)*ldt + tok] = (x @ w^T + bias)[b*tokens + tok][n] */
 int gyre_op_linear_t(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N,
                      const float* bias, int tokens_per_batch, int ldt, void* y);

@@ -546,7 +546,7 @@ def test_ln_linear(M, K, N, bias):
     ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
     y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(xd), M, K, vp(gd), vp(bd), 1e-5, vp(wd), N, vp(bias_d) if bias else None, 0, 0, None, 0,
-                                   vp(ws), ws.numel(), vp(y)))
+                                   None, 0, vp(ws), ws.numel(), vp(y)))
     report(f"ln_linear M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
     n = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
     y2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
@@ -557,7 +557,7 @@ def test_ln_linear(M, K, N, bias):
     # rows are independent: the same rows inside a smaller problem give the same bits
     Ms = 4096
     if M > Ms and L.gyre_op_ln_linear(st(), vp(xd), Ms, K, vp(gd), vp(bd), 1e-5, vp(wd), N, vp(bias_d) if bias else None, 0, 0, None,
-                                      0, vp(ws), ws.numel(), vp(y2)) == 0:
+                                      0, None, 0, vp(ws), ws.numel(), vp(y2)) == 0:
         assert torch.equal(y2[:Ms], y[:Ms])
 
 
@@ -572,7 +572,7 @@ def test_ln_linear_geglu(M, K, F_):
     ws = torch.empty(L.gyre_op_ln_linear_workspace(2 * F_, K, M), dtype=torch.uint8, device=DEV)
     y = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w, geglu=True)), F_,
-                                   vp(repack_bias(bias_t, geglu=True)), 1, 0, None, 0, vp(ws), ws.numel(), vp(y)))
+                                   vp(repack_bias(bias_t, geglu=True)), 1, 0, None, 0, None, 0, vp(ws), ws.numel(), vp(y)))
     report(f"ln_geglu M{M} K{K} F{F_}", y.float().cpu(), ref, TOL)
 
 
@@ -588,7 +588,7 @@ def test_ln_fused_qkv(B, tokens, C):
     qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
     vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
     rc = L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), 3 * C, None, 0,
-                             tokens, vp(vt), tokens, vp(ws), ws.numel(), vp(qk))
+                             tokens, vp(vt), tokens, None, 0, vp(ws), ws.numel(), vp(qk))
     if rc == -6:
         pytest.skip("planner picks a tile config without the folded form for this shape")
     _lib.check(rc)
@@ -607,12 +607,51 @@ def test_ln_linear_large_mean_and_small_shapes():
     ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), N, None, 0, 0,
-                                   None, 0, vp(ws), ws.numel(), vp(y)))
+                                   None, 0, None, 0, vp(ws), ws.numel(), vp(y)))
     report("ln_linear mean = 8 sigma", y.float().cpu(), ref, 2 * TOL)
     xs = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV); wsm = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
     gs = torch.ones(64, device=DEV); ys = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
-    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, vp(ws), ws.numel(), vp(ys)) == -6
-    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, vp(ws), 16, vp(ys)) == -4
+    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, None, 0, vp(ws), ws.numel(), vp(ys)) == -6
+    assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, None, 0, vp(ws), 16, vp(ys)) == -4
+
+
+@pytest.mark.parametrize("M,C,res", [(65536, 320, True), (16384, 640, True), (4096, 1280, True), (40000 + 24, 320, False),
+                                     (16384, 1280, True)])
+def test_linear_row_statistics_feed_the_folded_layernorm(M, C, res):
+    """A C x C projection (+ residual) leaves per row the partial sums of its rounded outputs (one per N tile); the next GEMM's
+    folded LayerNorm finishes mean / rstd from them - no statistics pass.  Checks the partial sums against the stored tensor,
+    and the chained result against the fp32 reference and against the same chain with the statistics pass (same bits unless
+    E[x^2] - mean^2 and the two-pass variance round differently: compared by tolerance)."""
+    L = _lib.lib()
+    parts = L.gyre_op_linear_rowstats_parts(M, C, C, 1 if res else 0)
+    if parts <= 0:
+        pytest.skip("planner picks a tile config without the row-statistics epilogue for this shape")
+    x = bf16_round(randn(M, C, seed=110))
+    w1 = bf16_round(randn(C, C, seed=111) / math.sqrt(C))
+    b1 = randn(C, seed=112) * 0.3 + 0.2
+    r = bf16_round(randn(M, C, seed=113) + 0.5) if res else None
+    y1 = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.full((parts, M, 2), float("nan"), device=DEV)
+    _lib.check(L.gyre_op_linear_rowstats(st(), vp(to_dev_bf16(x)), M, C, vp(repack_linear(w1)), C, vp(b1.to(DEV)),
+                                         vp(to_dev_bf16(r)) if res else None, vp(y1), vp(stats)))
+    ref1 = F.linear(x, w1, b1) + (r if res else 0)
+    report(f"linear+rowstats M{M} C{C}", y1.float().cpu(), ref1, TOL)
+    y1f = y1.float()
+    tot = stats.sum(0)
+    assert torch.allclose(tot[:, 0], y1f.sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(tot[:, 1], (y1f * y1f).sum(1), rtol=1e-4, atol=2e-3)
+    # consumer: LayerNorm(y1) @ w2^T with gamma / beta, statistics from the partial sums
+    g, b = randn(C, seed=114) * 0.2 + 1, randn(C, seed=115) * 0.2
+    w2 = bf16_round(randn(C, C, seed=116) / math.sqrt(C))
+    ref2 = F.linear(F.layer_norm(y1f.cpu(), (C,), g, b, 1e-5), w2)
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(C, C, M), dtype=torch.uint8, device=DEV)
+    out_p = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    out_s = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    args = (st(), vp(y1), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w2)), C, None, 0, 0, None, 0)
+    _lib.check(L.gyre_op_ln_linear(*args, vp(stats), parts, vp(ws), ws.numel(), vp(out_p)))
+    _lib.check(L.gyre_op_ln_linear(*args, None, 0, vp(ws), ws.numel(), vp(out_s)))
+    report(f"ln_linear from producer statistics M{M} C{C}", out_p.float().cpu(), ref2, TOL)
+    assert rel_l2(out_p.float().cpu(), out_s.float().cpu()) < 2e-3
 
 
 # ---- pipelined 32x32x16 tile configs (kernels_gemm4s.hip): 4 waves 20 = 192x320, 21 = 256x256, 22 = 128x320, 23 = 128x256;
