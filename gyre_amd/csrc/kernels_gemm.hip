@@ -144,19 +144,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
         }
         const int m = m_base + i * 16 + fr;
         const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-        // folded LayerNorm: the column constants are re-read from LDS for every slab.  The opaque zero keeps the compiler from
-        // merging the reads of all slabs into one set held in registers next to the live accumulators (measured: it spilled
-        // every accumulator of the 256-row tiles to scratch).
-        int lz = 0;
-        if (LNF) asm volatile("" : "+v"(lz));
         if (gg) {
 #pragma unroll
             for (int j = 0; j + 1 < NI; j += 2) {
                 const int nin = n_base + j * 16 + 4 * fq;
                 float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0), cv = bv, cg = bv;
                 if (LNF) {      // column constants of this wave's tile staged in LDS by the kernel (zeros past N)
-                    bv = *(const float4*)(lbb + lz + j * 16 + 4 * fq); bg = *(const float4*)(lbb + lz + j * 16 + 16 + 4 * fq);
-                    cv = *(const float4*)(lcs + lz + j * 16 + 4 * fq); cg = *(const float4*)(lcs + lz + j * 16 + 16 + 4 * fq);
+                    bv = *(const float4*)(lbb + j * 16 + 4 * fq); bg = *(const float4*)(lbb + j * 16 + 16 + 4 * fq);
+                    cv = *(const float4*)(lcs + j * 16 + 4 * fq); cg = *(const float4*)(lcs + j * 16 + 16 + 4 * fq);
                 } else if (p.bias && nin < p.N) { bv = *(const float4*)(p.bias + nin); bg = *(const float4*)(p.bias + nin + 16); }
                 const float4 val = ep_affine<LNF>(acc[i][j], bv, cv, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
                 const float4 gate = ep_affine<LNF>(acc[i][j + 1], bg, cg, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
@@ -174,8 +169,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 if (n < p.N) {
                     if (LNF) {
-                        o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + lz + j * 16 + 4 * fq),
-                                            *(const float4*)(lcs + lz + j * 16 + 4 * fq), lrstd[i], lrmu[i]);
+                        o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + j * 16 + 4 * fq),
+                                            *(const float4*)(lcs + j * 16 + 4 * fq), lrstd[i], lrmu[i]);
                     } else if (p.bias) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
                     if (rbias) { float4 tv = *(const float4*)(rbias + n); o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w; }
                 }
@@ -235,14 +230,12 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
     const int cv_total = p.N - p.vt_col0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        int lz = 0;
-        if (LNF) asm volatile("" : "+v"(lz));     // see gemm_epilogue_staged
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n_base + j * 16 + 4 * fq;
             float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             if (LNF) {
-                o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + lz + j * 16 + 4 * fq), *(const float4*)(lcs + lz + j * 16 + 4 * fq),
+                o = ep_affine<true>(acc[i][j], *(const float4*)(lbb + j * 16 + 4 * fq), *(const float4*)(lcs + j * 16 + 4 * fq),
                                     lrstd[i], lrmu[i]);
             } else if (p.bias && n < p.N) { float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
             *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
