@@ -995,6 +995,9 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     // batch-invariant planning: whether a shape gets an 8-wave tile depends on M = batch x rows, and the folded and the
     // separate LayerNorm round differently - so that mode keeps the separate pass for every batch size
     if (g_invariant_batch > 0) return false;
+    // tuning bit 16: GEGLU FF1 keeps its separate LayerNorm (its GELU epilogue is VALU-bound and the fold adds ~15 % to it:
+    // forward 19.14 ms folded, 19.26 not, 19.52 with no fold at all - same box)
+    if (p.geglu && (p.debug & 0x10000)) return false;
     if (p.mode != GEMM_LINEAR || p.A2 || p.rowbias || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 4) return false;
     if (!gemm_staged_epilogue_ok(p)) return false;
     int splits = 1;
