@@ -198,3 +198,32 @@ def test_folded_layernorm_full_size_matches_the_separate_pass_and_follows_weight
     assert float((plain2 - plain).norm() / plain.norm()) > 1e-3          # the update changes the output ...
     err2 = float((fused2 - plain2).norm() / plain2.norm())
     assert err2 < 2.5e-2, err2                                             # ... and the folded copies followed it
+
+
+def test_folded_layernorm_chain_through_a_depth_two_transformer():
+    """Transformer depth 2 (SDXL-style levels, linear projections): the second block's norm1 takes its row statistics from the
+    FIRST block's FF2 epilogue, not from proj_in.  Two levels (320, 640 channels, depth 1 / 2), 64x64 latents, batch 16 - large
+    enough that the planner gives the projections 8-wave tiles - against the same network with separate LayerNorm passes."""
+    L = _lib.lib()
+    cfg = gcfg.UNetConfig(block_out_channels=(320, 640), attn_levels=(True, True), num_heads=(5, 10), transformer_depth=(1, 2),
+                          cross_attention_dim=768, use_linear_projection=True)
+    net = fill(GyreHipUNet(cfg).to(torch.bfloat16).to(DEV), 3)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
+    ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
+    t = torch.full((16,), 300, device=DEV)
+    net(x, t, encoder_hidden_states=ctx)             # first call: weight upload, context projections, weight folding
+    fused = net(x, t, encoder_hidden_states=ctx).sample.float()
+    n_fused = L.gyre_last_launch_count()
+    old = L.gyre_debug_gemm_ablation(0x800)
+    try:
+        plain = net(x, t, encoder_hidden_states=ctx).sample.float()
+        n_plain = L.gyre_last_launch_count()
+    finally:
+        L.gyre_debug_gemm_ablation(old)
+    err = float((fused - plain).norm() / plain.norm())
+    print(f"depth-2 transformer, folded vs separate LayerNorm: rel-L2 {err:.2e}; launches {n_fused} vs {n_plain}")
+    assert torch.isfinite(fused).all() and err < 2.5e-2
+    # every LayerNorm of the 10 transformer blocks (2 + 3 at level 0 with depth 1 -> 5, 2 x 2 + ... ) lost its launch: the folded
+    # form runs strictly fewer kernels, and at least one per block comes from a producer's epilogue
+    assert n_fused <= n_plain - 10, (n_fused, n_plain)
