@@ -227,8 +227,12 @@ typedef __attribute__((address_space(1))) const void gbl_void_a;
 // up to the row offset - and that offset (the reference maximum of the row) is subtracted by the MFMA itself through its
 // C input.  p = exp2(S') then costs one v_exp per score and nothing else; rows are re-centred in a wave-uniform branch
 // on the first tile and whenever a score exceeds the reference maximum by 2^TAU (practically never afterwards).
-template <int D, int QI, int PD, bool FOLD>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, const bf16_t* zero) {
+// QLOOP (short key sequences - the 77-token text context: every key tile fits its own ring slot): a workgroup stages K / V^T of
+// its (batch, head) ONCE and then walks `qiter` consecutive query blocks with no barrier and no further DMA, the next block's
+// Q fragments being fetched while the current one is computed.  The one-block form spends most of its time in the serial
+// chain Q load -> tile DMA -> barrier -> 2 tiles -> store (47 us for the 64x64 cross-attention, 84 MB: 1.8 TB/s).
+template <int D, int QI, int PD, bool FOLD, bool QLOOP = false>
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, const bf16_t* zero, int qiter) {
     constexpr int NS = PD + 2;               // ring depth: PD tiles in flight + the one being computed + one spare,
                                              // so a refill never targets a stage a slower wave may still be reading
     constexpr int DP = (D + 31) / 32 * 32;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int q0 = blockIdx.x * (64 * QI) + wave * (16 * QI);
+    int q0 = (QLOOP ? blockIdx.x * qiter : blockIdx.x) * (64 * QI) + wave * (16 * QI);
     const bf16_t* qb = p.q + (size_t)b * p.Nq * p.ldq + h * D;
     const bf16_t* kb = p.k + (size_t)b * p.Nk * p.ldk + h * D;
     const bf16_t* vb = p.vt + ((size_t)b * p.H * D + (size_t)h * D) * p.ldvt;
@@ -294,25 +298,31 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
 
     // ---- Q fragments ---------------------------------------------------------------------------------------
     bf16x8_t qf[QI][KS];
+    auto load_q = [&](int qq0, bf16x8_t (&dst)[QI][KS]) {
 #pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        const int q = q0 + qi * 16 + fr;
+        for (int qi = 0; qi < QI; ++qi) {
+            const int q = qq0 + qi * 16 + fr;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d = ks * 32 + fq * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q < p.Nq && d < D) v = *(const uint4*)(qb + (size_t)q * p.ldq + d);
-            qf[qi][ks] = __builtin_bit_cast(bf16x8_t, v);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d = ks * 32 + fq * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (q < p.Nq && d < D) v = *(const uint4*)(qb + (size_t)q * p.ldq + d);
+                dst[qi][ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
         }
-    }
+    };
+    load_q(q0, qf);
     f32x4_t o[QI][DO];
     float m_run[QI], l_run[QI];
+    auto reset = [&]() {
 #pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        m_run[qi] = FOLD ? 0.f : -1e30f; l_run[qi] = 0.f;
+        for (int qi = 0; qi < QI; ++qi) {
+            m_run[qi] = FOLD ? 0.f : -1e30f; l_run[qi] = 0.f;
 #pragma unroll
-        for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
+            for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    reset();
     const float sc = p.k_prescaled ? 1.0f : rsqrtf((float)D) * 1.4426950408889634f;
     // FOLD: a row is re-centred only when a score exceeds its reference maximum by 2^TAU.  p <= 2^60, row sums
     // <= 2^60 * Nk and the fp32 PV accumulators stay far inside the fp32 range; every row keeps a term >= 1 from
@@ -467,6 +477,57 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
         }
     };
     const int nt = (p.Nk + 63) / 64;
+    auto finish = [&](int qq0) {
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            float l;
+            if (ONES) {   // O^T row D (block D/16, local row D%16 -> lanes fq = (D%16)/4, register (D%16)%4) for query fr
+                l = __shfl(o[qi][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr);
+            } else {
+                l = l_run[qi];
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+            }
+            const float inv = 1.0f / l;
+            const int q = qq0 + qi * 16 + fr;
+            if (q >= p.Nq) continue;
+            bf16_t* orow = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#pragma unroll
+            for (int di = 0; di < DO; ++di) {
+                const int d = di * 16 + 4 * fq;
+                if (d < D) {
+                    uint2 pk = make_uint2(pack_bf16x2(o[qi][di][0] * inv, o[qi][di][1] * inv),
+                                          pack_bf16x2(o[qi][di][2] * inv, o[qi][di][3] * inv));
+                    *(uint2*)(orow + d) = pk;
+                }
+            }
+        }
+    };
+    if constexpr (QLOOP) {
+        // nt <= NS (launcher): tile t lives in slot t for the whole kernel
+        for (int t0 = 0; t0 < nt; ++t0) issue(t0 * 64, t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < qiter; ++it) {
+            if (q0 >= p.Nq) break;                               // per wave: nothing below synchronises
+            bf16x8_t qn[QI][KS];
+            const bool more = it + 1 < qiter;
+            if (more) load_q(q0 + 64 * QI, qn);                  // in flight under this block's tiles
+            for (int t = 0; t < nt; ++t) {
+                const int kv0 = t * 64;
+                if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}); else tile(t, kv0, std::false_type{});
+            }
+            finish(q0);
+            if (!more) break;
+#pragma unroll
+            for (int qi = 0; qi < QI; ++qi)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[qi][ks] = qn[qi][ks];
+            reset();
+            q0 += 64 * QI;
+        }
+        return;
+    }
 #pragma unroll
     for (int t0 = 0; t0 < PD; ++t0)
         if (t0 < nt) issue(t0 * 64, t0);
@@ -482,31 +543,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
         __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS (the only barrier per tile)
         if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}); else tile(t, kv0, std::false_type{});
     }
-
-#pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        float l;
-        if (ONES) {   // O^T row D (block D/16, local row D%16 -> lanes fq = (D%16)/4, register (D%16)%4) for query fr
-            l = __shfl(o[qi][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr);
-        } else {
-            l = l_run[qi];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-        }
-        const float inv = 1.0f / l;
-        const int q = q0 + qi * 16 + fr;
-        if (q >= p.Nq) continue;
-        bf16_t* orow = p.o + ((size_t)b * p.Nq + q) * p.ldo + h * D;
-#pragma unroll
-        for (int di = 0; di < DO; ++di) {
-            const int d = di * 16 + 4 * fq;
-            if (d < D) {
-                uint2 pk = make_uint2(pack_bf16x2(o[qi][di][0] * inv, o[qi][di][1] * inv),
-                                      pack_bf16x2(o[qi][di][2] * inv, o[qi][di][3] * inv));
-                *(uint2*)(orow + d) = pk;
-            }
-        }
-    }
+    finish(q0);
 }
 
 
@@ -831,7 +868,8 @@ static const bf16_t* attn_zero_page() {
     return (const bf16_t*)p;
 }
 
-static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1, 2 = v2 plain, 3 = v2 folded, 4 = v2 QI=4 (D <= 32), 5 = v3
+static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1, 2 = v2 plain, 3 = v2 folded, 4 = v2 QI=4 (D <= 32), 5 = v3,
+                                             // 6 = auto without the several-query-blocks-per-workgroup form of short key sequences
 extern "C" int gyre_debug_force_attn_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
 template <int D, int QI, bool FOLD = false>
@@ -843,14 +881,30 @@ static int launch_attn2_t(hipStream_t st, const AttnParams& p) {
     const size_t lds = (size_t)(PD + 2) * STAGE;
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
+    const int nblk = (p.Nq + 64 * QI - 1) / (64 * QI);
+    GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
+                        2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
+    // short key sequence with many query blocks (cross-attention against the text context): K / V^T staged once per
+    // workgroup, several query blocks per workgroup - as many as still leave ~2 workgroups per CU
+    if constexpr (D == 40 || D == 64 || D == 80 || D == 160) {
+        int qiter = (int)((long)nblk * p.B * p.H / 512);
+        if (qiter > 8) qiter = 8;
+        if (qiter > nblk) qiter = nblk;
+        if ((p.Nk + 63) / 64 <= PD + 2 && qiter >= 2 && g_attn_variant == 0) {
+            auto kern = k_attn2<D, QI, PD, FOLD, true>;
+            static std::atomic<unsigned long long> attr_done{0};
+            if (gyre_lds_attr_needed(attr_done))
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((nblk + qiter - 1) / qiter, p.B * p.H), dim3(256), lds, st, p, zero, qiter);
+            GYRE_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     auto kern = k_attn2<D, QI, PD, FOLD>;
     static std::atomic<unsigned long long> attr_done{0};
     if (gyre_lds_attr_needed(attr_done))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((p.Nq + 64 * QI - 1) / (64 * QI), p.B * p.H);
-    GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
-                        2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
+    hipLaunchKernelGGL(kern, dim3(nblk, p.B * p.H), dim3(256), lds, st, p, zero, 1);
     GYRE_LAUNCH_CHECK();
     return 0;
 }
@@ -898,7 +952,7 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) GYRE_FAIL(-1, "attention: strides must be multiples of 8");
     if (p.ldvt < (p.Nk + 7) / 8 * 8) GYRE_FAIL(-1, "attention: ldvt must cover Nk rounded up to 8");
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
-    const int var = g_attn_variant;
+    const int var = g_attn_variant == 6 ? 0 : g_attn_variant;
     // software-pipelined folded kernel; with only a couple of key tiles (cross-attention, Nk = 77) its longer prologue
     // costs more than the overlap wins (measured 47.8 vs 41.1 us), so short key sequences stay on the v2 form
     // (48 query rows per wave, QI = 3, was tried for D = 40: 232 B/lane of spills at 2 waves/SIMD - not built)
