@@ -329,8 +329,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
     // the tile that set its reference, so nothing underflows either.
     constexpr float TAU = 60.f;
 
-    auto tile = [&](int t, int kv0, auto tail_tag) {
+    // half_tag: a tail tile whose keys 32..63 all lie past Nk (the second tile of a 77-key context holds 13 keys): the two key
+    // fragments and the PV step of that half are skipped instead of masked
+    auto tile = [&](int t, int kv0, auto tail_tag, auto half_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
+        constexpr bool HALF = decltype(half_tag)::value;
+        constexpr int NKI = HALF ? 2 : 4;
         const char* k_lds = smem + (t % NS) * STAGE;
         const char* v_lds = k_lds + KBYTES;
 
@@ -339,10 +343,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
         for (int qi = 0; qi < QI; ++qi) {
             const float c0 = FOLD ? -m_run[qi] : 0.f;     // FOLD: S' = S - m_ref straight out of the matrix core
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
+            for (int ki = 0; ki < NKI; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
         }
 #pragma unroll
-        for (int ki = 0; ki < 4; ++ki) {
+        for (int ki = 0; ki < NKI; ++ki) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8_t kf = __builtin_bit_cast(
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             for (int qi = 0; qi < QI; ++qi) {
                 float mx = -1e30f;
 #pragma unroll
-                for (int ki = 0; ki < 4; ++ki)
+                for (int ki = 0; ki < NKI; ++ki)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (TAIL) {
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
                     m_run[qi] += delta;
                     l_run[qi] *= alpha;
 #pragma unroll
-                    for (int ki = 0; ki < 4; ++ki)
+                    for (int ki = 0; ki < NKI; ++ki)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s[qi][ki][r] -= delta;
 #pragma unroll
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             for (int qi = 0; qi < QI; ++qi) {
                 float ls = 0.f;
 #pragma unroll
-                for (int ki = 0; ki < 4; ++ki)
+                for (int ki = 0; ki < NKI; ++ki)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float pv = __builtin_amdgcn_exp2f(s[qi][ki][r]);
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
         for (int qi = 0; qi < (FOLD ? 0 : QI); ++qi) {
             float mx = -1e30f;
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki)
+            for (int ki = 0; ki < NKI; ++ki)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (TAIL) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             m_run[qi] = m_new;
             float ls = 0.f;
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki)
+            for (int ki = 0; ki < NKI; ++ki)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float pv = __builtin_amdgcn_exp2f(fmaf(s[qi][ki][r], sc, nm));
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             }
         }
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
+        for (int ks2 = 0; ks2 < NKI / 2; ++ks2) {
             bf16x8_t pf[QI];
 #pragma unroll
             for (int qi = 0; qi < QI; ++qi) {
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
             if (more) load_q(q0 + 64 * QI, qn);                  // in flight under this block's tiles
             for (int t = 0; t < nt; ++t) {
                 const int kv0 = t * 64;
-                if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}); else tile(t, kv0, std::false_type{});
+                if (kv0 + 32 >= p.Nk) tile(t, kv0, std::true_type{}, std::true_type{});
+                else if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}, std::false_type{});
+                else tile(t, kv0, std::false_type{}, std::false_type{});
             }
             finish(q0);
             if (!more) break;
@@ -541,7 +547,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS (the only barrier per tile)
-        if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}); else tile(t, kv0, std::false_type{});
+        if (kv0 + 32 >= p.Nk) tile(t, kv0, std::true_type{}, std::true_type{});
+                else if (kv0 + 64 > p.Nk) tile(t, kv0, std::true_type{}, std::false_type{});
+                else tile(t, kv0, std::false_type{}, std::false_type{});
     }
     finish(q0);
 }
