@@ -907,9 +907,15 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         const int nk_ = (p.K + BK - 1) / BK;
         if (!(p.debug & 0x400) && p.N % 320 == 0 && (p.mode == GEMM_CONV3 ? nk_ >= 20 : nk_ >= 32) && gemm4s_supports(p, 24))
             big(24, 1.00, 256, 320);
-        // (GEGLU FF1 on the pipelined tile: wins a cache-evicting isolated comparison - COLD=1 tools/geglu_compare.py: 64x64
-        //  202 -> 190 us, 32x32 141 -> 131, 16x16 140 -> 109 - and LOSES in the UNet, forward 19.56 -> 19.83 ms same-box A/B:
-        //  not taken, like the other short-K shapes)
+        // GEGLU FF1 (N = 8C, K = C): the 320-wide 8-wave tile of the 16x16x32 kernel has an odd fragment count per wave and
+        // cannot pair value / gate columns, the pipelined kernel's 32-wide fragments can.  Taken only where the WEIGHTS are
+        // the big operand (N > M: the 16x16 level, 26 MB of weights against 10 MB of activations; 140 -> 109 us cold, UNet
+        // forward 19.45 -> 19.23 ms same-box): there every operand is cold inside the UNet, as in the cache-evicting
+        // comparison (COLD=1 tools/geglu_compare.py).  At 64x64 / 32x32 the activations dominate and are still in the
+        // Infinity Cache behind their producer - the warm regime, where the 256x256 tile wins: with the pipelined tile on all
+        // three levels the forward went 19.56 -> 19.83 ms (debug bit 14 = this rule off).
+        else if (!(p.debug & 0x4400) && p.geglu && (long)p.N > (long)p.M && p.N % 320 == 0 && gemm4s_supports(p, 24))
+            big(24, 1.00, 256, 320);
         // few output tiles but a long reduction (the 8x8 / 16x16 UNet levels: K = 9*Cin up to 23040): cut K into
         // slices so that tiles x slices covers the chip; fp32 slabs are reduced by k_splitk_reduce
         const int nk = (p.K + BK - 1) / BK;
@@ -1002,6 +1008,7 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     if (!gemm_staged_epilogue_ok(p)) return false;
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
+    if (cfg == 24) return splits == 1 && gemm4s_supports(p, 24);      // pipelined 256x320 tile (kernels_gemm4s.hip)
     if (cfg < 4 || cfg > 7 || splits > 1) return false;
     if (p.geglu && (cfg == 4 || cfg == 5)) return false;
     if (p.vt_out) {
@@ -1087,7 +1094,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     }
     if (p.rowstat_out && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");
-    if (p.ln_colsum && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
+    if (p.ln_colsum && ((cfg != 24 && (cfg < 4 || cfg > 7)) || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: the folded LayerNorm needs an unsplit 8-wave tile config with the staged epilogue (see gemm_ln_fusable)");
     if (cfg >= 4) {
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");

@@ -66,7 +66,10 @@ __device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) {
 
 // ZFILL: how the conv's zero padding reaches LDS: 0 = out-of-range raw-buffer requests, 1 = 64-bit pointers to a zero page
 // WM x WN waves: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, the 256x320 tile: 160 accumulators per wave).
-template <int BM, int BN, int WM, int WN, int MODE, int ZFILL>
+// LNF: LayerNorm folded into the GEMM (GemmParams::ln_colsum with ln_stats or ln_parts): the epilogue applies
+// rstd * acc - rstd * mean * colsum + bias per element (linear mode, unsplit; instantiated for the 8-wave 256x320 tile only -
+// the weight-dominated GEGLU FF1 of the 16x16 level)
+template <int BM, int BN, int WM, int WN, int MODE, int ZFILL, bool LNF = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams p, int tiles_m, int tiles_n, int splits, int group_m) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
 
     const int hi = lane >> 5, l31 = lane & 31;
     const int m_base = m0 + wm * TM, n_base = n0 + wn * TN;
-    if (splits > 1) {
+    if (!LNF && splits > 1) {
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
         }
         return;
     }
-    if (p.debug & 4) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+    if (!LNF && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -341,6 +344,31 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
     for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 32 + l31;
         const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        // folded LayerNorm: this lane's accumulators of slab i all belong to row m
+        float lrstd = 1.f, lrmu = 0.f;
+        if constexpr (LNF) {
+            if (m < p.M) {
+                if (p.ln_nparts > 0) {            // partial sums left by the GEMM that produced the rows
+                    float su = 0.f, sq = 0.f;
+                    for (int t = 0; t < p.ln_nparts; ++t) {
+                        const float2 v = ((const float2*)p.ln_parts)[(size_t)t * p.M + m];
+                        su += v.x; sq += v.y;
+                    }
+                    const float invk = 1.0f / (float)p.K;
+                    const float mean = su * invk;
+                    lrstd = 1.0f / sqrtf(fmaxf(sq * invk - mean * mean, 0.f) + p.ln_eps);
+                    lrmu = lrstd * mean;
+                } else {
+                    const float2 rs = ((const float2*)p.ln_stats)[m];
+                    lrstd = rs.x; lrmu = rs.y;
+                }
+            }
+        }
+        auto affine = [&](float a0, float a1, float a2, float a3, const float4& b, const float4& c) {
+            if (LNF) return make_float4(fmaf(a0, lrstd, fmaf(-lrmu, c.x, b.x)), fmaf(a1, lrstd, fmaf(-lrmu, c.y, b.y)),
+                                        fmaf(a2, lrstd, fmaf(-lrmu, c.z, b.z)), fmaf(a3, lrstd, fmaf(-lrmu, c.w, b.w)));
+            return make_float4(a0 + b.x, a1 + b.y, a2 + b.z, a3 + b.w);
+        };
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             constexpr int dummy = 0; (void)dummy;
@@ -351,13 +379,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         const int nin = n_base + j * 32 + 8 * g + 4 * hi;     // value rows; their gates are 16 rows further
-                        float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0);
+                        float4 bv = make_float4(0, 0, 0, 0), bg = make_float4(0, 0, 0, 0), cv = bv, cg = bv;
                         if (p.bias && nin < p.N) { bv = *(const float4*)(p.bias + nin); bg = *(const float4*)(p.bias + nin + 16); }
+                        if (LNF && nin < p.N) { cv = *(const float4*)(p.ln_colsum + nin); cg = *(const float4*)(p.ln_colsum + nin + 16); }
+                        const float4 val = affine(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3], bv, cv);
+                        const float4 gate = affine(acc[i][j][4 * g + 8], acc[i][j][4 * g + 9], acc[i][j][4 * g + 10], acc[i][j][4 * g + 11], bg, cg);
                         float4 o;
-                        o.x = (acc[i][j][4 * g + 0] + bv.x) * gelu_erf_f(acc[i][j][4 * g + 8] + bg.x);
-                        o.y = (acc[i][j][4 * g + 1] + bv.y) * gelu_erf_f(acc[i][j][4 * g + 9] + bg.y);
-                        o.z = (acc[i][j][4 * g + 2] + bv.z) * gelu_erf_f(acc[i][j][4 * g + 10] + bg.z);
-                        o.w = (acc[i][j][4 * g + 3] + bv.w) * gelu_erf_f(acc[i][j][4 * g + 11] + bg.w);
+                        o.x = val.x * gelu_erf_f(gate.x);
+                        o.y = val.y * gelu_erf_f(gate.y);
+                        o.z = val.z * gelu_erf_f(gate.z);
+                        o.w = val.w * gelu_erf_f(gate.w);
                         *(float4*)(slab + l31 * ROWF + (j - j0) * 16 + 8 * g + 4 * hi) = o;
                     }
             } else {
@@ -368,7 +399,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
                         const int n = n_base + j * 32 + 8 * g + 4 * hi;
                         float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                         if (n < p.N) {
-                            if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                            if (LNF) o = affine(o.x, o.y, o.z, o.w, *(const float4*)(p.bias + n), *(const float4*)(p.ln_colsum + n));
+                            else if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
                             if (rbias) { const float4 tv = *(const float4*)(rbias + n); o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w; }
                         }
                         *(float4*)(slab + l31 * ROWF + (j - j0) * 32 + 8 * g + 4 * hi) = o;
@@ -450,7 +482,17 @@ static int launch_cfg4s(hipStream_t st, const GemmParams& p, int kcls_base, int 
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, tiles_m, tiles_n, splits, group_m);             \
     } while (0)
-    if (p.mode == GEMM_LINEAR) GYRE_GEMM4S_GO(GEMM_LINEAR, 0);
+    if (p.mode == GEMM_LINEAR && p.ln_colsum) {
+        if constexpr (BM == 256 && BN == 320 && NW == 8) {
+            auto kern = k_gemm4s<BM, BN, WM, WN, GEMM_LINEAR, 0, true>;
+            static std::atomic<unsigned long long> attr_done{0};
+            if (gyre_lds_attr_needed(attr_done))
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, tiles_m, tiles_n, splits, group_m);
+        } else {
+            GYRE_FAIL(-6, "gemm: the folded LayerNorm exists for the 8-wave 256x320 pipelined tile only");
+        }
+    } else if (p.mode == GEMM_LINEAR) GYRE_GEMM4S_GO(GEMM_LINEAR, 0);
     else if (p.debug & 0x200) GYRE_GEMM4S_GO(GEMM_CONV3, 1);
     else GYRE_GEMM4S_GO(GEMM_CONV3, 0);
 #undef GYRE_GEMM4S_GO

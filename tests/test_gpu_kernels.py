@@ -652,6 +652,22 @@ def test_linear_row_statistics_feed_the_folded_layernorm(M, C, res):
     _lib.check(L.gyre_op_ln_linear(*args, None, 0, vp(ws), ws.numel(), vp(out_s)))
     report(f"ln_linear from producer statistics M{M} C{C}", out_p.float().cpu(), ref2, TOL)
     assert rel_l2(out_p.float().cpu(), out_s.float().cpu()) < 2e-3
+    if M == 4096:
+        # weight-dominated GEGLU consumer (N = 8C > M): the planner gives it the pipelined 256x320 kernel, whose epilogue
+        # finishes the statistics from the same partial sums
+        F_ = 4 * C
+        w3 = bf16_round(randn(2 * F_, C, seed=117) / math.sqrt(C))
+        b3 = randn(2 * F_, seed=118) * 0.5
+        val, gate = F.linear(F.layer_norm(y1f.cpu(), (C,), g, b, 1e-5), w3, b3).chunk(2, dim=-1)
+        ws3 = torch.empty(L.gyre_op_ln_linear_workspace(2 * F_, C, M), dtype=torch.uint8, device=DEV)
+        gp = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+        gs = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+        gargs = (st(), vp(y1), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w3, geglu=True)), F_,
+                 vp(repack_bias(b3, geglu=True)), 1, 0, None, 0)
+        _lib.check(L.gyre_op_ln_linear(*gargs, vp(stats), parts, vp(ws3), ws3.numel(), vp(gp)))
+        _lib.check(L.gyre_op_ln_linear(*gargs, None, 0, vp(ws3), ws3.numel(), vp(gs)))
+        report(f"ln_geglu from producer statistics M{M} C{C}", gp.float().cpu(), val * F.gelu(gate), TOL)
+        assert rel_l2(gp.float().cpu(), gs.float().cpu()) < 2e-3
 
 
 # ---- pipelined 32x32x16 tile configs (kernels_gemm4s.hip): 4 waves 20 = 192x320, 21 = 256x256, 22 = 128x320, 23 = 128x256;
