@@ -5,7 +5,7 @@
      gyre_op_linear / gyre_op_conv3x3 with gyre_debug_force_gemm_cfg(cfg | splits << 8) for every valid combination
   3. prints planner time vs best time per problem and the summed headroom over the forward
 
-Usage (GPU box):  python tools/gemm_sweep.py [B] [latent] [sd15|sdxl|vae] [extra cfg ids, comma separated]     default 16 64 sd15
+Usage (GPU box):  [COLD=1|2|3] python tools/gemm_sweep.py [B] [latent] [sd15|sdxl|vae] [extra cfg ids, comma separated]     default 16 64 sd15
 (vae: one decode of B latents; sdxl: the SDXL-base topology)
 """
 import collections
@@ -41,8 +41,11 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(0)
 
-    COLD = os.environ.get("COLD") in ("1", "2")  # 1: evict L2 / Infinity Cache before every timed launch (the in-UNet regime)
+    COLD = os.environ.get("COLD") in ("1", "2", "3")  # 1: evict L2 / Infinity Cache before every timed launch (the in-UNet regime)
     NOFLUSH = os.environ.get("COLD") == "2"      # 2: time launches one by one like 1, but leave the caches alone
+    REWARM = os.environ.get("COLD") == "3"       # 3: like 1, then the activation operand is re-written by a copy kernel: what a layer
+                                                 #    sees right behind its producer (activations in the Infinity Cache, weights cold)
+    rewarm_pair = [None, None]
     if COLD:
         fl_a = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
         fl_b = torch.empty(384 << 20, dtype=torch.uint8, device=dev)
@@ -59,6 +62,8 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
             for _ in range(reps):
                 if not NOFLUSH:
                     fl_a.copy_(fl_b)
+                    if REWARM and rewarm_pair[0] is not None:
+                        rewarm_pair[0].copy_(rewarm_pair[1])
                 else:
                     torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,6 +105,8 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
             call = lambda: L.gyre_op_conv3x3(st, C.c_void_p(x.data_ptr()), Bn, f["Hi"], f["Wi"], f["Cin"], C.c_void_p(w.data_ptr()), N,
                                              None, C.c_void_p(res.data_ptr()) if res is not None else None, f["stride"], f["ups"], 0,
                                              C.c_void_p(y.data_ptr()))
+        if REWARM:
+            rewarm_pair[0], rewarm_pair[1] = x, x.clone()
         # dual-source problems (skip concat) are timed as single-source ones of the same shape; the pipelined kernel (24) cannot
         # take them, so it is left out and "planner" is the recorded choice of the real (dual-source) launch
         L.gyre_debug_force_gemm_cfg((f["cfg"] | (f["splits"] << 8)) if dual else 0)
