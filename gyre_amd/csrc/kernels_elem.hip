@@ -240,14 +240,20 @@ __global__ __launch_bounds__(256) void k_gn_partial(GnParams p, int TX, int PY, 
         }
     }
     __syncthreads();
+    // fold in two fixed-order steps that use the whole block: per channel over the PY pixel rows, then per group over its
+    // channels.  (One thread per group walking PY x C/G entries left 7/8 of the block idle for ~120 dependent LDS reads while
+    // the chip - every workgroup of the launch is resident at once - streamed nothing.)
+    float2* red2 = (float2*)red;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int y = 0; y < PY; ++y) { const float2 t = red2[(size_t)y * p.C + c]; a += t.x; b += t.y; }
+        red2[c] = make_float2(a, b);          // row 0, own column: nobody else reads it before the barrier
+    }
+    __syncthreads();
     const int cpg = p.C / p.G;
     for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
         float a = 0.f, b = 0.f;
-        for (int y = 0; y < PY; ++y)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                a += red[((size_t)y * p.C + c) * 2 + 0];
-                b += red[((size_t)y * p.C + c) * 2 + 1];
-            }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const float2 t = red2[c]; a += t.x; b += t.y; }
         float* dst = p.partial + (((size_t)n * p.nchunks + chunk) * p.G + g) * 2;
         dst[0] = a; dst[1] = b;
     }
