@@ -8,6 +8,7 @@
 // gyre/pipeline/unet/core.py:274 and unified_pipeline.py:309,1531:
 //   torch.nn.GroupNorm + SiLU, torch.nn.LayerNorm, diffusers Timesteps/TimestepEmbedding.
 #include "kernels.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------
 // NCHW (f32/bf16/f16) -> NHWC bf16, channels zero-padded to Cpad (multiple of 8)
@@ -324,6 +325,84 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p, size_t total_vec) 
     *(uint4*)(p.y + gp * p.C + c) = pack8(f);
 }
 
+// Apply with the finalize step folded into its prologue: a workgroup = (pixel chunk, sample) like k_gn_partial; it first redoes
+// k_gn_finalize's arithmetic for its sample (same order -> same bits: nchunks partial sums per group from L2, then a = rstd * gamma,
+// b = beta - mean * a per channel into LDS) and then streams its pixels.  One launch and one dependent round trip per GroupNorm
+// less; the extra reads are 2 KB per thread block against 40 KB of pixels.
+__global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY, int pix_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ab = (float*)smem_raw;                 // [2][C]
+    float* red_s = ab + 2 * p.C;                  // [256]
+    float* red_q = red_s + 256;                   // [256]
+    float* mean_s = red_q + 256;                  // [256]
+    float* rstd_s = mean_s + 256;                 // [256]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int cpg = p.C / p.G;
+    {
+        const float cnt = (float)p.HW * (float)cpg;
+        int parts = 256 / p.G;
+        if (parts < 1) parts = 1;
+        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+        float a = 0.f, b = 0.f;
+        if (part < parts)
+            for (int ch = part; ch < p.nchunks; ch += parts) {
+                const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+                a += src[0]; b += src[1];
+            }
+        red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
+        __syncthreads();
+        if (threadIdx.x < p.G) {
+            float sa = 0.f, sb = 0.f;
+            for (int q = 0; q < parts; ++q) { sa += red_s[q * p.G + g]; sb += red_q[q * p.G + g]; }
+            const float mean = sa / cnt;
+            const float var = fmaxf(sb / cnt - mean * mean, 0.f);
+            mean_s[g] = mean;
+            rstd_s[g] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            const int gg = c / cpg;
+            const float aa = rstd_s[gg] * p.gamma[c];
+            ab[c] = aa;
+            ab[p.C + c] = p.beta[c] - mean_s[gg] * aa;
+        }
+        __syncthreads();
+    }
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int CV = p.C / 8, C2 = p.C - p.C1;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(p.HW, p0 + pix_per_chunk);
+    if (ty >= PY) return;
+    for (int pix = p0 + ty; pix < p1; pix += PY) {
+        const size_t gp = (size_t)n * p.HW + pix;
+#pragma unroll
+        for (int v = 0; v < GN_MAXV; ++v) {
+            const int cv = tx + v * TX;
+            if (cv < CV) {
+                const int c = cv * 8;
+                const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
+                float f[8];
+                unpack8(*(const uint4*)src, f);
+                const float4 a0 = *(const float4*)(ab + c), a1 = *(const float4*)(ab + c + 4);
+                const float4 b0 = *(const float4*)(ab + p.C + c), b1 = *(const float4*)(ab + p.C + c + 4);
+                const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = fmaf(a[j], f[j], b[j]);
+                    f[j] = p.silu ? silu_f(y) : y;
+                }
+                *(uint4*)(p.y + gp * p.C + c) = pack8(f);
+            }
+        }
+    }
+}
+// the fused form needs nothing k_gn_finalize would have to publish (the backward pass asks for mean / rstd)
+static bool gn_finalize_in_apply(const GnParams& p) {
+    static const bool separate = getenv("GYRE_GN_SEPARATE_FINALIZE") != nullptr;      // tuning / bit-equality checks
+    return !separate && !p.mean_rstd && p.G <= 256;
+}
+
 int gn_pick_chunks(int B, int HW, int C) {
     // The chunking fixes the order the per-sample statistics are summed in, so it must not depend on B (batch
     // independence): 64 chunks per sample for 1024 <= HW <= 16384 (what the batch-16 tuning used), 16-pixel chunks
@@ -353,6 +432,7 @@ int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
     GyreProfScope prof_(KC_GN_STATS, st, 0.0, (double)p.B * p.HW * p.C * 2.0);
     hipLaunchKernelGGL(k_gn_partial, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
     GYRE_LAUNCH_CHECK();
+    if (gn_finalize_in_apply(p)) return 0;           // launch_groupnorm_apply finishes the statistics itself
     hipLaunchKernelGGL(k_gn_finalize, dim3(p.B), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
     return 0;
@@ -360,6 +440,17 @@ int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
     size_t total = (size_t)p.B * p.HW * (p.C / 8);
     GyreProfScope prof_(KC_GN_APPLY, st, 0.0, (double)p.B * p.HW * p.C * 4.0);
+    if (gn_finalize_in_apply(p)) {
+        const int CV = p.C / 8;
+        const int TX = CV < 256 ? CV : 256;
+        if ((CV + TX - 1) / TX > GN_MAXV) GYRE_FAIL(-6, "groupnorm: C too large");
+        int PY = 256 / TX; if (PY < 1) PY = 1;
+        const int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
+        const size_t lds = ((size_t)2 * p.C + 4 * 256) * sizeof(float);
+        hipLaunchKernelGGL(k_gn_apply_fin, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+        GYRE_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_gn_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, total);
     GYRE_LAUNCH_CHECK();
     return 0;
