@@ -52,6 +52,8 @@ _SIGS = {
     "gyre_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "gyre_unet_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_unet_set_context": (_i, [_vp, _vp, _vp, _i, _i, _i]),
+    "gyre_unet_set_context_slot": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "gyre_unet_select_context": (_i, [_vp, _i]),
     "gyre_unet_set_tome": (_i, [_vp, _i]),
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
@@ -61,6 +63,7 @@ _SIGS = {
     "gyre_unet_vjp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i, _vp]),
     "gyre_unet_vjp_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_unet_vjp_finish": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
+    "gyre_unet_vjp_pending": (_i, [_vp]),
     "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
     "gyre_vae_destroy": (None, [_vp]),
     "gyre_vae_num_params": (_i, [_vp]),

@@ -231,7 +231,13 @@ class ClipGuidedMode:
             else:
                 self._guided_stem_only = False
                 res, grads = self.model_k_fn(child, latents, sigma, u)
-            s = sigma if not isinstance(sigma, torch.Tensor) else sigma.reshape(-1)[0].to(res.device, res.dtype)
+            # k_utils.append_dims(sigma, ndim): a per-sample sigma vector broadcasts over its own image (:292-296)
+            if not isinstance(sigma, torch.Tensor):
+                s = sigma
+            elif sigma.numel() == res.shape[0] and sigma.numel() > 1:
+                s = sigma.reshape(-1, *[1] * (res.ndim - 1)).to(res.device, res.dtype)
+            else:
+                s = sigma.reshape(-1)[0].to(res.device, res.dtype)
             return res + grads * (s ** 2)
         return wrapped
 

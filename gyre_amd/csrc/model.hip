@@ -81,7 +81,7 @@ const char* gyre_unet_param_key(const gyre_unet* h, int i) {
 int gyre_unet_set_weight(gyre_unet* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* st) {
     if (!h || !key || !p || !shape) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     h->finalized = false;
-    h->cache_valid = false;
+    h->invalidate_contexts();
     return h->store.set_weight(key, p, dtype, shape, ndim, (hipStream_t)st);
 }
 int gyre_unet_finalize(gyre_unet* h, void* st) {
@@ -94,7 +94,7 @@ size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     if (!h) return 0;
     if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0)) return 0;
     size_t peak = h->ex.arena.peak;
-    if (h->cache_valid && h->cache_B == B && h->cache_S == S) {   // cached-context path allocates a subset; take the max
+    if (h->cur().valid && h->cur().B == B && h->cur().S == S) {   // cached-context path allocates a subset; take the max
         if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0, nullptr, true)) return 0;
         peak = std::max(peak, h->ex.arena.peak);
     }
@@ -172,7 +172,20 @@ int gyre_unet_set_context(gyre_unet* h, void* st, const void* ctx, int cdt, int 
     if (!h || !ctx) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     if (cdt < 0 || cdt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
-    return h->set_context((hipStream_t)st, ctx, cdt, B, S);
+    return h->set_context((hipStream_t)st, ctx, cdt, B, S, 0);
+}
+int gyre_unet_set_context_slot(gyre_unet* h, void* st, const void* ctx, int cdt, int B, int S, int slot) {
+    if (!h || !ctx) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    if (cdt < 0 || cdt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    return h->set_context((hipStream_t)st, ctx, cdt, B, S, slot);
+}
+int gyre_unet_select_context(gyre_unet* h, int slot) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (slot < 0 || slot >= GYRE_CTX_SLOTS) GYRE_FAIL(GYRE_ERR_INVALID, "unet: context slot out of range");
+    if (!h->ctx_slots[slot].valid) GYRE_FAIL(GYRE_ERR_INVALID, "unet: context slot holds no projected context (set_weight invalidates all)");
+    h->cur_slot = slot;
+    return 0;
 }
 int gyre_unet_debug_tap(gyre_unet* h, const char* name, float* out_nchw_f32, size_t out_bytes) {
     if (!h || !name || !out_nchw_f32) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
@@ -231,6 +244,7 @@ int gyre_unet_vjp_begin(gyre_unet* h, void* st, const void* x, int xdt, const in
     g_launches = 0;
     return gyre_unet_vjp_forward(*h, false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, eps_out, odt, temb_add);
 }
+int gyre_unet_vjp_pending(gyre_unet* h) { return h && h->vjp.valid ? 1 : 0; }
 int gyre_unet_vjp_finish(gyre_unet* h, void* st, const void* d_eps, int ddt, void* dx_out, int dxdt) {
     if (!h || !d_eps || !dx_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     for (int d : {ddt, dxdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");

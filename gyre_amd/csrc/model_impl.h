@@ -708,10 +708,15 @@ struct gyre_unet {
     // debug taps (parity tests): name -> (device f32 NCHW buffer, capacity in bytes); consumed by the next forward
     std::map<std::string, std::pair<float*, size_t>> taps;
     // text-context cache (cross-attention K / V^T per layer, and the bf16 copy of the context)
-    std::vector<CtxKV> kv_cache;
-    void* kv_buf = nullptr; size_t kv_bytes = 0;
-    int cache_B = 0, cache_S = 0; bool cache_valid = false;
-    ~gyre_unet() { if (kv_buf) (void)hipFree(kv_buf); }
+    // GYRE_CTX_SLOTS independent entries: a hires-fix / graft tree and CFGUNet_Sequential alternate between contexts on
+    // every step (reference unet/cfg.py:27-38, unet/hires_fix.py:123-235); gyre_unet_select_context switches without
+    // re-projecting.  The fields below alias the CURRENT slot.
+    struct CtxSlot { std::vector<CtxKV> kv; void* buf = nullptr; size_t bytes = 0; int B = 0, S = 0; bool valid = false; };
+    CtxSlot ctx_slots[GYRE_CTX_SLOTS];
+    int cur_slot = 0;
+    CtxSlot& cur() { return ctx_slots[cur_slot]; }
+    void invalidate_contexts() { for (auto& sl : ctx_slots) sl.valid = false; }
+    ~gyre_unet() { for (auto& sl : ctx_slots) if (sl.buf) (void)hipFree(sl.buf); }
 
     template <typename F> void for_each_cross_attn(F f) {
         for (auto& lv : down) for (auto& t : lv.attn) for (auto& b : t.blocks) f(b.a2);
@@ -720,8 +725,13 @@ struct gyre_unet {
     }
     // Project the text context through every cross-attention to_k / to_v once; the denoising loop then calls
     // forward with ctx == NULL (the context is constant over the 50+ UNet evaluations of a request).
-    int set_context(hipStream_t st, const void* ctx, int cdt, int B, int S) {
+    int set_context(hipStream_t st, const void* ctx, int cdt, int B, int S, int slot = 0) {
         if (B < 1 || S < 1) GYRE_FAIL(GYRE_ERR_INVALID, "unet: empty context");
+        if (slot < 0 || slot >= GYRE_CTX_SLOTS) GYRE_FAIL(GYRE_ERR_INVALID, "unet: context slot out of range");
+        cur_slot = slot;
+        CtxSlot& sl = ctx_slots[slot];
+        void*& kv_buf = sl.buf; size_t& kv_bytes = sl.bytes; bool& cache_valid = sl.valid; int &cache_B = sl.B, &cache_S = sl.S;
+        std::vector<CtxKV>& kv_cache = sl.kv;
         const int D = cfg.cross_attention_dim, Spad = (S + 7) / 8 * 8;
         size_t need = align_up((size_t)B * S * D * 2, 256);
         for_each_cross_attn([&](AttnW& a) { need += align_up((size_t)B * S * a.c * 2, 256) + align_up((size_t)B * a.c * Spad * 2, 256); });
@@ -870,9 +880,9 @@ struct gyre_unet {
         Exec& e = ex;
         const int D = c.cross_attention_dim;
         const bool cached = use_ctx_cache;
-        if (cached && (!cache_valid || cache_B != B || cache_S != S))
+        if (cached && (!cur().valid || cur().B != B || cur().S != S))
             GYRE_FAIL(GYRE_ERR_INVALID, "unet: ctx == NULL needs a gyre_unet_set_context call with the same B and S");
-        e.ctx_cache = cached ? &kv_cache : nullptr;
+        e.ctx_cache = cached ? &cur().kv : nullptr;
         e.ctx_layer = 0;
         Tn xin, cx, emb, t1, t2, tp;
         TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));

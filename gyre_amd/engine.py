@@ -26,7 +26,9 @@ into PNG artifacts.  What this class has to honour is therefore exactly what the
   * no-op memory knobs (attention / VAE slicing, xformers): 288 GB of HBM3E, the whole batch stays resident.
 
 Features outside the native hot path raise NotImplementedError (-> gRPC UNIMPLEMENTED, services/exception_to_grpc.py):
-CLIP guidance, depth / hint images (ControlNet, T2I), textual-inversion token embeddings, tiling.
+depth / hint images (ControlNet, T2I), textual-inversion token embeddings, tiling, brownian sampler noise.  CLIP guidance
+is implemented (gyre_amd/clipguided.py over the native input-gradient sweeps).  The safety checker stays the host module the
+manager loaded; it is RUN exactly as the reference runs it (``_safety_check``), never skipped silently.
 """
 from __future__ import annotations
 
@@ -267,7 +269,7 @@ class GyreUnifiedPipeline:
                  clip_guidance_base: Optional[str] = None, clip_gradient_length: Optional[int] = None,
                  clip_gradient_threshold: Optional[float] = None, clip_gradient_maxloss: Optional[float] = None,
                  clip_prompt=None, vae_cutouts: Optional[int] = None, approx_cutouts: Optional[int] = None, no_cutouts=False,
-                 lora=None, token_embeddings=None,
+                 run_safety_checker: bool = True, lora=None, token_embeddings=None,
                  hires_fix=None, hires_oos_fraction=None, tiling=False, debug_latent_tags=None, debug_latent_prefix="",
                  cfg_execution: str = "parallel"):
         if depth_map is not None or hint_images:
@@ -309,8 +311,8 @@ class GyreUnifiedPipeline:
             if u is None:
                 continue
             LR.remove_lora_from_model(u)                    # the reference strips leftovers on every call (:2190-2200)
-            if hasattr(u, "set_tome"):
-                u.set_tome(self._tome)
+            if hasattr(u, "set_tome"):                      # the reference patches ToMe into self.unet only (:1580-1584)
+                u.set_tome(self._tome if u is self.unet else 0)
         if lora:
             for i, spec in enumerate(lora if isinstance(lora, (list, tuple)) else [lora]):
                 tensors, weights = (spec if isinstance(spec, (list, tuple)) else (spec, {}))
@@ -341,13 +343,40 @@ class GyreUnifiedPipeline:
                       churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
                       sigma_max=sigma_max, **clip_kw)
         images = images.float().cpu()                       # reference: result_image.cpu() ... BCHW 0..1 (:2512-2531)
-        nsfw: List[bool] = [False] * images.shape[0]       # tests / engines run with nsfw_behaviour "ignore"
+        images, nsfw = self._safety_check(images, run_safety_checker)
         if output_type == "pil":
-            from PIL import Image
-            images = [Image.fromarray((im.permute(1, 2, 0).numpy() * 255).round().astype("uint8")) for im in images]
+            images = self.numpy_to_pil(images.permute(0, 2, 3, 1).numpy())
         elif output_type not in ("tensor", "pt"):
             raise ValueError(f"output_type {output_type!r}")
         if not return_dict:
             return images, nsfw
         from types import SimpleNamespace
         return SimpleNamespace(images=images, nsfw_content_detected=nsfw)
+
+    @staticmethod
+    def numpy_to_pil(images):
+        """NHWC 0..1 floats -> PIL images (what the reference inherits from DiffusionPipeline.numpy_to_pil)."""
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None]
+        return [Image.fromarray(im) for im in (images * 255).round().astype("uint8")]
+
+    def _safety_check(self, images: torch.Tensor, run_safety_checker: bool):
+        """The host-side NSFW check of the reference (unified_pipeline.py:2512-2523): whenever a checker is loaded it sees
+        the finished images - ``feature_extractor`` on the PIL images, then ``safety_checker(images=<NHWC numpy>,
+        clip_input=<pixel_values in the text-embedding dtype>)`` - and its (possibly blacked-out) images and per-image flags
+        are what the call returns.  The server's default ``nsfw_behaviour`` is "block" (server.py:660) and relies on it."""
+        if not run_safety_checker or self.safety_checker is None:
+            return images, [False] * images.shape[0]
+        if self.feature_extractor is None:
+            raise ValueError("a safety_checker needs the pipeline's feature_extractor")
+        result_numpy = images.permute(0, 2, 3, 1).numpy()
+        dev = self.execution_device
+        te_param = next(iter(self.text_encoder.parameters()), None) if hasattr(self.text_encoder, "parameters") else None
+        dtype = te_param.dtype if te_param is not None else torch.float32
+        clip_input = self.feature_extractor(self.numpy_to_pil(result_numpy), return_tensors="pt").to(dev)
+        result_numpy, nsfw = self.safety_checker(images=result_numpy, clip_input=clip_input.pixel_values.to(dtype))
+        if isinstance(result_numpy, torch.Tensor):
+            result_numpy = result_numpy.float().cpu().numpy()
+        import numpy as np
+        return torch.from_numpy(np.ascontiguousarray(result_numpy)).permute(0, 3, 1, 2), [bool(f) for f in nsfw]

@@ -59,18 +59,30 @@ class _NativeModule(nn.Module):
         self._handle_device: Optional[torch.device] = None
         self._dirty = True
         self._ws: Optional[torch.Tensor] = None
-        self._ctx_src, self._ctx_ver, self._ctx_handle = None, -1, None
-        self.register_load_state_dict_post_hook(lambda m, ik: m._invalidate())
+        self._ctx_slots: list = []        # [(tensor, version, handle, B, native slot)], most recently used last
+        self.register_load_state_dict_post_hook(lambda m, ik: m._weights_replaced())
 
     # -- lifecycle ---------------------------------------------------------------------------
+    def _weights_replaced(self):
+        """load_state_dict ran: the parameters are the new truth.  fp32 LoRA overrides (gyre_amd/lora.py) and the LoRA base
+        cache describe the OLD weights and would shadow the new ones at the next upload - drop them."""
+        ov = getattr(self, "_weight_overrides", None)
+        if ov:
+            ov.clear()
+        st = getattr(self, "_lora_state", None)
+        if st is not None:
+            st["base"].clear()
+            st["loras"].clear()
+        self._invalidate()
+
     def _invalidate(self):
         self._dirty = True
-        self._ctx_src = None
+        self._ctx_slots = []
 
     def _apply(self, fn, *a, **k):  # .to() / .half() / .cuda(): the native copy is stale afterwards
         r = super()._apply(fn, *a, **k)
         self._dirty = True
-        self._ctx_src = None
+        self._ctx_slots = []
         return r
 
     def _destroy(self):
@@ -191,11 +203,12 @@ class GyreHipUNet(_NativeModule):
     """Drop-in for diffusers.UNet2DConditionModel on the reference's hot path."""
 
     _kind = "unet"
+    CTX_SLOTS = 4                         # include/gyre_hip.h GYRE_CTX_SLOTS
 
     def __init__(self, config: Optional[UNetConfig] = None):
         super().__init__()
         self.config = config or sd15_unet()
-        self._ctx_src, self._ctx_ver, self._ctx_handle = None, -1, None
+        self._ctx_slots = []
         _build_tree(self, unet_param_shapes(self.config))
 
     def _shapes(self):
@@ -339,16 +352,35 @@ class GyreHipUNet(_NativeModule):
         with torch.cuda.device(dev):
             # context cache: the denoising loop passes the SAME embeddings tensor on every call (the reference binds
             # it once per request, unet/core.py:242-259); project it through the cross-attention K/V weights once.
-            # Identity + version of a tensor we keep referenced => the storage cannot have been recycled.
+            # Identity + version of a tensor we keep referenced => the storage cannot have been recycled.  CTX_SLOTS
+            # entries, least recently used evicted: the leaves of a hires-fix / graft tree and CFGUNet_Sequential
+            # (unet/cfg.py:27-38, unet/hires_fix.py:123-235) alternate between contexts on every step.
             src = encoder_hidden_states
             try:
                 ver = src._version
             except RuntimeError:          # inference tensors carry no version counter: never trust the cache for them
                 ver = None
-            if ver is None or not (self._ctx_src is src and self._ctx_ver == ver and self._ctx_handle == h):
-                _lib.check(L.gyre_unet_set_context(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)),
-                                                   C.c_void_p(ctx.data_ptr()), _lib.dtype_code(ctx), B, S))
-                self._ctx_src, self._ctx_ver, self._ctx_handle = src, ver, h
+            slots = self._ctx_slots
+            hit = None
+            if ver is not None:
+                for i, (s_src, s_ver, s_h, s_B, _) in enumerate(slots):
+                    if s_src is src and s_ver == ver and s_h == h and s_B == B:
+                        hit = i
+                        break
+            if hit is not None:
+                entry = slots.pop(hit)
+                _lib.check(L.gyre_unet_select_context(C.c_void_p(h), entry[4]))
+                slots.append(entry)
+            else:
+                used = {e[4] for e in slots}
+                free = [k for k in range(self.CTX_SLOTS) if k not in used]
+                slot = free[0] if free else slots.pop(0)[4]
+                _lib.check(L.gyre_unet_set_context_slot(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)),
+                                                        C.c_void_p(ctx.data_ptr()), _lib.dtype_code(ctx), B, S, slot))
+                if ver is not None:
+                    slots.append((src, ver, h, B, slot))
+                else:
+                    self._ctx_slots = [e for e in slots if e[4] != slot]
             need = L.gyre_unet_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
                 _lib.check(-1 if "unet:" in L.gyre_last_error().decode() else -4)
@@ -464,11 +496,9 @@ class _UNetInputGrad(torch.autograd.Function):
     def backward(fctx, d_out):
         sample, t, enc = fctx.saved_tensors
         m = fctx.module
-        if getattr(m, "_vjp_pending", None) is fctx.token:
-            try:
-                return m._vjp_finish(fctx.h, sample, d_out), None, None, None, None, None
-            except ValueError:
-                pass                                   # state dropped by another call on the handle: recompute
+        if getattr(m, "_vjp_pending", None) is fctx.token and _lib.lib().gyre_unet_vjp_pending(C.c_void_p(fctx.h)):
+            return m._vjp_finish(fctx.h, sample, d_out), None, None, None, None, None
+        # state dropped by another call on the handle (gyre_unet_vjp_pending == 0): recompute in one shot
         _, dx = m._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
         return dx, None, None, None, None, None
 

@@ -809,7 +809,10 @@ class DiffusersLikeScheduler:
         lower_second = idx == len(ts) - 2 and small
         lam_s0, alpha_s0, sigma_s0 = self._lambda_alpha_sigma(t)
         x0 = (sample - sigma_s0 * eps) / alpha_s0                       # data prediction from the eps model
-        self.outputs = (self.outputs + [(int(t), x0)])[-max(self.solver_order, 1):]
+        # history = data predictions only; their timesteps are read off the SCHEDULE (timesteps[idx - 1], [idx - 2]) as the
+        # pinned DPMSolverMultistepScheduler.step does - identical for a single UNet, and what keeps two grafted leaves
+        # that step this shared object at the same timestep finite (reference common_scheduler.py:240,261-283)
+        self.outputs = (self.outputs + [x0])[-max(self.solver_order, 1):]
         lam_t, alpha_t, sigma_t = self._lambda_alpha_sigma(prev_t)
         h = lam_t - lam_s0
         em1 = math.expm1(-h)                                            # e^{-h} - 1
@@ -820,17 +823,17 @@ class DiffusersLikeScheduler:
             use = 2
         else:
             use = 3
-        m0 = self.outputs[-1][1]
+        m0 = self.outputs[-1]
         out = (sigma_t / sigma_s0) * sample - (alpha_t * em1) * m0
         if use >= 2:
-            s1, m1 = self.outputs[-2]
+            s1, m1 = ts[idx - 1], self.outputs[-2]
             lam_s1 = self._lambda_alpha_sigma(s1)[0]
             r0 = (lam_s0 - lam_s1) / h
             d1_0 = (m0 - m1) * (1.0 / r0)
             if use == 2:
                 out = out - (0.5 * alpha_t * em1) * d1_0
             else:
-                s2, m2 = self.outputs[-3]
+                s2, m2 = ts[idx - 2], self.outputs[-3]
                 lam_s2 = self._lambda_alpha_sigma(s2)[0]
                 r1 = (lam_s1 - lam_s2) / h
                 d1_1 = (m1 - m2) * (1.0 / r1)
@@ -890,9 +893,11 @@ class DiffusersScheduler:
         self.set_eps_unets([eps_unet])
 
     def set_eps_unets(self, eps_unets):
-        """One noise predictor per mode-tree leaf (common_scheduler.py set_eps_unets).  The step arithmetic of PLMS /
-        DPM-Solver++ is stateful, so only ONE leaf can be driven per loop (the reference shares one diffusers scheduler
-        object between the leaves of a graft, which steps its multistep history twice per timestep)."""
+        """One noise predictor per mode-tree leaf (common_scheduler.py set_eps_unets).  Every leaf gets its own step
+        wrapper over the ONE scheduler object, exactly as the reference builds them (common_scheduler.py:240
+        ``self.unets = [self.wrap_unet(eps_unet) for eps_unet in self.eps_unets]``): DDIM is stateless, so a grafted
+        inpaint runs as it should; PLMS / DPM-Solver++ keep a multistep history in that shared object, which the two
+        leaves of a graft both feed while they overlap (0.1 < u < 0.3) - the reference's behaviour, reproduced."""
         self.eps_unets = list(eps_unets)
         self.eps_unet = self.eps_unets[-1] if self.eps_unets else None
 
@@ -900,9 +905,6 @@ class DiffusersScheduler:
                       prediction_type: str = "epsilon"):
         if self.eps_unet is None:
             raise ValueError("Epsilon unet needs to be set before timesteps")
-        if len(self.eps_unets) != 1:
-            raise ValueError("Diffusers-style samplers (ddim, plms, dpmsolverpp_*) drive a single UNet: use a k-diffusion "
-                             "sampler with grafted inpaint / hires fix")
         if prediction_type not in ("epsilon", "v_prediction"):
             raise NotImplementedError(f"prediction_type {prediction_type!r}")
         self.prediction_type = prediction_type
@@ -920,11 +922,12 @@ class DiffusersScheduler:
 
         class _DUnet:
             """wrap_unet (common_scheduler.py:261-283): x_t, t -> eps -> scheduler.step -> x_{t-1}"""
-            evals = 0
+            def __init__(self, eps_unet):
+                self.eps_unet, self.evals = eps_unet, 0
 
             def __call__(self, x, t):
                 t = int(t)
-                eps = outer.eps_unet(x, t)
+                eps = self.eps_unet(x, t)
                 if outer.prediction_type == "v_prediction":
                     # eps = sqrt(abar) v + sqrt(1 - abar) x   (x0 = sqrt(abar) x - sqrt(1 - abar) v)
                     a = float(outer.sched.alphas_cumprod[t])
@@ -932,8 +935,8 @@ class DiffusersScheduler:
                 self.evals += 1
                 return outer.sched.step(eps, t, x)
 
-        self.unets = [_DUnet()]
-        self.unet = self.unets[0]
+        self.unets = [_DUnet(e) for e in self.eps_unets]
+        self.unet = self.unets[-1]
 
     def prepare_initial_latents(self, latents: Tensor) -> Tensor:
         return latents * self.sched.init_noise_sigma

@@ -128,6 +128,13 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
  * gyre_unet_forward / _ex accept ctx == NULL with the same B and S and reuse them.  Any set_weight invalidates it.
  * In the reference the same tensor is re-projected on every call (unet/core.py:253-259 binds it per wrapper). */
 int gyre_unet_set_context(gyre_unet* h, void* stream, const void* ctx, int ctx_dtype, int B, int S);
+/* The cache holds GYRE_CTX_SLOTS entries: the leaves of a hires-fix / graft tree and CFGUNet_Sequential
+ * (unet/cfg.py:27-38, unet/hires_fix.py:123-235) alternate between two to four contexts on EVERY step.  _slot projects into
+ * the given entry and makes it current (gyre_unet_set_context = slot 0); gyre_unet_select_context makes an already projected
+ * entry current without any device work (GYRE_ERR_INVALID when that entry is empty or was invalidated by a set_weight). */
+#define GYRE_CTX_SLOTS 4
+int gyre_unet_set_context_slot(gyre_unet* h, void* stream, const void* ctx, int ctx_dtype, int B, int S, int slot);
+int gyre_unet_select_context(gyre_unet* h, int slot);
 
 /* Token merging (ToMe) for the UNet's self-attentions - the reference's pipeline option "tome: <r>"
  * (gyre/pipeline/unified_pipeline.py:1580-1588 -> nonfree/tome_patcher.py:14-52, nonfree/tome_unet.py:138-182,243):
@@ -167,7 +174,10 @@ int gyre_unet_vjp(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, c
 /* The same in two calls, for an autograd node: _begin runs the forward pass (eps_out as gyre_unet_forward) and keeps the
  * activations the adjoints need in `workspace` (gyre_unet_vjp_workspace_bytes; must stay untouched), _finish runs the reverse
  * sweep for a cotangent.  At most one pending pair per handle: any other call on the handle in between drops the state and
- * _finish then returns GYRE_ERR_INVALID (the caller falls back to gyre_unet_vjp). */
+ * _finish then returns GYRE_ERR_INVALID.  gyre_unet_vjp_pending tells the caller beforehand (1 = the state of the last _begin is
+ * still there, 0 = dropped: fall back to the one-shot gyre_unet_vjp), so that a real argument error of _finish is never
+ * mistaken for a dropped state. */
+int gyre_unet_vjp_pending(gyre_unet* h);
 int gyre_unet_vjp_begin(gyre_unet* h, void* stream, const void* x_nchw, int x_dtype, const int64_t* t_dev,
                         const void* ctx, int ctx_dtype, int B, int H, int W, int S, void* workspace, size_t workspace_bytes,
                         void* eps_out_nchw, int out_dtype, const float* temb_add);

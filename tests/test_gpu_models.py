@@ -140,6 +140,25 @@ def test_sd15_vae_decode_full_size():
     report("SD1.5 vae decode 1x4x64x64", got.cpu(), ref, 3e-2)
 
 
+def test_sd15_vae_encode_full_size():
+    """VAE encode at the real 512x512 size against the oracle's moments (unified_pipeline.py:309-313 `vae.encode(x)
+    .latent_dist`): mean and clamped log-variance, plus the posterior sample drawn from the same generator."""
+    cfg = gcfg.sd15_vae()
+    sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg), 0)
+    net = GyreHipVAE(cfg)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    img = (torch.stack([xx, yy, xx * yy])[None] + 0.25 * randn(1, 3, 512, 512, seed=4)).clamp(-1, 1)
+    ref = M.vae_encode_moments(sd, cfg, img)
+    dist = net.encode(img.to(DEV)).latent_dist
+    assert dist.parameters.shape == (1, 8, 64, 64)
+    report("SD1.5 vae encode 1x3x512x512 (moments)", dist.parameters.float().cpu(), ref, 3e-2)
+    report("SD1.5 vae encode mean", dist.mean.float().cpu(), ref[:, :4], 3e-2)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    report("SD1.5 vae posterior sample", dist.sample(generator=g1).float().cpu(), M.vae_posterior_sample(ref, g2), 3e-2)
+
+
 def test_tiny_sdxl_topology_parity():
     """SDXL-style UNet (3 levels, depth 0/2/3, linear projections, text_time added conditioning) - an extension
     beyond the reference (BASELINE config 4); parity against the build's own oracle."""
@@ -185,6 +204,50 @@ def test_context_cache_matches_uncached_and_tracks_changes():
     rc = L.gyre_unet_forward(C.c_void_p(h), None, C.c_void_p(x3.data_ptr()), 0, C.c_void_p(t3.data_ptr()), None, 0, 3, 16, 16, 77,
                              C.c_void_p((ws.data_ptr() + 255) & ~255), ws.numel() - 256, C.c_void_p(o3.data_ptr()), 0)
     assert rc == -1 and b"set_context" in L.gyre_last_error()
+
+
+def test_context_cache_holds_alternating_contexts():
+    """GYRE_CTX_SLOTS entries: hires-fix leaves / CFGUNet_Sequential (reference unet/cfg.py:27-38,
+    unet/hires_fix.py:123-235) alternate between contexts on every call - no re-projection after the first round, results
+    bit-equal to a handle that only ever saw that context; a fifth context evicts the least recently used one; a weight
+    update drops them all."""
+    import ctypes as C
+    from gyre_amd import _lib
+    cfg = gcfg.tiny_unet()
+    net, sd = make_unet(cfg)
+    x = randn(2, 4, 16, 16, seed=21).to(DEV)
+    t = torch.tensor([700, 30], device=DEV)
+    ctxs = [randn(2, 77 if i != 2 else 154, cfg.cross_attention_dim, seed=40 + i).to(DEV) for i in range(5)]
+    fresh = []
+    for c in ctxs:
+        other, _ = make_unet(cfg)
+        fresh.append(other(x, t, encoder_hidden_states=c).sample)
+    L = _lib.lib()
+    calls = {"n": 0}
+    orig = L.gyre_unet_set_context_slot
+
+    class Counting:                                            # count the projections the shell asks for
+        def __call__(self, *a):
+            calls["n"] += 1
+            return orig(*a)
+    L.gyre_unet_set_context_slot = Counting()
+    try:
+        for rnd in range(3):
+            for i in range(4):
+                assert torch.equal(net(x, t, encoder_hidden_states=ctxs[i]).sample, fresh[i]), (rnd, i)
+        assert calls["n"] == 4 and len(net._ctx_slots) == 4
+        assert torch.equal(net(x, t, encoder_hidden_states=ctxs[4]).sample, fresh[4])       # evicts context 0 (LRU)
+        assert calls["n"] == 5
+        assert torch.equal(net(x, t, encoder_hidden_states=ctxs[3]).sample, fresh[3]) and calls["n"] == 5
+        assert torch.equal(net(x, t, encoder_hidden_states=ctxs[0]).sample, fresh[0]) and calls["n"] == 6
+        # selecting an empty / invalidated entry through the raw C ABI is an error, not stale data
+        net.load_state_dict(sd)
+        net(x, t, encoder_hidden_states=ctxs[1])
+        assert calls["n"] == 7 and len(net._ctx_slots) == 1
+        assert L.gyre_unet_select_context(C.c_void_p(net._handle), 3) == -1 and b"slot" in L.gyre_last_error()
+        assert L.gyre_unet_select_context(C.c_void_p(net._handle), 7) == -1
+    finally:
+        L.gyre_unet_set_context_slot = orig
 
 
 def test_lora_merge_on_native_unet():

@@ -618,9 +618,22 @@ def test_pipeline_grafted_inpaint_tree(tiny):
     calls.update(base=0, inpaint=0)
     GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp, grafted_inpaint=True)(**{**kw, "mask_image": None, "strength": 0.5})
     assert (calls["inpaint"], calls["base"]) == (0, 6)
-    # diffusers-style samplers keep one multistep history: they refuse a multi-leaf tree
-    with pytest.raises(ValueError, match="single UNet"):
-        pipe(**{**kw, "sampler": "plms"})
+    # diffusers-style samplers: one step wrapper per leaf over the ONE scheduler object, as the reference builds them
+    # (common_scheduler.py:240,261-283) - the same leaf schedule as above, finite results for every sampler of that family.
+    # (steps_offset: strength 1.0 starts at timesteps[1], so one evaluation less than the k-diffusion loop)
+    for smp in ("ddim", "plms", "dpmsolverpp_2", "dpmsolverpp_3"):
+        calls.update(base=0, inpaint=0)
+        out_d = pipe(**{**kw, "sampler": smp})
+        assert calls["inpaint"] > 0 and calls["base"] > calls["inpaint"], (smp, calls)
+        assert pipe.last_unet_evals == calls["inpaint"] + calls["base"]
+        assert out_d.shape == (2, 4, 16, 16) and bool(torch.isfinite(out_d).all()), smp
+    # DDIM keeps no history: with the graft window closed (blend start = end = 2: p = 0 always) the tree equals the plain
+    # runway-inpaint request bit for bit
+    p_closed = GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp,
+                            grafted_inpaint={"start": 2.0, "end": 3.0})
+    a = p_closed(**{**kw, "sampler": "ddim"})
+    b = GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp)(**{**kw, "sampler": "ddim"})
+    assert torch.equal(a, b)
     # hires fix above the threshold: four leaves (natural + full size, each grafted)
     calls.update(base=0, inpaint=0)
     bmask = torch.zeros(1, 1, 192, 256)
