@@ -257,6 +257,49 @@ def main():
     if images is not None:
         assert bool(torch.isfinite(images).all()), "non-finite output"
     evals = getattr(pipe, "last_unet_evals", 0)
+
+    # ---- the latency half of the metric (after the timed region; never part of `value`) -------------------------------------
+    # (a) one image alone: UNet batch 2 (CFG), the per-image latency floor of a single GPU
+    # (b) ONE batch-of-B request split over all ranks with the reference's batched_seeds rule (= --scaling strong): what a
+    #     Gyre client sees when the node's GPUs serve its request together.  Every rank takes part (all_gather of the latents).
+    latency = {}
+    if args.config == "sd15" and args.scaling == "weak":
+        def one_request(rlo, rhi, total):
+            n = rhi - rlo
+            if n > 0:
+                seeds_ = [420420420 + j for j in range(rlo, rhi)]
+                lat_ = pipe(seeds=seeds_, height=size, width=size, num_inference_steps=n_steps, guidance_scale=7.5,
+                            sampler="dpmpp_2m", output_type="latent", input_ids=ids0[rlo:rhi], negative_ids=neg[rlo:rhi])
+                pipe.vae_decode(lat_)
+            else:
+                lat_ = torch.zeros((0, 4, size // 8, size // 8), device=dev)
+            if world > 1:
+                lat_ = gather_batches(lat_, [e - s_ for s_, e in shard_bounds(total, world)])
+            return lat_
+
+        def timed(fn, reps):
+            ts_ = []
+            for _ in range(reps):
+                barrier()
+                t_ = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts_.append(time.perf_counter() - t_)
+            tt_ = torch.tensor(ts_, device=dev if (world > 1 and backend == "nccl") else "cpu", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            return float(tt_.median())
+        ids0 = synthetic_prompt_ids(B, seed=1234).to(dev)          # the SAME request on every rank
+        if world == 1:
+            one_request(0, 1, 1)                                    # warm-up at UNet batch 2 (workspace, planner)
+            latency["latency_b1_s"] = round(timed(lambda: one_request(0, 1, 1), 2), 4)
+            latency["latency_b1_note"] = "wall time of a ONE-image request on one GPU (51 CFG UNet evaluations at batch 2 + VAE decode)"
+        slo, shi = shard_bounds(B, world)[rank]
+        one_request(slo, shi, B)                                    # warm-up at the shard's batch size
+        latency["latency_request_split_s"] = round(timed(lambda: one_request(slo, shi, B), 2), 4)
+        latency["latency_request_split_note"] = (f"wall time of ONE batch-of-{B} request split over the {world} GPU(s) of the node "
+                                                 f"(batched_seeds rule, per-rank images {[e - s_ for s_, e in shard_bounds(B, world)]}; "
+                                                 f"max over ranks, median of 2)")
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -334,6 +377,7 @@ def main():
                             else "wall time of one batch-of-%d request on rank 0 (per-image latency at batch %d)" % (B, B),
             "roofline": roof,
         }
+        out.update(latency)
         if per_img:
             out["step_mfma_frac"] = round(sum(sizes) * per_img / (elapsed / args.steps) / MFMA_PEAK_TFLOPS / world, 4)
             out["step_mfma_frac_note"] = ("algorithmic 0.803 TFLOP per UNet sample-forward x all evaluations; the cross-attention K/V "

@@ -87,6 +87,10 @@ _SIGS = {
     "gyre_get_batch_invariant": (_i, []),
     "gyre_op_groupnorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _sz, _vp]),
     "gyre_op_groupnorm_workspace": (_sz, [_i, _i, _i, _i]),
+    "gyre_op_gemm_splitk_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "gyre_op_conv3x3_colstats": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "gyre_op_linear_colstats": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "gyre_op_groupnorm_colstats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "gyre_op_layernorm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp]),
     "gyre_op_linear": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "gyre_op_linear_t": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),

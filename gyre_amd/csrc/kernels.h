@@ -25,6 +25,12 @@ struct GnParams {
     int nchunks;
     bf16_t* y;           // [B][HW][C]
     float* mean_rstd = nullptr;  // optional [B][G][2] (backward pass)
+    // statistics left by the producers of x / x2 (GemmParams::colstat_out): [B][cs_chunks][C_src / cs_unit][2] per source.
+    // When cs_x is set (and cs_x2 for a dual-source call) launch_groupnorm_stats is not needed: launch_groupnorm_apply
+    // finishes the group statistics from them in its prologue (cs_unit divides C1, C - C1 and C / G).
+    const float* cs_x = nullptr; int cs_x_chunks = 0;
+    const float* cs_x2 = nullptr; int cs_x2_chunks = 0;
+    int cs_unit = 0;
 };
 size_t gn_workspace_bytes(int B, int HW, int C, int G);
 int gn_pick_chunks(int B, int HW, int C);
@@ -34,6 +40,7 @@ int gemm_get_batch_invariant();
 int launch_groupnorm_stats(hipStream_t st, const GnParams& p);   // partial sums + finalize -> scale_shift
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+b)
 bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch path for small feature maps
+bool gn_accepts_colstats(const GnParams& p);                     // cs_unit / shapes fit the producer-statistics form of the apply
 int launch_groupnorm_small(hipStream_t st, const GnParams& p);
 int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
                      bf16_t* y);
@@ -96,7 +103,18 @@ struct GemmParams {
     // (variance as E[x^2] - mean^2 in fp32): the separate statistics pass disappears.
     float* rowstat_out = nullptr;
     const float* ln_parts = nullptr; int ln_nparts = 0; float ln_eps = 1e-5f;
+    // GroupNorm statistics straight from the kernel that PRODUCED the tensor (the column counterpart of rowstat_out):
+    // colstat_out [M / colstat_rows][N / colstat_unit][2] = per block of colstat_rows consecutive output rows and per unit of
+    // colstat_unit consecutive channels the sum and the sum of squares of the bf16-rounded outputs, reduced in a fixed order
+    // (rows of a 16- / 32-row slab -> slabs -> wave tiles -> channels of the unit; no atomics).  colstat_rows is dictated by
+    // the kernel the planner picks: gemm_colstat_rows(p) (0: this problem cannot; the consumer then runs its own statistics
+    // pass).  The row blocks never straddle a sample (rows_per_sample % colstat_rows == 0 is part of the condition), so a
+    // GroupNorm over the tensor - alone or as one source of a skip concat - finishes mean / rstd from these partials
+    // (GnParams::cs_x / cs_x2) and the statistics pass over the tensor disappears.
+    float* colstat_out = nullptr; int colstat_unit = 0;
 };
+// rows per colstat_out row block launch_gemm would use for `p` (p.colstat_unit and p.rows_per_sample set); 0: unsupported
+int gemm_colstat_rows(const GemmParams& p);
 // number of N tiles (= partial sums per row) launch_gemm would emit into rowstat_out for `p`; 0: this problem cannot
 int gemm_rowstat_parts(const GemmParams& p);
 // true when launch_gemm would run `p` (ln_colsum set or not) on a kernel that supports the folded LayerNorm

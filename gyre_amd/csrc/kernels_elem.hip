@@ -344,7 +344,28 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
         if (parts < 1) parts = 1;
         const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
         float a = 0.f, b = 0.f;
-        if (part < parts)
+        if (p.cs_x) {
+            // statistics left by the PRODUCERS of x / x2 (GemmParams::colstat_out): per source [B][chunks][C_src / unit][2].
+            // Group g = channels [g * cpg, (g + 1) * cpg) of the concatenation: its units below C1 come from x, the others
+            // from x2 (unit divides C1, C - C1 and cpg).  Fixed order: source, chunk (strided over the parts), unit.
+            const int unit = p.cs_unit, c_lo = g * cpg, c_hi = c_lo + cpg;
+            if (part < parts) {
+                const int nu1 = p.C1 / unit;
+                const int u0 = min(c_lo, p.C1) / unit, u1 = min(c_hi, p.C1) / unit;
+                if (u1 > u0)
+                    for (int ch = part; ch < p.cs_x_chunks; ch += parts) {
+                        const float2* src = (const float2*)p.cs_x + ((size_t)n * p.cs_x_chunks + ch) * nu1;
+                        for (int u = u0; u < u1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
+                    }
+                const int nu2 = (p.C - p.C1) / unit;
+                const int v0 = (max(c_lo, p.C1) - p.C1) / unit, v1 = (max(c_hi, p.C1) - p.C1) / unit;
+                if (v1 > v0)
+                    for (int ch = part; ch < p.cs_x2_chunks; ch += parts) {
+                        const float2* src = (const float2*)p.cs_x2 + ((size_t)n * p.cs_x2_chunks + ch) * nu2;
+                        for (int u = v0; u < v1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
+                    }
+            }
+        } else if (part < parts)
             for (int ch = part; ch < p.nchunks; ch += parts) {
                 const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
                 a += src[0]; b += src[1];
@@ -437,7 +458,15 @@ int launch_groupnorm_stats(hipStream_t st, const GnParams& p) {
     GYRE_LAUNCH_CHECK();
     return 0;
 }
+bool gn_accepts_colstats(const GnParams& p) {
+    const int unit = p.cs_unit;
+    if (unit <= 0 || !gn_finalize_in_apply(p) || gn_use_small(p.HW, p.C, p.C1, p.G)) return false;
+    const int cpg = p.C / p.G;
+    return p.C % p.G == 0 && cpg % unit == 0 && p.C1 % unit == 0 && (p.C - p.C1) % unit == 0;
+}
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
+    if (p.cs_x && (!gn_accepts_colstats(p) || p.cs_x_chunks <= 0 || (p.C1 < p.C && (!p.cs_x2 || p.cs_x2_chunks <= 0))))
+        GYRE_FAIL(-1, "groupnorm: producer statistics need the finalize-in-apply form, units that divide the groups and both sources");
     size_t total = (size_t)p.B * p.HW * (p.C / 8);
     GyreProfScope prof_(KC_GN_APPLY, st, 0.0, (double)p.B * p.HW * p.C * 4.0);
     if (gn_finalize_in_apply(p)) {

@@ -113,12 +113,16 @@ __device__ __forceinline__ float4 ep_affine(const f32x4_t& a, const float4& b, c
 
 // RS: per-row (sum, sum of squares) of this wave tile's rounded outputs -> rs_row[row of the wave tile] (LDS); rs_part = per-wave
 // LDS scratch of 16 x (TN / 8) float2 (GemmParams::rowstat_out)
-template <int MI, int NI, int TN, bool GG, bool LNF = false, bool RS = false>
+// CS: per-COLUMN (sum, sum of squares) of this wave tile's rounded outputs -> cs_wave[column of the wave tile] (LDS)
+// (GemmParams::colstat_out): every lane puts the values it stored (what the consumer will read; zeros past M / N) back into
+// the slab position it took them from, then each lane walks the 16 rows of "its" columns - LDS operations of one wave
+// complete in order, so no barrier is involved - and keeps the running sums over the wave tile's slabs in registers.
+template <int MI, int NI, int TN, bool GG, bool LNF = false, bool RS = false, bool CS = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
                                                      int fr, int fq, int lane, float* my, const float* lrstd = nullptr,
                                                      const float* lrmu = nullptr, const float* lcs = nullptr,
                                                      const float* lbb = nullptr, float2* rs_part = nullptr,
-                                                     float2* rs_row = nullptr) {
+                                                     float2* rs_row = nullptr, float2* cs_wave = nullptr) {
     constexpr int TNO_FULL = TN;                 // staged columns per wave without GEGLU
     constexpr bool gg = GG;
     constexpr int tno = gg ? TNO_FULL / 2 : TNO_FULL;    // output columns this wave produces
@@ -127,6 +131,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
     const int n_out = gg ? p.N / 2 : p.N;
     constexpr int vec_per_row = tno / 8;
     constexpr int NV = (16 * vec_per_row + 63) / 64;       // row-wise vectors per lane per slab
+    constexpr int CSN = CS ? (tno + 63) / 64 : 1;          // columns per lane of the column-statistics walk
+    float cs_s[CSN], cs_q[CSN];
+#pragma unroll
+    for (int c = 0; c < CSN; ++c) { cs_s[c] = 0.f; cs_q[c] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         // the residual vectors of this slab are requested first, so their latency runs under the LDS round trip
@@ -187,8 +195,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
             const float4 lo = *(const float4*)(my + row * rowf + c8 * 8);
             const float4 hi = *(const float4*)(my + row * rowf + c8 * 8 + 4);
             float rs_s = 0.f, rs_q = 0.f;
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (mm < p.M && nn < n_out) {
-                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
                 if (p.residual) {
                     float r[8];
                     unpack8(rres[q], r);
@@ -197,13 +206,29 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 }
                 const uint4 pk = pack8(f);
                 *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pk;
-                if (RS) {           // statistics of what the consumer will read: the rounded values
-                    unpack8(pk, f);
+                if (RS || CS) unpack8(pk, f);     // statistics of what the consumer will read: the rounded values
+                if (RS) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { rs_s += f[e]; rs_q = fmaf(f[e], f[e], rs_q); }
                 }
             }
             if (RS) rs_part[v] = make_float2(rs_s, rs_q);       // v = row * vec_per_row + c8
+            if (CS) {
+                *(float4*)(my + row * rowf + c8 * 8) = make_float4(f[0], f[1], f[2], f[3]);
+                *(float4*)(my + row * rowf + c8 * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            }
+        }
+        if (CS) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CSN; ++c) {
+                const int col = lane + 64 * c;
+                if (col < tno) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float t = my[r * rowf + col]; cs_s[c] += t; cs_q[c] = fmaf(t, t, cs_q[c]); }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (RS) {
             // LDS operations of one wave complete in order: the 16 row sums below see this slab's partials
@@ -215,6 +240,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 rs_row[i * 16 + lane] = make_float2(su, sq);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (CS) {
+#pragma unroll
+        for (int c = 0; c < CSN; ++c) {
+            const int col = lane + 64 * c;
+            if (col < tno) cs_wave[col] = make_float2(cs_s[c], cs_q[c]);
         }
     }
 }
@@ -271,7 +303,8 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
 // ------------------------------------------------------------------------------------------------
 // LNF: folded LayerNorm (GemmParams::ln_colsum / ln_stats) applied by the staged epilogue
 // RS: also emit per-row partial statistics of the output tile (GemmParams::rowstat_out)
-template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false, bool RS = false>
+// CS: also emit per-column-unit partial statistics of the output tile (GemmParams::colstat_out)
+template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false, bool RS = false, bool CS = false>
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
@@ -413,7 +446,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (!LNF && !RS && splits > 1) {     // (the folded-LayerNorm / row-statistics forms are launched unsplit, staged epilogue only)
+    if (!LNF && !RS && !CS && splits > 1) {     // (the folded-LayerNorm / statistics forms are launched unsplit, staged epilogue only)
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
         return;
     }
-    if (!LNF && !RS && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+    if (!LNF && !RS && !CS && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     }
     // coalesced LDS-staged epilogue when every 8-channel group is 16-byte addressable, else the direct one
     const int n_out = p.geglu ? p.N / 2 : p.N;
-    if (LNF || RS || (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
+    if (LNF || RS || CS || (p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
                 (((size_t)p.out | (size_t)p.residual) & 15) == 0)) {
         float* my = (float*)smem_raw + wave * (16 * (TN + 4));   // the operand ring is dead after the last barrier
         float lrstd[MI], lrmu[MI];
@@ -495,6 +528,33 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
             }
             return;
         }
+        if constexpr (CS) {
+            // wave tile column sums -> LDS [8 waves][TN] behind the slabs; after the block barrier one thread per tile column adds
+            // the WM wave tiles in order, then one thread per unit adds its channels and writes the tile's partial
+            float2* cs_all = (float2*)((float*)smem_raw + 8 * 16 * (TN + 4));
+            float2* chan = cs_all + 8 * TN;
+            gemm_epilogue_staged<MI, NI, TN, false, false, false, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, nullptr, nullptr,
+                                                                          nullptr, nullptr, nullptr, nullptr, cs_all + wave * TN);
+            __syncthreads();
+            for (int t = tid; t < BN; t += 512) {
+                const int wn_ = t / TN, col = t - wn_ * TN;
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { const float2 v = cs_all[(w * WN + wn_) * TN + col]; su += v.x; sq += v.y; }
+                chan[t] = make_float2(su, sq);
+            }
+            __syncthreads();
+            const int unit = p.colstat_unit;
+            for (int u = tid; u * unit < BN; u += 512) {
+                const int n = n0 + u * unit;
+                if (n < p.N) {
+                    float su = 0.f, sq = 0.f;
+                    for (int c = 0; c < unit; ++c) { const float2 v = chan[u * unit + c]; su += v.x; sq += v.y; }
+                    ((float2*)p.colstat_out)[(size_t)tm * (p.N / unit) + n / unit] = make_float2(su, sq);
+                }
+            }
+            return;
+        }
         if (p.vt_out && n0 + wn * TN >= p.vt_col0) {             // V columns of a fused Q|K|V projection (wave-uniform)
             gemm_epilogue_staged_t<MI, NI, TN, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
             return;
@@ -505,7 +565,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         gemm_epilogue_staged<MI, NI, TN, false, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
         return;
     }
-    if constexpr (!LNF && !RS) gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
+    if constexpr (!LNF && !RS && !CS) gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq);
 }
 
 // out = bf16( sum_s slab[s] + bias + rowbias + residual ), fixed summation order (deterministic)
@@ -531,7 +591,92 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits)
     *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
 }
 
+// The same reduction for a tensor whose consumer is a GroupNorm (GemmParams::colstat_out): a workgroup owns CS_RED_ROWS
+// consecutive rows (never straddling a sample) x CB consecutive columns (whole units), a thread 8 consecutive columns of every
+// PY-th row, so the per-channel sums of the ROUNDED outputs accumulate in registers; they are folded rows -> channels -> units
+// through LDS in a fixed order and leave as one partial per (row block, unit).  Grid = row blocks x column blocks: as many
+// workgroups as the plain reduction has at these sizes (a one-dimensional grid of row blocks left the chip idle at small M).
+#define CS_RED_ROWS 16
+__global__ __launch_bounds__(256) void k_splitk_reduce_cs(GemmParams p, int splits, int CB, int TX, int PY) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* red = (float2*)smem_raw;             // [PY][CB]
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int m0 = blockIdx.x * CS_RED_ROWS, nb = blockIdx.y * CB;
+    if (ty < PY && tx * 8 < CB) {
+        const int n = nb + tx * 8;
+        float s[8], ss[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+        float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+        }
+        for (int r = ty; r < CS_RED_ROWS; r += PY) {
+            const int m = m0 + r;
+            if (m >= p.M) break;
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < splits; ++sp) {
+                const float* src = p.splitk_ws + ((size_t)sp * p.M + m) * p.N + n;
+                const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+                a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += bs[e];
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias + n;
+                const float4 b0 = *(const float4*)rb, b1 = *(const float4*)(rb + 4);
+                a[0] += b0.x; a[1] += b0.y; a[2] += b0.z; a[3] += b0.w; a[4] += b1.x; a[5] += b1.y; a[6] += b1.z; a[7] += b1.w;
+            }
+            if (p.residual) {
+                float rr[8];
+                unpack8(*(const uint4*)(p.residual + (size_t)m * p.ldr + n), rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += rr[e];
+            }
+            const uint4 pk = pack8(a);
+            *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = pk;
+            unpack8(pk, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += a[e]; ss[e] = fmaf(a[e], a[e], ss[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(size_t)ty * CB + tx * 8 + e] = make_float2(s[e], ss[e]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CB; c += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int y = 0; y < PY; ++y) { const float2 t = red[(size_t)y * CB + c]; a += t.x; b += t.y; }
+        red[c] = make_float2(a, b);              // row 0, own column
+    }
+    __syncthreads();
+    const int unit = p.colstat_unit, nu = p.N / unit;
+    for (int u = threadIdx.x; u * unit < CB; u += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int c = u * unit; c < (u + 1) * unit; ++c) { const float2 t = red[c]; a += t.x; b += t.y; }
+        ((float2*)p.colstat_out)[(size_t)blockIdx.x * nu + nb / unit + u] = make_float2(a, b);
+    }
+}
+// column block of the reduction: the smallest multiple of lcm(8, unit) that is >= 128 and divides N (N itself otherwise)
+static int cs_red_colblock(int N, int unit) {
+    int l = unit;
+    while (l % 8) l += unit;
+    for (int cb = l; cb < N; cb += l)
+        if (cb >= 128 && N % cb == 0) return cb;
+    return N;
+}
+
 int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits) {
+    if (p.colstat_out) {
+        const int CB = cs_red_colblock(p.N, p.colstat_unit);
+        const int TX = CB / 8;
+        int PY = 256 / TX; if (PY < 1) PY = 1; if (PY > CS_RED_ROWS) PY = CS_RED_ROWS;
+        const size_t lds = (size_t)PY * CB * sizeof(float2);
+        hipLaunchKernelGGL(k_splitk_reduce_cs, dim3((unsigned)((p.M + CS_RED_ROWS - 1) / CS_RED_ROWS), (unsigned)(p.N / CB)), dim3(256), lds, st,
+                           p, splits, CB, TX, PY);
+        GYRE_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t nthreads = (size_t)p.M * (p.N / 4);
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
     GYRE_LAUNCH_CHECK();
@@ -845,7 +990,25 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
-    if (p.mode == GEMM_LINEAR && p.rowstat_out) {
+    if (p.colstat_out && splits == 1) {
+        if constexpr (BN == 320) {
+            const bool uni = (p.Cin % BK == 0) && (p.C1 % BK == 0);
+#define GYRE_GEMM8_CS(MODE_, UNI_)                                                                                  \
+    do {                                                                                                            \
+        auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_, false, false, true>;                                       \
+        static std::atomic<unsigned long long> attr_done{0};                                                        \
+        if (gyre_lds_attr_needed(attr_done))                                                                        \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
+    } while (0)
+            if (p.mode == GEMM_LINEAR) GYRE_GEMM8_CS(GEMM_LINEAR, true);
+            else if (uni) GYRE_GEMM8_CS(GEMM_CONV3, true);
+            else GYRE_GEMM8_CS(GEMM_CONV3, false);
+#undef GYRE_GEMM8_CS
+        } else {
+            GYRE_FAIL(-6, "gemm: column statistics exist for the 320-wide tiles only (see gemm_colstat_rows)");
+        }
+    } else if (p.mode == GEMM_LINEAR && p.rowstat_out) {
         auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, false, true>;
         static std::atomic<unsigned long long> attr_done{0};
         if (gyre_lds_attr_needed(attr_done))
@@ -865,11 +1028,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
     }
 #undef GYRE_GEMM8_GO
     GYRE_LAUNCH_CHECK();
-    if (splits > 1) {
-        const size_t nthreads = (size_t)p.M * (p.N / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p, splits);
-        GYRE_LAUNCH_CHECK();
-    }
+    if (splits > 1) return launch_splitk_reduce(st, p, splits);
     return 0;
 }
 
@@ -1032,6 +1191,26 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     return (p.N + bn - 1) / bn;
 }
 
+// Which kernel would emit the column statistics of `p`, and with what row-block size.  Mirrors launch_gemm's decisions.
+int gemm_colstat_rows(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    const int unit = p.colstat_unit;
+    if (unit <= 0 || g_force_cfg || p.force_cfg || (p.debug & 0x20000) || g_invariant_batch > 0) return 0;   // bit 17: separate statistics pass
+    if (p.out_mode != OUT_BF16 || p.geglu || p.vt_out || p.ln_colsum || p.rowstat_out || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 8) return 0;
+    if (p.N % unit || 320 % unit || p.rows_per_sample <= 0 || p.M % p.rows_per_sample) return 0;
+    if (!gemm_staged_epilogue_ok(p)) return 0;
+    int splits = 1;
+    const int cfg = plan_cfg(p, &splits);
+    int rows = 0;
+    if (splits > 1) rows = (cs_red_colblock(p.N, unit) <= 2048) ? CS_RED_ROWS : 0;     // k_splitk_reduce_cs
+    else if (cfg == 4) rows = 256;
+    else if (cfg == 5) rows = 128;
+    else if (cfg == 24 && p.mode == GEMM_CONV3) rows = 256;                    // pipelined 256x320 tile (kernels_gemm4s.hip)
+    if (!rows || p.rows_per_sample % rows) return 0;
+    return rows;
+}
+
 GemmPlan gemm_plan(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;      // same planner inputs as launch_gemm
@@ -1091,6 +1270,14 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.vt_out) {
         const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
+    }
+    if (p.colstat_out) {
+        GemmParams q = p0;
+        q.splitk_ws = nullptr;
+        const int rows = gemm_colstat_rows(q);
+        const int want = splits > 1 ? CS_RED_ROWS : cfg == 4 ? 256 : cfg == 5 ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
+        if (rows <= 0 || rows != want)
+            GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
     }
     if (p.rowstat_out && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");

@@ -69,7 +69,8 @@ __device__ __forceinline__ srd_t make_srd(const void* base, unsigned bytes) {
 // LNF: LayerNorm folded into the GEMM (GemmParams::ln_colsum with ln_stats or ln_parts): the epilogue applies
 // rstd * acc - rstd * mean * colsum + bias per element (linear mode, unsplit; instantiated for the 8-wave 256x320 tile only -
 // the weight-dominated GEGLU FF1 of the 16x16 level)
-template <int BM, int BN, int WM, int WN, int MODE, int ZFILL, bool LNF = false>
+// CS: column statistics of the output tile for the GroupNorm that consumes it (GemmParams::colstat_out; unsplit launches)
+template <int BM, int BN, int WM, int WN, int MODE, int ZFILL, bool LNF = false, bool CS = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams p, int tiles_m, int tiles_n, int splits, int group_m) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
 
     const int hi = lane >> 5, l31 = lane & 31;
     const int m_base = m0 + wm * TM, n_base = n0 + wn * TN;
-    if (!LNF && splits > 1) {
+    if (!LNF && !CS && splits > 1) {
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
         float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
         }
         return;
     }
-    if (!LNF && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
+    if (!LNF && !CS && (p.debug & 4)) {  // tuning ablation: no epilogue (keep the accumulators alive with one conditional store)
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -332,6 +333,98 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
 
     // ---- staged epilogue: 32-row slabs of the wave tile through LDS (fp32), then whole rows out --------------------------------
     // (the operand ring is dead: the barrier above is behind every LDS read and every DMA write of every wave).
+    if constexpr (CS) {
+        // Column statistics for the consuming GroupNorm (GemmParams::colstat_out; plain bias / time-embedding / residual
+        // epilogue only).  Passes of <= 2 column blocks = 8 (or 4) 16-byte vectors per row: a power of two, so a lane keeps
+        // the SAME 8 channels for every row it reads back and their sum / sum of squares stay in registers over the wave
+        // tile's rows (of the rounded values: what the consumer will read).  Per pass the lanes that share a channel vector
+        // are folded through the wave's own slab region (LDS operations of one wave complete in order), then - behind the
+        // block barrier - the WM wave tiles per column, then the channels of each unit; fixed order throughout.
+        constexpr int NPC = (NI + 1) / 2, ROWC = 2 * 32 + 4, FST = 20;   // FST: floats per lane in the fold area (conflict-free b128)
+        static_assert(64 * FST <= 32 * ROWC, "fold area exceeds the wave's slab");
+        float* slabc = (float*)smem + w * (32 * ROWC);
+        float2* cs_all = (float2*)((float*)smem + NW * 32 * ROWC);
+        float2* chan = cs_all + NW * TN;
+#pragma unroll
+        for (int ps = 0; ps < NPC; ++ps) {
+            const int j0 = 2 * ps, j1 = j0 + 2 < NI ? j0 + 2 : NI;
+            const int vpr = (j1 - j0) * 4, R = 64 / vpr;            // vectors per row, rows per read-back step
+            const int c8 = lane & (vpr - 1), r0 = lane / vpr;
+            const int nn = n_base + j0 * 32 + c8 * 8;
+            float cs_s[8], cs_q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m_base + i * 32 + l31;
+                const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+#pragma unroll
+                for (int j = j0; j < j1; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n_base + j * 32 + 8 * g + 4 * hi;
+                        float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                        if (n < p.N) {
+                            if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w; }
+                            if (rbias) { const float4 tv = *(const float4*)(rbias + n); o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w; }
+                        }
+                        *(float4*)(slabc + l31 * ROWC + (j - j0) * 32 + 8 * g + 4 * hi) = o;
+                    }
+                for (int row = r0; row < 32; row += R) {
+                    const int mm = m_base + i * 32 + row;
+                    if (mm < p.M && nn < p.N) {
+                        const float4 a = *(const float4*)(slabc + row * ROWC + c8 * 8);
+                        const float4 b = *(const float4*)(slabc + row * ROWC + c8 * 8 + 4);
+                        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        if (p.residual) {
+                            float r[8];
+                            unpack8(*(const uint4*)(p.residual + (size_t)mm * p.ldr + nn), r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += r[e];
+                        }
+                        const uint4 pk = pack8(f);
+                        *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pk;
+                        unpack8(pk, f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { cs_s[e] += f[e]; cs_q[e] = fmaf(f[e], f[e], cs_q[e]); }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float* fold = slabc + lane * FST;
+            *(float4*)(fold) = make_float4(cs_s[0], cs_s[1], cs_s[2], cs_s[3]);
+            *(float4*)(fold + 4) = make_float4(cs_s[4], cs_s[5], cs_s[6], cs_s[7]);
+            *(float4*)(fold + 8) = make_float4(cs_q[0], cs_q[1], cs_q[2], cs_q[3]);
+            *(float4*)(fold + 12) = make_float4(cs_q[4], cs_q[5], cs_q[6], cs_q[7]);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < (j1 - j0) * 32) {
+                const int cv = lane >> 3, e = lane & 7;
+                float su = 0.f, sq = 0.f;
+                for (int r = 0; r < R; ++r) { const float* src = slabc + (cv + vpr * r) * FST; su += src[e]; sq += src[8 + e]; }
+                cs_all[w * TN + j0 * 32 + lane] = make_float2(su, sq);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        for (int t = tid; t < BN; t += NW * 64) {
+            const int wn_ = t / TN, col = t - wn_ * TN;
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WM; ++ww) { const float2 v = cs_all[(ww * WN + wn_) * TN + col]; su += v.x; sq += v.y; }
+            chan[t] = make_float2(su, sq);
+        }
+        __syncthreads();
+        const int unit = p.colstat_unit;
+        for (int u = tid; u * unit < BN; u += NW * 64) {
+            const int n = n0 + u * unit;
+            if (n < p.N) {
+                float su = 0.f, sq = 0.f;
+                for (int c = 0; c < unit; ++c) { const float2 v = chan[u * unit + c]; su += v.x; sq += v.y; }
+                ((float2*)p.colstat_out)[(size_t)tm * (p.N / unit) + n / unit] = make_float2(su, sq);
+            }
+        }
+        return;
+    }
     // With 8 waves a full-width slab per wave would not fit LDS: the column blocks go in two passes.
     constexpr int NPASS = NW == 8 ? 2 : 1;
     constexpr int JP = (NI + NPASS - 1) / NPASS;          // column blocks (32 wide) per pass
@@ -462,7 +555,8 @@ static int launch_cfg4s(hipStream_t st, const GemmParams& p, int kcls_base, int 
     const int grid = tiles_m * tiles_n * splits;
     // LDS: two operand stages; the epilogue's four 32-row fp32 slabs reuse them
     constexpr int NW = WM * WN, NI = BN / WN / 32, JP = NW == 8 ? (NI + 1) / 2 : NI;
-    constexpr size_t ring = (size_t)2 * (BM + BN) * 128, epi = (size_t)NW * 32 * (JP * 32 + 4) * 4;
+    constexpr size_t ring = (size_t)2 * (BM + BN) * 128,
+                     epi = (size_t)NW * 32 * (JP * 32 + 4) * 4 + (size_t)(NW * (BN / WN) + BN) * 8;   // slabs + column-statistics scratch
     constexpr size_t lds = ring > epi ? ring : epi;
     // tile rows per group: the ~32 tiles an XCD runs at a time should cover about as many A rows as W rows
     int group_m = 1;
@@ -491,6 +585,17 @@ static int launch_cfg4s(hipStream_t st, const GemmParams& p, int kcls_base, int 
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, tiles_m, tiles_n, splits, group_m);
         } else {
             GYRE_FAIL(-6, "gemm: the folded LayerNorm exists for the 8-wave 256x320 pipelined tile only");
+        }
+    } else if (p.colstat_out && splits == 1) {
+        if constexpr (BM == 256 && BN == 320 && NW == 8) {
+            if (p.mode != GEMM_CONV3) GYRE_FAIL(-6, "gemm: the pipelined tile emits column statistics for convolutions only");
+            auto kern = k_gemm4s<BM, BN, WM, WN, GEMM_CONV3, 0, false, true>;
+            static std::atomic<unsigned long long> attr_done{0};
+            if (gyre_lds_attr_needed(attr_done))
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p, tiles_m, tiles_n, splits, group_m);
+        } else {
+            GYRE_FAIL(-6, "gemm: column statistics exist for the 8-wave 256x320 pipelined tile only");
         }
     } else if (p.mode == GEMM_LINEAR) GYRE_GEMM4S_GO(GEMM_LINEAR, 0);
     else if (p.debug & 0x200) GYRE_GEMM4S_GO(GEMM_CONV3, 1);

@@ -352,6 +352,24 @@ int gyre_op_groupnorm(void* st, const void* x, const void* x2, int C1, int B, in
     TRY(launch_groupnorm_stats((hipStream_t)st, p));
     return launch_groupnorm_apply((hipStream_t)st, p);
 }
+// GroupNorm whose statistics come from the producers of x / x2 (gyre_op_conv3x3_colstats / gyre_op_linear_colstats): no
+// statistics pass, one launch.
+int gyre_op_groupnorm_colstats(void* st, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
+                               const float* gamma, const float* beta, float eps, int silu, const float* cs_x, int cs_x_chunks,
+                               const float* cs_x2, int cs_x2_chunks, int unit, void* ws, size_t wsb, void* y) {
+    if (!x || !gamma || !beta || !ws || !y || !cs_x) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (wsb < gn_workspace_bytes(B, HW, C, groups)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "groupnorm workspace too small");
+    GnParams p;
+    p.x = (const bf16_t*)x; p.x2 = x2 ? (const bf16_t*)x2 : (const bf16_t*)x; p.C1 = x2 ? C1 : C;
+    p.B = B; p.HW = HW; p.C = C; p.G = groups; p.gamma = gamma; p.beta = beta; p.eps = eps; p.silu = silu;
+    p.nchunks = gn_pick_chunks(B, HW, C);
+    p.partial = (float*)ws;
+    p.scale_shift = (float*)((char*)ws + align_up((size_t)B * p.nchunks * groups * 2 * sizeof(float), 256));
+    p.y = (bf16_t*)y;
+    p.cs_x = cs_x; p.cs_x_chunks = cs_x_chunks; p.cs_x2 = x2 ? cs_x2 : nullptr; p.cs_x2_chunks = x2 ? cs_x2_chunks : 0; p.cs_unit = unit;
+    if (!gn_accepts_colstats(p)) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "groupnorm: this shape does not take producer statistics");
+    return launch_groupnorm_apply((hipStream_t)st, p);
+}
 int gyre_op_layernorm(void* st, const void* x, int M, int C, const float* g, const float* b, float eps, void* y) {
     if (!x || !g || !b || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     return launch_layernorm((hipStream_t)st, (const bf16_t*)x, M, C, g, b, eps, (bf16_t*)y);
@@ -385,6 +403,54 @@ int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, con
     p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = Cout; p.rows_per_sample = Ho * Wo;
     p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
     return launch_gemm((hipStream_t)st, p);
+}
+// The same operators leaving the GroupNorm statistics of their output (GemmParams::colstat_out): stats_out
+// [M / rows][N / unit][2] f32 with rows = *rows_out, the row-block size of the kernel the planner picks (<= 0 and
+// GYRE_ERR_UNSUPPORTED when that kernel cannot).  ws: split-K slab space (gyre_op_gemm_splitk_bytes; may be null when 0).
+static int op_colstats_go(hipStream_t st, GemmParams& p, int unit, int rps, float* stats_out, size_t stats_bytes, void* ws,
+                          size_t ws_bytes, int* rows_out) {
+    p.colstat_unit = unit; p.rows_per_sample = rps;
+    const int rows = gemm_colstat_rows(p);
+    if (rows_out) *rows_out = rows;
+    if (rows <= 0) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "colstats: the planner's kernel for this shape cannot emit column statistics");
+    if (stats_bytes < (size_t)(p.M / rows) * (p.N / unit) * 2 * sizeof(float)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "colstats: stats buffer too small");
+    GemmPlan pl = gemm_plan(p);
+    if (pl.ws_bytes) {
+        if (!ws || ws_bytes < pl.ws_bytes) GYRE_FAIL(GYRE_ERR_WORKSPACE, "colstats: split-K workspace too small");
+        p.splitk_ws = (float*)ws; p.splitk_ws_bytes = ws_bytes;
+    }
+    p.colstat_out = stats_out;
+    return launch_gemm(st, p);
+}
+size_t gyre_op_gemm_splitk_bytes(int conv, int M, int N, int K, int B) {
+    GemmParams p;
+    p.mode = conv ? GEMM_CONV3 : GEMM_LINEAR; p.M = M; p.N = N; p.K = K; p.Cin = conv ? K / 9 : 0; p.lda = conv ? K / 9 : K;
+    p.ldc = N; p.ldr = N; p.samples = B; p.out_mode = OUT_BF16;
+    if (conv) { p.Ho = p.Wo = p.Hi = p.Wi = (int)sqrt((double)(M / (B > 0 ? B : 1))); }
+    return gemm_plan(p).ws_bytes;
+}
+int gyre_op_conv3x3_colstats(void* st, const void* x, int B, int Hi, int Wi, int Cin, const void* w, int Cout, const float* bias,
+                             const void* residual, int stride, int ups, int unit, void* y, float* stats_out, size_t stats_bytes,
+                             void* ws, size_t ws_bytes, int* rows_out) {
+    if (!x || !w || !y || !stats_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    const int Hin = ups ? 2 * Hi : Hi, Win = ups ? 2 * Wi : Wi;
+    const int Ho = (Hin + 2 - 3) / stride + 1, Wo = (Win + 2 - 3) / stride + 1;
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = Cin; p.mode = GEMM_CONV3; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo;
+    p.stride = stride; p.pad = 1; p.ups = ups; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * Ho * Wo; p.samples = B;
+    p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = Cout;
+    p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
+    return op_colstats_go((hipStream_t)st, p, unit, Ho * Wo, stats_out, stats_bytes, ws, ws_bytes, rows_out);
+}
+int gyre_op_linear_colstats(void* st, const void* x, int M, int K, const void* w, int N, const float* bias, const void* residual,
+                            int rows_per_sample, int unit, void* y, float* stats_out, size_t stats_bytes, void* ws, size_t ws_bytes,
+                            int* rows_out) {
+    if (!x || !w || !y || !stats_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K;
+    p.N = N; p.M = M; p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = N; p.samples = M / rows_per_sample;
+    p.out = y; p.ldc = N; p.out_mode = OUT_BF16;
+    return op_colstats_go((hipStream_t)st, p, unit, rows_per_sample, stats_out, stats_bytes, ws, ws_bytes, rows_out);
 }
 int gyre_op_repack_conv_weight(void* st, const float* w, int Cout, int Cin, int KH, int KW, int Cin_pad, void* out) {
     if (!w || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");

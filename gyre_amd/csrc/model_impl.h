@@ -61,6 +61,9 @@ struct Arena {
 struct Tn {  // NHWC bf16 activation (or a raw byte buffer when C == 0)
     bf16_t* p = nullptr; size_t off = (size_t)-1, bytes = 0;
     int B = 0, H = 0, W = 0, C = 0;
+    // GroupNorm statistics its producer left (GemmParams::colstat_out): [B][cs_chunks][C / cs_unit][2] floats in the arena,
+    // released with the tensor; cs_chunks == 0: none (or invalidated by an in-place update of the tensor)
+    float* cs = nullptr; size_t cs_off = (size_t)-1, cs_bytes = 0; int cs_chunks = 0, cs_unit = 0;
     int rows() const { return B * H * W; }
     bool valid() const { return off != (size_t)-1; }
 };
@@ -256,6 +259,7 @@ struct Exec {
     const std::vector<CtxKV>* ctx_cache = nullptr;
     size_t ctx_layer = 0;
     int batch = 0;   // samples in the current call (planner hint, see gemm_set_batch_invariant)
+    int cs_unit = 0; // channels per GroupNorm-statistics unit the producers emit (0 = producers emit none; set per call)
     int tome_r = 0;  // ToMe: keys / values merged per self-attention (0 = off; reference option "tome", nonfree/tome_unet.py)
 
     bool dry() const { return arena.dry; }
@@ -271,7 +275,29 @@ struct Exec {
         return 0;
     }
     int alloc_raw(Tn& t, size_t bytes) { return alloc(t, 1, 1, 1, (int)((bytes + 1) / 2)); }
-    void free(Tn& t) { if (t.valid()) { arena.release(t.off, t.bytes); t.off = (size_t)-1; t.p = nullptr; } }
+    void free(Tn& t) {
+        if (t.valid()) { arena.release(t.off, t.bytes); t.off = (size_t)-1; t.p = nullptr; }
+        if (t.cs_off != (size_t)-1) { arena.release(t.cs_off, t.cs_bytes); t.cs_off = (size_t)-1; t.cs = nullptr; t.cs_chunks = 0; }
+    }
+    // Ask the launch described by `p` (output tensor y, `rps` rows per sample) to leave the GroupNorm statistics of y
+    // (GemmParams::colstat_out).  Only where the consumer takes the streaming two-kernel GroupNorm (large maps) and the planner's
+    // kernel for the shape can; otherwise y simply carries none and its GroupNorm runs its own statistics pass.
+    int attach_colstats(GemmParams& p, Tn& y, int rps) {
+        if (!cs_unit || !store || rps <= 256 || (p.rowbias && p.rows_per_sample != rps)) return 0;
+        if (!p.samples) p.samples = batch;
+        GemmParams q = p;
+        q.colstat_unit = cs_unit; q.rows_per_sample = rps;
+        const int rows = gemm_colstat_rows(q);
+        if (rows <= 0 || rps / rows > 64) return 0;        // the apply prologue of every workgroup re-reads all chunks
+        y.cs_chunks = rps / rows; y.cs_unit = cs_unit;
+        y.cs_bytes = (size_t)y.B * y.cs_chunks * (p.N / cs_unit) * 2 * sizeof(float);
+        y.cs_off = arena.alloc(y.cs_bytes);
+        if (y.cs_off == (size_t)-1 || (!arena.dry && y.cs_off + y.cs_bytes > arena.cap))
+            GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small (GroupNorm statistics)");
+        y.cs = arena.dry ? nullptr : (float*)(arena.base + y.cs_off);
+        p.colstat_unit = cs_unit; p.rows_per_sample = rps; p.colstat_out = y.cs;
+        return 0;
+    }
 
     // GroupNorm (+SiLU) of x (optionally concatenated with x2 along C)
     int groupnorm(const Tn& x, const Tn* x2, const float* g, const float* b, float eps, int silu, Tn& y) {
@@ -291,7 +317,15 @@ struct Exec {
             if (gn_use_small(HW, C, x.C, groups)) {
                 TRY(launch_groupnorm_small(st, p));
             } else {
-                TRY(launch_groupnorm_stats(st, p));
+                // statistics straight from the producers of x (and of the skip tensor x2), when both left them
+                if (x.cs_chunks > 0 && (!x2 || (x2->cs_chunks > 0 && x2->cs_unit == x.cs_unit))) {
+                    p.cs_unit = x.cs_unit;
+                    if (gn_accepts_colstats(p)) {
+                        p.cs_x = x.cs; p.cs_x_chunks = x.cs_chunks;
+                        if (x2) { p.cs_x2 = x2->cs; p.cs_x2_chunks = x2->cs_chunks; }
+                    }
+                }
+                if (!p.cs_x) TRY(launch_groupnorm_stats(st, p));
                 TRY(launch_groupnorm_apply(st, p));
             }
         }
@@ -330,6 +364,7 @@ struct Exec {
         p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
         if (residual) { p.residual = residual->p; p.ldr = residual->C; }
         p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
+        TRY(attach_colstats(p, y, Ho * Wo));       // every conv output of the UNet feeds a GroupNorm
         return run_gemm(p);
     }
     // final 3x3 conv straight to the caller's NCHW buffer
@@ -349,12 +384,15 @@ struct Exec {
     // runs the separate statistics pass.
     struct RowStatBuf { Tn t; int nparts = 0; };
     // rs: the caller wants the row statistics of y (and frees rs->t after the consumer ran)
+    // cs_for: the output tensor (y == cs_for->p) feeds a GroupNorm: ask the launch for its statistics (attach_colstats)
     int linear(const bf16_t* x, int lda, const bf16_t* x2, int lda2, int C1, int M, int K, const bf16_t* w, int N,
-               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc, RowStatBuf* rs = nullptr) {
+               const float* bias, const bf16_t* residual, int ldr, int geglu, bf16_t* y, int ldc, RowStatBuf* rs = nullptr,
+               Tn* cs_for = nullptr) {
         GemmParams p;
         p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
         p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
         p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
+        if (cs_for && !rs) TRY(attach_colstats(p, *cs_for, cs_for->H * cs_for->W));
         if (rs) {
             if (!p.samples) p.samples = batch;
             rs->nparts = store ? gemm_rowstat_parts(p) : 0;
@@ -607,7 +645,7 @@ struct Exec {
         }
         free(rs_h.t);
         TRY(alloc(out, B, x.H, x.W, C));
-        TRY(linear(h.p, C, nullptr, 0, 0, M, C, w.pout, C, w.poutb, x.p, C, 0, out.p, C));
+        TRY(linear(h.p, C, nullptr, 0, 0, M, C, w.pout, C, w.poutb, x.p, C, 0, out.p, C, nullptr, sv ? nullptr : &out));
         if (sv) sv->hlast = h; else free(h);
         return 0;
     }
@@ -698,6 +736,7 @@ struct gyre_unet {
     UNetVjpState vjp;
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
+    int gn_unit = 0;     // gcd of block_out_channels / groups: every GroupNorm group (skip concats included) is a whole number of units
     bf16_t *te1w, *te2w; float *te1b, *te2b;
     bf16_t* tproj_w = nullptr; float* tproj_b = nullptr;
     ConvW conv_in, conv_out;
@@ -781,6 +820,12 @@ struct gyre_unet {
         if (c.cross_attention_dim % 8) GYRE_FAIL(GYRE_ERR_INVALID, "cross_attention_dim must be a multiple of 8");
         ex.groups = c.norm_num_groups;
         ex.store = &store;
+        gn_unit = 0;
+        for (int i = 0; i < n; ++i) {
+            int a = c.block_out_channels[i] / c.norm_num_groups, b = gn_unit;
+            while (b) { const int t = a % b; a = b; b = t; }
+            gn_unit = a;
+        }
         const int c0 = c.block_out_channels[0];
         temb_dim = 4 * c0;
         // total columns of the batched time_emb_proj
@@ -877,6 +922,7 @@ struct gyre_unet {
         ex.arena.reset((char*)ws, ws_bytes, dry);
         vjp.valid = false;                           // the arena is being reused: a pending reverse sweep has lost its activations
         ex.st = st; ex.batch = B;
+        ex.cs_unit = gn_unit;                        // producers leave GroupNorm statistics where they can (attach_colstats)
         Exec& e = ex;
         const int D = c.cross_attention_dim;
         const bool cached = use_ctx_cache;
@@ -931,9 +977,10 @@ struct gyre_unet {
             }
             const bool adapt_before = adapter && (c.attn_levels[i] || !down[i].has_resample);
             auto adapt = [&]() -> int {
+                Tn& s_ = skips.back();
+                s_.cs_chunks = 0;                      // updated in place: its producer's statistics no longer describe it
                 if (dry) return 0;
                 if (!adapter[i]) GYRE_FAIL(GYRE_ERR_INVALID, "unet: null adapter state");
-                const Tn& s_ = skips.back();
                 return launch_add_nchw_into_nhwc(st, adapter[i], rdt, B, s_.C, s_.H * s_.W, s_.C, s_.p);
             };
             if (adapt_before) TRY(adapt());
@@ -958,6 +1005,7 @@ struct gyre_unet {
             if (n_down_res != (int)skips.size())
                 GYRE_FAIL(GYRE_ERR_INVALID, "unet: " + std::to_string(skips.size()) + " down-block residuals expected, got " +
                           std::to_string(n_down_res));
+            for (auto& sk : skips) sk.cs_chunks = 0;   // updated in place below: the producers' statistics are stale
             if (!dry)
                 for (size_t k = 0; k < skips.size(); ++k) {
                     if (!down_res[k]) GYRE_FAIL(GYRE_ERR_INVALID, "unet: null down-block residual");
@@ -965,6 +1013,7 @@ struct gyre_unet {
                     TRY(launch_add_nchw_into_nhwc(st, down_res[k], rdt, B, sk.C, sk.H * sk.W, sk.C, sk.p));
                 }
         }
+        if (mid_res) h.cs_chunks = 0;
         if (mid_res && !dry) TRY(launch_add_nchw_into_nhwc(st, mid_res, rdt, B, h.C, h.H * h.W, h.C, h.p));
         for (int i = 0; i < n; ++i) {
             const int lvl = n - 1 - i;
@@ -1113,7 +1162,7 @@ struct gyre_vae {
         const int n = cfg.n_levels;
         if (B < 1 || H < 1 || W < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: empty input");
         if ((H % (1 << (n - 1))) || (W % (1 << (n - 1)))) GYRE_FAIL(GYRE_ERR_INVALID, "vae.encode: H, W must be multiples of 8");
-        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B; ex.cs_unit = 0;
         Exec& e = ex;
         Tn x, h;
         TRY(e.alloc(x, B, H, W, pad8(cfg.in_channels)));
@@ -1145,7 +1194,7 @@ struct gyre_vae {
                    void* out, int odt) {
         const int n = cfg.n_levels;
         if (B < 1 || h_ < 1 || w_ < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae.decode: empty input");
-        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B;
+        ex.arena.reset((char*)ws, wsb, dry); ex.st = st; ex.batch = B; ex.cs_unit = 0;
         Exec& e = ex;
         Tn x, q, h;
         const int zc = pad8(cfg.latent_channels);

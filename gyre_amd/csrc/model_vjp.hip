@@ -353,7 +353,7 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
     if (!ctx && !dry) GYRE_FAIL(GYRE_ERR_INVALID, "unet vjp: the text context must be passed (the K/V cache holds no row-major V)");
     Exec& e = u.ex;
     e.arena.reset((char*)ws, ws_bytes, dry);
-    e.st = st; e.batch = B; e.ctx_cache = nullptr; e.ctx_layer = 0;
+    e.st = st; e.batch = B; e.ctx_cache = nullptr; e.ctx_layer = 0; e.cs_unit = 0;   // the reverse sweep recomputes its own GroupNorm statistics
     const int D = c.cross_attention_dim;
     Tn xin, cx, emb, t1, t2, tp;
     TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
@@ -526,7 +526,7 @@ int gyre_vae_run_decode_vjp(gyre_vae& v, bool dry, hipStream_t st, const void* z
     const int n = c.n_levels;
     if (B < 1 || h_ < 1 || w_ < 1) GYRE_FAIL(GYRE_ERR_INVALID, "vae decode vjp: empty input");
     Exec& e = v.ex;
-    e.arena.reset((char*)ws, wsb, dry); e.st = st; e.batch = B;
+    e.arena.reset((char*)ws, wsb, dry); e.st = st; e.batch = B; e.cs_unit = 0;
     const int zc = pad8(c.latent_channels);
     struct RNode { const ResW* rw; Tn x, out; ResSave rs; };
     struct UNode { const ConvW* cw; Tn x, out; };

@@ -90,6 +90,9 @@ class GyreUnifiedPipeline:
         self._hires_oos_fraction, self._hires_image_oos_fraction = 0.6, 1.0
         self._text_embedding_layer = "final"
         self._tome = 0
+        self._shard_devices: list = []       # engine option "shard_devices": fan one request over these device slots
+        self._shard_bit_exact = False
+        self._executor = None
         self.clip_default_config = CG.ClipGuidanceConfig()
 
     # ---- what PipelineWrapper / DiffusionPipelineWrapper touch -----------------------------------------------------------
@@ -160,6 +163,16 @@ class GyreUnifiedPipeline:
                         cfg.guidance_base = str(sv)
                     else:
                         raise ValueError(f"Unknown option {sk}: {sv} passed as part of clip settings")
+            elif key == "shard_devices":
+                # Extension (north_star: "request batches shard data-parallel across the 8 GPUs of one node"): the images of
+                # ONE request are split over these devices with the reference's batched_seeds rule and run concurrently from
+                # one host thread + HIP stream per device inside this process (gyre_amd/executor.py); weights are replicated
+                # on first use.  {"devices": [...], "bit_exact": true} additionally plans split-K batch-invariantly so that
+                # the result equals the single-device run bit for bit.
+                devs = value.get("devices", []) if isinstance(value, dict) else (value or [])
+                self._shard_bit_exact = bool(value.get("bit_exact", False)) if isinstance(value, dict) else False
+                self._shard_devices = [torch.device(d if not isinstance(d, int) else f"cuda:{d}") for d in devs]
+                self._executor = None
             elif key == "grafted_depth":
                 if value:
                     raise NotImplementedError(f"option {key!r} is outside the native hot path")
@@ -334,14 +347,23 @@ class GyreUnifiedPipeline:
                 if hasattr(_b, "update"):
                     _b.update(1)
         to_dev = lambda t: None if t is None else t.to(dev)
-        images = pipe(generators=generators, text_embeddings=cond, uncond_embeddings=unc, height=height, width=width,
-                      num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                      sampler=sampler_name(self.scheduler), image=to_dev(image), mask_image=to_dev(mask_image),
-                      strength=strength, karras_rho=karras_rho, eta=eta, cfg_execution=cfg_execution, callback=cb,
-                      hires_fix=hires_fix, hires_oos_fraction=hires_oos_fraction, outmask_image=to_dev(outmask_image),
-                      prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
-                      churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
-                      sigma_max=sigma_max, **clip_kw)
+        request = dict(generators=generators, text_embeddings=cond, uncond_embeddings=unc, height=height, width=width,
+                       num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                       sampler=sampler_name(self.scheduler), image=to_dev(image), mask_image=to_dev(mask_image),
+                       strength=strength, karras_rho=karras_rho, eta=eta, cfg_execution=cfg_execution,
+                       hires_fix=hires_fix, hires_oos_fraction=hires_oos_fraction,
+                       prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
+                       churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
+                       sigma_max=sigma_max, **clip_kw)
+        if len(self._shard_devices) > 1 and B > 1 and not clip_kw and not lora and not self._tome:
+            # one request over several device slots (engine option "shard_devices"); progress / cancellation are polled once
+            # per request here: the replicas run their loops concurrently and a per-step callback has no single owner.
+            # (CLIP guidance couples the batch through its flat-loss stop; per-request LoRA / ToMe patch one
+            # UNet object - such requests run on this slot alone)
+            images = self._sharded(pipe, request, outmask_image=to_dev(outmask_image), image=to_dev(image))
+            cb({"i": num_inference_steps - 1})
+        else:
+            images = pipe(callback=cb, outmask_image=to_dev(outmask_image), **request)
         images = images.float().cpu()                       # reference: result_image.cpu() ... BCHW 0..1 (:2512-2531)
         images, nsfw = self._safety_check(images, run_safety_checker)
         if output_type == "pil":
@@ -352,6 +374,26 @@ class GyreUnifiedPipeline:
             return images, nsfw
         from types import SimpleNamespace
         return SimpleNamespace(images=images, nsfw_content_detected=nsfw)
+
+    def _sharded(self, pipe, request, outmask_image=None, image=None):
+        from . import images as I
+        from .executor import DeviceSlotExecutor
+        if self._executor is None or self._executor.pipelines[0].unet is not self.unet:
+            pipe0 = GyrePipeline(self.unet, self.vae, None, device=self.execution_device, inpaint_unet=self.inpaint_unet,
+                                 grafted_inpaint=self._grafted_inpaint)
+            self._executor = DeviceSlotExecutor.replicate(pipe0, self._shard_devices)
+        ex = self._executor
+        for rep in ex.pipelines:                 # per-request engine settings follow the replicas
+            rep.grafted_inpaint = self._grafted_inpaint
+            rep.hires_fix, rep.hires_threshold_fraction = pipe.hires_fix, pipe.hires_threshold_fraction
+            rep.hires_oos_fraction, rep.hires_image_oos_fraction = pipe.hires_oos_fraction, pipe.hires_image_oos_fraction
+        latents = ex(bit_exact=self._shard_bit_exact, **request)
+        result = ex.decode(latents)
+        if image is not None and outmask_image is not None:         # unified_pipeline.py:2493-2510
+            src = image if image.ndim == 4 else image[None]
+            om = outmask_image if outmask_image.ndim == 4 else outmask_image[None]
+            result = I.outmask_composite(result, src.to(result.device), om.to(result.device))
+        return result
 
     @staticmethod
     def numpy_to_pil(images):

@@ -96,6 +96,21 @@ class _NativeModule(nn.Module):
         except Exception:
             pass
 
+    _NATIVE_STATE = ("_handle", "_handle_device", "_ws", "_ws_vjp", "_ctx_slots", "_vjp_pending")
+
+    def __deepcopy__(self, memo):
+        """A copy gets its OWN native handle (created at first use): the reference clones modules with ``deepcopy`` - per
+        device slot in ``clone_model`` (gyre/pipeline/model_utils.py:172-217) - and two Python objects sharing one
+        ``gyre_unet*`` would free it twice and race on its workspace planner."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._NATIVE_STATE:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._handle, new._handle_device, new._ws, new._ctx_slots, new._dirty = None, None, None, [], True
+        return new
+
     def _c_cfg(self):
         raise NotImplementedError
 

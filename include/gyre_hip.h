@@ -239,7 +239,8 @@ int gyre_debug_force_attn_variant(int v);
  * bit2 = no epilogue.  Planner switches for same-box A/B runs (results stay valid): bit8 = default tile order, bit9 = conv
  * zero padding from a zero page in the pipelined kernel, bit10 = no pipelined (32x32x16) tile configs, bit11 = LayerNorm as a
  * separate pass (no fold into the consuming GEMM), bit15 = folded LayerNorm takes its row statistics from a separate pass
- * instead of the producing GEMM's epilogue, bit16 = the GEGLU FF1 keeps its separate LayerNorm. */
+ * instead of the producing GEMM's epilogue, bit16 = the GEGLU FF1 keeps its separate LayerNorm, bit17 = GroupNorm keeps its own
+ * statistics pass (no statistics from the producing conv / GEMM). */
 int gyre_debug_gemm_ablation(int bits);
 
 /* ---- batch-invariant mode ------------------------------------------------
@@ -262,6 +263,24 @@ int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B
                       const float* gamma, const float* beta, float eps, int silu,
                       void* workspace, size_t workspace_bytes, void* y);
 size_t gyre_op_groupnorm_workspace(int B, int HW, int C, int groups);
+/* GroupNorm statistics from the PRODUCER of a tensor.  On the UNet's large feature maps the kernels that write a tensor a
+ * GroupNorm will read (3x3 convs incl. their split-K reduction, the transformer's proj_out) also leave, per block of `rows`
+ * consecutive output rows and per `unit` of consecutive channels, the sum and the sum of squares of the bf16 values they
+ * stored: stats_out [M / rows][N / unit][2] f32, fixed summation order, no atomics.  rows is dictated by the kernel the
+ * planner picks (returned through rows_out; GYRE_ERR_UNSUPPORTED when that kernel cannot: then the consumer runs its own
+ * statistics pass); unit divides every GroupNorm group that will read the tensor - alone or as part of a skip concat.
+ * gyre_op_groupnorm_colstats is the consumer: no statistics pass, mean / rstd are finished from the partials of x (and x2) in
+ * the prologue of the one launch that normalises.  workspace of the producers: gyre_op_gemm_splitk_bytes (0 = none). */
+size_t gyre_op_gemm_splitk_bytes(int conv, int M, int N, int K, int B);
+int gyre_op_conv3x3_colstats(void* stream, const void* x, int B, int Hi, int Wi, int Cin, const void* w_repacked, int Cout,
+                             const float* bias, const void* residual, int stride, int ups, int unit, void* y, float* stats_out,
+                             size_t stats_bytes, void* workspace, size_t workspace_bytes, int* rows_out);
+int gyre_op_linear_colstats(void* stream, const void* x, int M, int K, const void* w_bf16_rowmajor, int N, const float* bias,
+                            const void* residual, int rows_per_sample, int unit, void* y, float* stats_out, size_t stats_bytes,
+                            void* workspace, size_t workspace_bytes, int* rows_out);
+int gyre_op_groupnorm_colstats(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
+                               const float* gamma, const float* beta, float eps, int silu, const float* cs_x, int cs_x_chunks,
+                               const float* cs_x2, int cs_x2_chunks, int unit, void* workspace, size_t workspace_bytes, void* y);
 int gyre_op_layernorm(void* stream, const void* x, int M, int C, const float* gamma, const float* beta,
                       float eps, void* y);
 /* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (+residual); geglu!=0: w holds [2N,K], y = val*gelu(gate) */

@@ -883,3 +883,164 @@ def test_tome_rejects_bad_arguments():
     assert L.gyre_op_tome_merge(st(), vp(x), 36, vp(x), 36, 1, 64, 36, 8, vp(ws), ws.numel(), vp(out), vp(out), 64, None, None) == -1   # C % 8
     x = torch.zeros(1, 64, 64, dtype=torch.bfloat16, device=DEV)
     assert L.gyre_op_tome_merge(st(), vp(x), 64, vp(x), 64, 1, 64, 64, 8, vp(ws), 16, vp(out), vp(out), 64, None, None) == -4         # workspace
+
+
+# ---- GroupNorm statistics from the producing kernel (GemmParams::colstat_out) -------------------------------------------------
+def _colstats_ref(y_nhwc, B, rows, unit):
+    """[B * HW / rows][C / unit][2] sums / sums of squares of the stored bf16 values, in float64."""
+    C = y_nhwc.shape[-1]
+    t = y_nhwc.double().reshape(-1, rows, C // unit, unit)
+    return torch.stack([t.sum(dim=(1, 3)), (t * t).sum(dim=(1, 3))], dim=-1)
+
+
+def _check_colstats(name, stats, y, B, rows, unit):
+    ref = _colstats_ref(y.float().cpu().reshape(-1, y.shape[-1]), B, rows, unit)
+    got = stats.double().cpu().reshape(ref.shape)
+    scale = ref[..., 1].sqrt().mean() * math.sqrt(rows * unit)          # typical magnitude of a sum of rows*unit values
+    e_sum = float((got[..., 0] - ref[..., 0]).abs().max() / scale)
+    e_sq = float(((got[..., 1] - ref[..., 1]).abs() / ref[..., 1].clamp_min(1e-30)).max())
+    print(f"[parity] {name}: column statistics vs float64 sums of the stored values: sum err {e_sum:.2e} (of a typical sum), "
+          f"sumsq rel err {e_sq:.2e}, row block {rows}")
+    assert e_sum < 1e-4 and e_sq < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,res,want_rows", [
+    (16, 64, 64, 320, 320, 1, 0, True, 256),      # pipelined 256x320 tile, unsplit (64x64 level resnet convs)
+    (2, 64, 64, 8, 320, 1, 0, False, 0),          # conv_in-like (K = 72): whatever the planner picks, or unsupported
+    (16, 32, 32, 640, 640, 1, 0, True, 16),       # split K: statistics from the reduction kernel
+    (16, 64, 64, 320, 320, 2, 0, False, 0),       # downsample conv -> 32x32
+    (16, 32, 32, 640, 640, 1, 1, False, 256),     # upsample conv -> 64x64
+    (16, 32, 32, 1920, 640, 1, 0, True, 0),
+])
+def test_conv_emits_groupnorm_statistics(B, H, W, Cin, Cout, stride, ups, res, want_rows):
+    import ctypes as C
+    L = _lib.lib()
+    unit = 10
+    x = bf16_round(randn(B, Cin, H, W, seed=61) + 0.3)
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=62) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=63)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    ref = F.conv2d(xi, w, b, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = bf16_round(randn(B, Cout, Ho, Wo, seed=64)) if res else None
+    if res:
+        ref = ref + r
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    stats = torch.full((B * Ho * Wo // 16, Cout // unit, 2), float("nan"), dtype=torch.float32, device=DEV)
+    need = L.gyre_op_gemm_splitk_bytes(1, B * Ho * Wo, Cout, 9 * Cin, B)
+    ws = torch.empty(max(need, 16) + 256, dtype=torch.uint8, device=DEV)
+    rows = C.c_int(0)
+    args = (st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+            vp(to_dev_bf16(nhwc(r))) if res else None, stride, ups, unit, vp(y), vp(stats), stats.numel() * 4, vp(ws), ws.numel(),
+            C.byref(rows))
+    rc = L.gyre_op_conv3x3_colstats(*args)
+    if rc == -6 and want_rows == 0:
+        assert rows.value <= 0
+        pytest.skip("planner's kernel for this shape emits no column statistics: the consumer keeps its own pass")
+    _lib.check(rc)
+    if want_rows:
+        assert rows.value == want_rows
+    name = f"conv {B}x{H}x{W} {Cin}->{Cout} s{stride} ups{ups}"
+    report(name, y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+    nblk = B * Ho * Wo // rows.value
+    _check_colstats(name, stats[:nblk], y, B, rows.value, unit)
+    # the same launch without statistics stores the same bits; repeated launches are deterministic
+    y2 = torch.empty_like(y)
+    L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
+    try:
+        _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
+                                     vp(to_dev_bf16(nhwc(r))) if res else None, stride, ups, 0, vp(y2)))
+    finally:
+        L.gyre_debug_set_splitk_workspace(None, 0)
+    assert torch.equal(y, y2)
+    s1 = stats[:nblk].clone()
+    _lib.check(L.gyre_op_conv3x3_colstats(*args))
+    assert torch.equal(stats[:nblk], s1)
+
+
+@pytest.mark.parametrize("B,HW,C,res", [(16, 4096, 320, True), (16, 1024, 640, True), (2, 4096, 320, True), (3, 1024, 1280, False)])
+def test_linear_emits_groupnorm_statistics(B, HW, C, res):
+    """The transformer's proj_out (+ residual) feeds the next resnet's GroupNorm."""
+    import ctypes as Ct
+    L = _lib.lib()
+    unit, M = 10, B * HW
+    x = bf16_round(randn(M, C, seed=71))
+    w = bf16_round(randn(C, C, seed=72) / math.sqrt(C))
+    b = randn(C, seed=73)
+    r = bf16_round(randn(M, C, seed=74) * 2 + 0.5) if res else None
+    ref = F.linear(x, w, b) + (r if res else 0)
+    y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.full((M // 16, C // unit, 2), float("nan"), dtype=torch.float32, device=DEV)
+    rows = Ct.c_int(0)
+    rc = L.gyre_op_linear_colstats(st(), vp(to_dev_bf16(x)), M, C, vp(to_dev_bf16(w)), C, vp(b.to(DEV)),
+                                   vp(to_dev_bf16(r)) if res else None, HW, unit, vp(y), vp(stats), stats.numel() * 4, None, 0,
+                                   Ct.byref(rows))
+    if rc == -6:
+        pytest.skip("planner's kernel for this shape emits no column statistics")
+    _lib.check(rc)
+    assert rows.value in (128, 256) and HW % rows.value == 0
+    report(f"linear {M}x{C}x{C}", y.float().cpu(), ref, TOL)
+    _check_colstats(f"linear {M}x{C}x{C}", stats[:M // rows.value], y, B, rows.value, unit)
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,silu", [(2, 64, 64, 320, 0, 1), (16, 32, 32, 640, 0, 0), (2, 32, 32, 1280, 640, 1),
+                                              (2, 64, 64, 640, 320, 1), (2, 64, 64, 320, 320, 1)])
+def test_groupnorm_from_producer_statistics(B, H, W, C1, C2, silu):
+    """Consumer side: mean / rstd finished from per-(row block, 10-channel unit) partials of x (and of the skip tensor x2, whose
+    row blocks may differ: 256-row tiles vs the 16-row blocks of a split-K reduction) equal the kernel's own statistics pass."""
+    L = _lib.lib()
+    unit, HW, C = 10, H * W, C1 + C2
+    x = bf16_round(randn(B, C, H, W, seed=81) * 1.5 + 0.7)
+    gamma, beta = randn(C, seed=82) * 0.2 + 1.0, randn(C, seed=83) * 0.3
+    ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    xn = nhwc(x)
+    a = to_dev_bf16(xn[..., :C1])
+    b = to_dev_bf16(xn[..., C1:]) if C2 else None
+    rows_a, rows_b = 256, 16
+    cs_a = _colstats_ref(xn[..., :C1].reshape(-1, C1), B, rows_a, unit).float().to(DEV).contiguous()
+    cs_b = _colstats_ref(xn[..., C1:].reshape(-1, C2), B, rows_b, unit).float().to(DEV).contiguous() if C2 else None
+    ws = torch.empty(L.gyre_op_groupnorm_workspace(B, HW, C, 32) + 256, dtype=torch.uint8, device=DEV)
+    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.gyre_op_groupnorm_colstats(st(), vp(a), vp(b), C1, B, HW, C, 32, vp(gamma.to(DEV)), vp(beta.to(DEV)), 1e-5, silu,
+                                            vp(cs_a), HW // rows_a, vp(cs_b), HW // rows_b if C2 else 0, unit, vp(ws), ws.numel(), vp(y)))
+    report(f"groupnorm from producer statistics {B}x{H}x{W} {C1}+{C2}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+    y0 = torch.empty_like(y)
+    _lib.check(L.gyre_op_groupnorm(st(), vp(a), vp(b), C1, B, HW, C, 32, vp(gamma.to(DEV)), vp(beta.to(DEV)), 1e-5, silu, vp(ws),
+                                   ws.numel(), vp(y0)))
+    d = rel_l2(y.float(), y0.float())
+    print(f"[property] vs the kernel's own statistics pass: rel-L2 {d:.2e}")
+    assert d < 1e-3
+
+
+def test_unet_with_and_without_producer_statistics_full_size():
+    """SD1.5 UNet, 64x64 latents: GroupNorm statistics from the producing conv / GEMM epilogues (default) against the separate
+    statistics pass (tuning bit 17) - same network, two summation orders of the same sums; fewer launches."""
+    from gyre_amd import config as gcfg, weights
+    from gyre_amd.modules import GyreHipUNet
+    L = _lib.lib()
+    cfg = gcfg.sd15_unet()
+    net = GyreHipUNet(cfg)
+    net.load_state_dict(weights.synthetic_state_dict(weights.unet_param_shapes(cfg)))
+    net = net.to(torch.bfloat16).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 64, 64, generator=g).to(DEV)
+    ctx = torch.randn(2, 77, 768, generator=g).to(DEV)
+    t = torch.tensor([981, 20], device=DEV)
+    a = net(x, t, encoder_hidden_states=ctx).sample          # (first call: also projects the text context)
+    a2 = net(x, t, encoder_hidden_states=ctx).sample
+    n_a = L.gyre_last_launch_count()
+    assert torch.equal(a, a2)
+    old = L.gyre_debug_gemm_ablation(0x20000)
+    try:
+        b = net(x, t, encoder_hidden_states=ctx).sample
+        n_b = L.gyre_last_launch_count()
+    finally:
+        L.gyre_debug_gemm_ablation(old)
+    d = rel_l2(a.float(), b.float())
+    print(f"[property] UNet eps with producer statistics vs separate passes: rel-L2 {d:.2e}; launches {n_a} vs {n_b}")
+    assert d < 1.5e-2 and n_a < n_b
+    # batch equivariance survives: permuting the samples permutes the result bit-exactly
+    p = net(x.flip(0).contiguous(), t.flip(0).contiguous(), encoder_hidden_states=ctx.flip(0).contiguous()).sample
+    assert torch.equal(p.flip(0), a)
