@@ -239,10 +239,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up.  The last warm-up step runs with every MFMA kernel family instrumented to find the DOMINANT class; the timed
+    # region then carries HIP events around that class's launches only (events around all ~16 k launches of a step cost ~7 %:
+    # 0.99 s vs 1.07 s per request on the same box - that overhead belongs to the measurement, not to `value`).
+    dom_prefix = None
     for i in range(args.warmup):
+        last = i == args.warmup - 1
+        if last and not args.profile_all:
+            _lib.prof_enable(CANDIDATES)
         step(-1 - i)
+        if last and not args.profile_all:
+            torch.cuda.synchronize()
+            pre = {k: v for k, v in _lib.prof_collect().items() if any(k.startswith(c) for c in CANDIDATES)}
+            _lib.prof_enable([])
+            if pre:
+                dom_prefix = max(pre, key=lambda k: pre[k]["ms"])
     barrier()
-    _lib.prof_enable(None if args.profile_all else CANDIDATES)
+    _lib.prof_enable(None if args.profile_all else ([dom_prefix] if dom_prefix else CANDIDATES))
     step_times = []
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -200,6 +200,11 @@ int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const i
     g_launches = 0;
     return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr);
 }
+int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    h->hint_uniform_t = on != 0;
+    return 0;
+}
 int gyre_unet_forward_ctrl(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                            int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add,
                            const void* const* down_res, int n_down_res, int rdt, const void* mid_res,

@@ -736,6 +736,7 @@ struct gyre_unet {
     UNetVjpState vjp;
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
+    bool hint_uniform_t = false;   // gyre_unet_hint_uniform_timestep: consumed by the next forward
     int gn_unit = 0;     // gcd of block_out_channels / groups: every GroupNorm group (skip concats included) is a whole number of units
     bf16_t *te1w, *te2w; float *te1b, *te2b;
     bf16_t* tproj_w = nullptr; float* tproj_b = nullptr;
@@ -930,6 +931,12 @@ struct gyre_unet {
             GYRE_FAIL(GYRE_ERR_INVALID, "unet: ctx == NULL needs a gyre_unet_set_context call with the same B and S");
         e.ctx_cache = cached ? &cur().kv : nullptr;
         e.ctx_layer = 0;
+        // Every sample at the same timestep (what the samplers pass: one scalar per call) and no per-sample added
+        // conditioning: the time-embedding MLP and the batched time_emb_proj run for ONE row and every resnet reads it with a
+        // zero row stride (GemmParams::ld_rowbias) - same arithmetic per row, bit-identical results, 1/B of the work.
+        const bool uni_t = hint_uniform_t && !temb_add;
+        hint_uniform_t = false;
+        const int Bt = uni_t ? 1 : B, ld_tp = uni_t ? 0 : temb_cols;
         Tn xin, cx, emb, t1, t2, tp;
         TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
         if (!cached) TRY(e.alloc(cx, B, S, 1, D));
@@ -940,13 +947,13 @@ struct gyre_unet {
         if (!dry) {
             TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
             if (!cached) TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
-            TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
-            TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
-            TRY(launch_rowvec_linear(st, (float*)t1.p, B, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
+            TRY(launch_timestep_embedding(st, t, Bt, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
+            TRY(launch_rowvec_linear(st, (float*)emb.p, Bt, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
+            TRY(launch_rowvec_linear(st, (float*)t1.p, Bt, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
             // SDXL-style added conditioning (text_time): emb = time_embedding(t) + aug_emb, aug_emb from the host
             if (temb_add) TRY(launch_add_f32(st, (float*)t2.p, temb_add, (size_t)B * temb_dim));
             // every resnet's Linear(SiLU(temb)) in one launch
-            TRY(launch_rowvec_linear(st, (float*)t2.p, B, temb_dim, tproj_w, tproj_b, temb_cols, 1, (float*)tp.p, temb_cols));
+            TRY(launch_rowvec_linear(st, (float*)t2.p, Bt, temb_dim, tproj_w, tproj_b, temb_cols, 1, (float*)tp.p, temb_cols));
         }
         e.free(emb); e.free(t1); e.free(t2);
         const float* tproj = (const float*)tp.p;
@@ -967,7 +974,7 @@ struct gyre_unet {
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < c.layers_per_block; ++j) {
                 Tn r;
-                TRY(e.resnet(skips.back(), nullptr, down[i].res[j], tproj, temb_cols, 1e-5f, r));
+                TRY(e.resnet(skips.back(), nullptr, down[i].res[j], tproj, ld_tp, 1e-5f, r));
                 if (c.attn_levels[i]) {
                     Tn a;
                     TRY(e.transformer(r, cx, S, D, down[i].attn[j], a));
@@ -994,10 +1001,10 @@ struct gyre_unet {
         }
         {
             Tn a, b2;
-            TRY(e.resnet(skips.back(), nullptr, mid0, tproj, temb_cols, 1e-5f, a));
+            TRY(e.resnet(skips.back(), nullptr, mid0, tproj, ld_tp, 1e-5f, a));
             TRY(e.transformer(a, cx, S, D, mid_attn, b2));
             e.free(a);
-            TRY(e.resnet(b2, nullptr, mid1, tproj, temb_cols, 1e-5f, h));
+            TRY(e.resnet(b2, nullptr, mid1, tproj, ld_tp, 1e-5f, h));
             e.free(b2);
             TRY(tap("mid", h, c.block_out_channels[n - 1]));
         }
@@ -1020,7 +1027,7 @@ struct gyre_unet {
             for (int j = 0; j < c.layers_per_block + 1; ++j) {
                 Tn sk = skips.back(); skips.pop_back();
                 Tn r;
-                TRY(e.resnet(h, &sk, up[i].res[j], tproj, temb_cols, 1e-5f, r));
+                TRY(e.resnet(h, &sk, up[i].res[j], tproj, ld_tp, 1e-5f, r));
                 e.free(h); e.free(sk);
                 if (c.attn_levels[lvl]) {
                     Tn a;

@@ -72,6 +72,13 @@ class DeviceSlotExecutor:
         bounds = shard_bounds(n_items, self.world)
         out: List[Optional[torch.Tensor]] = [None] * self.world
         errs: List[BaseException] = []
+        # work the caller already queued on a device (e.g. a previous request on the same replica) must finish before a worker
+        # stream touches that replica's workspace: every worker stream first waits for the caller's current stream there
+        ahead = {}
+        for pl in self.pipelines:
+            d = torch.device(pl.device)
+            if d.type == "cuda" and d not in ahead:
+                ahead[d] = torch.cuda.current_stream(d)
 
         def run(r, s, e):
             try:
@@ -79,6 +86,7 @@ class DeviceSlotExecutor:
                 if dev.type == "cuda":
                     torch.cuda.set_device(dev)
                     stream = torch.cuda.Stream(device=dev)
+                    stream.wait_stream(ahead[dev])
                     with torch.cuda.stream(stream):
                         out[r] = work(r, s, e)
                     stream.synchronize()

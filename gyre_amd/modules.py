@@ -320,6 +320,7 @@ class GyreHipUNet(_NativeModule):
         if getattr(self, "_tome_applied", (None, None)) != (h, getattr(self, "_tome_r", 0)):
             _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
             self._tome_applied = (h, getattr(self, "_tome_r", 0))
+        self._t_uniform = not isinstance(timestep, torch.Tensor) or timestep.numel() == 1
         if isinstance(timestep, torch.Tensor):
             t = timestep.to(dev).to(torch.int64).reshape(-1)
             if t.numel() == 1:
@@ -404,6 +405,8 @@ class GyreHipUNet(_NativeModule):
             out = torch.empty((B, self.config.out_channels, H, W), dtype=sample.dtype, device=dev)
             aug = self._aug_embedding(added_cond_kwargs, B, dev)
             augp = C.c_void_p(aug.data_ptr()) if aug is not None else None
+            # one timestep for the whole batch (a scalar was passed): always stated explicitly, a stale hint never survives
+            _lib.check(L.gyre_unet_hint_uniform_timestep(C.c_void_p(h), 1 if getattr(self, "_t_uniform", False) else 0))
             if residuals is None:
                 _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
                                                   _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None,

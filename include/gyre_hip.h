@@ -122,6 +122,12 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
                       void* workspace, size_t workspace_bytes,
                       void* eps_out_nchw, int out_dtype);
 
+/* Hint for the NEXT gyre_unet_forward* call on this handle only: all B entries of t_dev hold the same value (the samplers
+ * of the reference pass ONE timestep per call: common_scheduler.py:344 / k-diffusion's sigma_to_t).  The time-embedding MLP and
+ * the batched time_emb_proj then run for one row that every resnet reads - 1/B of that work, bit-identical results.  Ignored
+ * when per-sample added conditioning (temb_add) is given.  A wrong hint gives every sample the first sample's timestep. */
+int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on);
+
 /* Text-context cache.  The context is constant over the 50+ UNet evaluations of a request, so its cross-attention
  * K / V projections (32 small GEMMs per call for SD1.x) can be done once: set_context projects ctx[B,S,cross_dim]
  * through every attn2.to_k / to_v into handle-owned buffers (may (re)allocate: not for the per-step path); afterwards

@@ -206,6 +206,22 @@ def test_context_cache_matches_uncached_and_tracks_changes():
     assert rc == -1 and b"set_context" in L.gyre_last_error()
 
 
+def test_uniform_timestep_fast_path_is_bit_identical():
+    """A scalar timestep (what the samplers pass) lets the time-embedding MLP run for one row that every resnet reads
+    (gyre_unet_hint_uniform_timestep): same bits as the per-sample tensor form, at full size and at a ragged batch."""
+    for cfg, B, hw in ((gcfg.tiny_unet(), 3, 16), (gcfg.sd15_unet(), 4, 32)):
+        net, _ = make_unet(cfg)
+        x = randn(B, 4, hw, hw, seed=31).to(DEV)
+        ctx = randn(B, 77, cfg.cross_attention_dim, seed=32).to(DEV)
+        a = net(x, 637, encoder_hidden_states=ctx).sample
+        b = net(x, torch.full((B,), 637, device=DEV), encoder_hidden_states=ctx).sample
+        c = net(x, torch.tensor(637), encoder_hidden_states=ctx).sample
+        assert torch.equal(a, b) and torch.equal(a, c)
+        t2 = torch.tensor([637] * (B - 1) + [12], device=DEV)          # per-sample timesteps still honoured
+        d = net(x, t2, encoder_hidden_states=ctx).sample
+        assert torch.equal(d[:B - 1], a[:B - 1]) and not torch.equal(d[B - 1], a[B - 1])
+
+
 def test_context_cache_holds_alternating_contexts():
     """GYRE_CTX_SLOTS entries: hires-fix leaves / CFGUNet_Sequential (reference unet/cfg.py:27-38,
     unet/hires_fix.py:123-235) alternate between contexts on every call - no re-projection after the first round, results
