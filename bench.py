@@ -392,10 +392,24 @@ def main():
         }
         out.update(latency)
         if per_img:
-            out["step_mfma_frac"] = round(sum(sizes) * per_img / (elapsed / args.steps) / MFMA_PEAK_TFLOPS / world, 4)
-            out["step_mfma_frac_note"] = ("algorithmic 0.803 TFLOP per UNet sample-forward x all evaluations; the cross-attention K/V "
-                                          "projections of the text context run once per request (context cache), i.e. <0.5 % of "
-                                          "the counted FLOPs are not executed on 50 of the 51 evaluations")
+            # CFG-parallel calls share the part of the network in front of the first cross-attention between the two halves of
+            # the batch (gyre_unet_hint_cfg_pairs): conv_in, the first resnet, proj_in, Q|K|V, the 64x64 self-attention and its
+            # to_out = 655.3 of the 12 848 GFLOP of a batch-16 evaluation, executed once per pair -> 2.55 % of the reference
+            # formulation's FLOPs are not executed.  step_mfma_frac counts EXECUTED FLOPs only.
+            shared = args.config == "sd15" and os.environ.get("GYRE_CFG_SHARED_PREFIX", "1") != "0"
+            executed = 1.0 - (0.0255 if shared else 0.0)
+            alg = sum(sizes) * per_img / (elapsed / args.steps) / MFMA_PEAK_TFLOPS / world
+            unet_part = evals * 2 * UNET_TFLOP_PER_SAMPLE * (size / 512) ** 2 / per_img
+            out["step_mfma_frac"] = round(alg * (1.0 - unet_part * (1.0 - executed)), 4)
+            out["step_mfma_frac_reference_formulation"] = round(alg, 4)
+            out["cfg_shared_prefix"] = shared
+            out["step_mfma_frac_note"] = ("EXECUTED FLOPs / time / 2.5 PFLOP/s: algorithmic 0.803 TFLOP per UNet sample-forward x all "
+                                          "evaluations, minus what the two halves of every CFG-parallel call share (everything in front "
+                                          "of the first cross-attention is evaluated once per (uncond, cond) pair: 2.55 % of a call; "
+                                          "bit-level equivalent, GYRE_CFG_SHARED_PREFIX=0 turns it off; "
+                                          "step_mfma_frac_reference_formulation counts those FLOPs as if executed twice); the "
+                                          "cross-attention K/V projections of the text context run once per request (context cache: "
+                                          "<0.5 % of the counted FLOPs are not executed on 50 of the 51 evaluations)")
         if classes:
             tot = sum(v["ms"] for v in classes.values())
             table = {}

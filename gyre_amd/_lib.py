@@ -55,6 +55,7 @@ _SIGS = {
     "gyre_unet_set_context_slot": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "gyre_unet_select_context": (_i, [_vp, _i]),
     "gyre_unet_hint_uniform_timestep": (_i, [_vp, _i]),
+    "gyre_unet_hint_cfg_pairs": (_i, [_vp, _i]),
     "gyre_unet_set_tome": (_i, [_vp, _i]),
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),

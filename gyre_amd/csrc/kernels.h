@@ -7,6 +7,8 @@
 int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
 int launch_add_nchw_into_nhwc(hipStream_t st, const void* r, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
 int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_t* y);
+// dst[o][0:inner] = dst[o][inner:2*inner] = src[o][0:inner] (bytes, multiples of 16), o < outer
+int launch_dup_batch(hipStream_t st, const void* src, void* dst, size_t outer, size_t inner_bytes);
 int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n);
 int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);
 // out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]; x f32 [B][K], W bf16 [N][K], out f32 [B][ldo].  act_in_silu: f = SiLU,

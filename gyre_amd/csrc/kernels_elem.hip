@@ -72,6 +72,25 @@ int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, 
     return 0;
 }
 
+// dst[o][0 : inner] = dst[o][inner : 2 inner] = src[o][0 : inner] for o < outer (inner in 16-byte vectors): a half batch
+// written twice - the two halves of a CFG-parallel call share every activation up to the first cross-attention
+__global__ __launch_bounds__(256) void k_dup_batch(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t inner, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t o = i / inner, r = i - o * inner;
+    const uint4 v = src[i];
+    dst[o * 2 * inner + r] = v;
+    dst[o * 2 * inner + inner + r] = v;
+}
+int launch_dup_batch(hipStream_t st, const void* src, void* dst, size_t outer, size_t inner_bytes) {
+    if (inner_bytes % 16 || ((size_t)src | (size_t)dst) % 16) GYRE_FAIL(-1, "dup_batch: 16-byte granularity");
+    const size_t inner = inner_bytes / 16, total = outer * inner;
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_dup_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, inner, total);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void k_cast_to_bf16(const void* __restrict__ x, int dtype, size_t n, bf16_t* __restrict__ y) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = f32_to_bf16(load_as_f32(x, dtype, i));

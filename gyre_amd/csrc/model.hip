@@ -92,12 +92,17 @@ int gyre_unet_finalize(gyre_unet* h, void* st) {
 }
 size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     if (!h) return 0;
-    if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0)) return 0;
-    size_t peak = h->ex.arena.peak;
-    if (h->cur().valid && h->cur().B == B && h->cur().S == S) {   // cached-context path allocates a subset; take the max
-        if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0, nullptr, true)) return 0;
-        peak = std::max(peak, h->ex.arena.peak);
-    }
+    // the maximum over the forms a forward of this shape can take: text context passed or cached, CFG halves sharing their
+    // prefix or not (gyre_unet_hint_cfg_pairs) - the hints arrive after the caller sized its workspace
+    size_t peak = 0;
+    const bool cached_too = h->cur().valid && h->cur().B == B && h->cur().S == S;
+    for (int cached = 0; cached <= (cached_too ? 1 : 0); ++cached)
+        for (int pairs = 0; pairs <= 1; ++pairs) {
+            if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0, nullptr, cached != 0, nullptr, 0, 0,
+                       nullptr, nullptr, 0, pairs))
+                return 0;
+            peak = std::max(peak, h->ex.arena.peak);
+        }
     return peak;
 }
 int gyre_unet_set_tome(gyre_unet* h, int r) {
@@ -199,6 +204,11 @@ int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const i
     if (xdt < 0 || xdt > 2 || cdt < 0 || cdt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
     return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr);
+}
+int gyre_unet_hint_cfg_pairs(gyre_unet* h, int on) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    h->hint_cfg_pairs = on != 0;
+    return 0;
 }
 int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on) {
     if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");

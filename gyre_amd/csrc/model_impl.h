@@ -299,6 +299,21 @@ struct Exec {
         return 0;
     }
 
+    // y = x written twice along the batch axis (B -> 2B); the producer's GroupNorm statistics follow (they are per sample)
+    int dup_batch(const Tn& x, Tn& y) {
+        TRY(alloc(y, 2 * x.B, x.H, x.W, x.C));
+        if (x.cs_chunks > 0) {
+            y.cs_chunks = x.cs_chunks; y.cs_unit = x.cs_unit; y.cs_bytes = 2 * x.cs_bytes;
+            y.cs_off = arena.alloc(y.cs_bytes);
+            if (y.cs_off == (size_t)-1 || (!arena.dry && y.cs_off + y.cs_bytes > arena.cap))
+                GYRE_FAIL(GYRE_ERR_WORKSPACE, "workspace too small (GroupNorm statistics)");
+            y.cs = arena.dry ? nullptr : (float*)(arena.base + y.cs_off);
+        }
+        if (dry()) return 0;
+        TRY(launch_dup_batch(st, x.p, y.p, 1, x.bytes));
+        if (x.cs_chunks > 0) TRY(launch_dup_batch(st, x.cs, y.cs, 1, x.cs_bytes));
+        return 0;
+    }
     // GroupNorm (+SiLU) of x (optionally concatenated with x2 along C)
     int groupnorm(const Tn& x, const Tn* x2, const float* g, const float* b, float eps, int silu, Tn& y) {
         int C = x.C + (x2 ? x2->C : 0);
@@ -589,8 +604,15 @@ struct Exec {
         free(b); free(sc);
         return 0;
     }
-    int transformer(const Tn& x, const Tn& ctx, int S, int ctx_dim, const TransW& w, Tn& out, TransSave* sv = nullptr) {
-        const int B = x.B, M = x.rows(), C = w.c;
+    // x_full != nullptr (inference only): x holds HALF the batch - the two halves of a CFG-parallel call are identical up
+    // to the first cross-attention (reference unet/cfg.py:49-57: cat[x, x] against cat[uncond, cond]) - so GroupNorm, proj_in
+    // and the first block's self-attention run once per pair; their result, the block input and its row statistics are then
+    // written twice along the batch axis (*x_full = the doubled x, the residual of proj_out) and the rest runs on 2B samples.
+    int transformer(const Tn& x_in, const Tn& ctx, int S, int ctx_dim, const TransW& w, Tn& out, TransSave* sv = nullptr,
+                    Tn* x_full = nullptr) {
+        int B = x_in.B, M = x_in.rows();
+        const int C = w.c;
+        Tn x = x_in;
         Tn a, h;
         TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
         TRY(alloc(h, B, x.H, x.W, C));
@@ -610,6 +632,20 @@ struct Exec {
                 const LnFold l1{bw.ln1g, bw.ln1b, &rs_h};
                 TRY(mha(h, false, nullptr, 0, 0, bw.a1, h, h2, nullptr, &l1, &rs1));
                 free(rs_h.t); rs_h.nparts = 0; free(h); h = h2;
+                if (x_full && bi == 0) {         // end of the part the CFG halves share: double the batch
+                    Tn hd;
+                    TRY(dup_batch(h, hd));
+                    free(h); h = hd;
+                    if (rs1.nparts > 0) {        // [nparts][M][2] floats -> [nparts][2M][2]
+                        Tn rd;
+                        TRY(alloc_raw(rd, 2 * rs1.t.bytes));
+                        if (!dry()) TRY(launch_dup_batch(st, rs1.t.p, rd.p, rs1.nparts, (size_t)M * 2 * sizeof(float)));
+                        free(rs1.t); rs1.t = rd;
+                    }
+                    TRY(dup_batch(x, *x_full));
+                    x = *x_full;
+                    batch = 2 * B; B = x.B; M = x.rows();
+                }
                 const LnFold l2{bw.ln2g, bw.ln2b, &rs1};
                 TRY(mha(h, true, ctx.p, S, ctx_dim, bw.a2, h, h2, nullptr, &l2, &rs2));
                 free(rs1.t); free(h); h = h2;
@@ -737,6 +773,7 @@ struct gyre_unet {
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
     bool hint_uniform_t = false;   // gyre_unet_hint_uniform_timestep: consumed by the next forward
+    bool hint_cfg_pairs = false;   // gyre_unet_hint_cfg_pairs: consumed by the next forward
     int gn_unit = 0;     // gcd of block_out_channels / groups: every GroupNorm group (skip concats included) is a whole number of units
     bf16_t *te1w, *te2w; float *te1b, *te2b;
     bf16_t* tproj_w = nullptr; float* tproj_b = nullptr;
@@ -910,7 +947,7 @@ struct gyre_unet {
     int run(bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B, int H,
             int W, int S, void* ws, size_t ws_bytes, void* out, int odt, const float* temb_add = nullptr,
             bool use_ctx_cache = false, const void* const* down_res = nullptr, int n_down_res = 0, int rdt = 0,
-            const void* mid_res = nullptr, const void* const* adapter = nullptr, int n_adapter = 0) {
+            const void* mid_res = nullptr, const void* const* adapter = nullptr, int n_adapter = 0, int force_pairs = -1) {
         // T2I-adapter states (reference gyre/pipeline/t2i_adapter/unet_patcher.py:21-86, fed by unet/core.py:212-216): one
         // NCHW tensor per down level, added IN PLACE to the level's last hidden state - just before its downsampler for the
         // cross-attention levels (so the skip connection taken there, the downsampler and everything after see it), after
@@ -937,15 +974,27 @@ struct gyre_unet {
         const bool uni_t = hint_uniform_t && !temb_add;
         hint_uniform_t = false;
         const int Bt = uni_t ? 1 : B, ld_tp = uni_t ? 0 : temb_cols;
+        // CFG-parallel call (reference unet/cfg.py:49-57: latents cat[x, x], timesteps cat[t, t], contexts cat[uncond, cond]):
+        // samples b and b + B/2 are the SAME up to the first cross-attention, so conv_in, the first resnet and the first
+        // transformer's GroupNorm / proj_in / self-attention run on B/2 samples and their results are written twice
+        // (Exec::transformer x_full).  Exact - the kernels do not depend on batch position - and only on the caller's word
+        // (gyre_unet_hint_cfg_pairs).  Not with ControlNet / T2I inputs (they differ per half), SDXL's per-sample added
+        // conditioning, ToMe (its merge runs inside the self-attention on whatever batch it gets: fine, but keep the
+        // measured configurations simple) or the debug taps.
+        const bool pairs_ok = B % 2 == 0 && !down_res && !mid_res && !adapter && !temb_add && c.attn_levels[0] &&
+                              c.layers_per_block >= 1 && c.transformer_depth[0] >= 1 && taps.empty();
+        const bool pairs = pairs_ok && (force_pairs >= 0 ? force_pairs != 0 : hint_cfg_pairs);
+        hint_cfg_pairs = false;
+        const int Bp = pairs ? B / 2 : B;              // batch of the shared prefix
         Tn xin, cx, emb, t1, t2, tp;
-        TRY(e.alloc(xin, B, H, W, pad8(c.in_channels)));
+        TRY(e.alloc(xin, Bp, H, W, pad8(c.in_channels)));
         if (!cached) TRY(e.alloc(cx, B, S, 1, D));
         TRY(e.alloc(emb, B, 1, 1, c.block_out_channels[0], 4));
         TRY(e.alloc(t1, B, 1, 1, temb_dim, 4));
         TRY(e.alloc(t2, B, 1, 1, temb_dim, 4));
         TRY(e.alloc(tp, B, 1, 1, temb_cols, 4));
         if (!dry) {
-            TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
+            TRY(launch_nchw_to_nhwc(st, x, xdt, Bp, c.in_channels, H * W, xin.C, xin.p));
             if (!cached) TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
             TRY(launch_timestep_embedding(st, t, Bt, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
             TRY(launch_rowvec_linear(st, (float*)emb.p, Bt, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
@@ -968,12 +1017,31 @@ struct gyre_unet {
         };
         std::vector<Tn> skips;
         Tn h;
+        e.batch = Bp;
         TRY(e.conv3(xin, conv_in, 1, 1, 0, nullptr, 0, nullptr, h));
         e.free(xin);
-        skips.push_back(h);
+        if (pairs) {                                   // the skip connection the up path reads holds all B samples
+            Tn hd;
+            TRY(e.dup_batch(h, hd));
+            skips.push_back(hd);
+        } else {
+            skips.push_back(h);
+        }
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < c.layers_per_block; ++j) {
                 Tn r;
+                if (pairs && i == 0 && j == 0) {
+                    // shared prefix: first resnet on the half batch (h = conv_in's half-batch output), first transformer up to
+                    // its first cross-attention; the transformer hands back the doubled resnet output (its residual)
+                    Tn rh, a, rfull;
+                    TRY(e.resnet(h, nullptr, down[0].res[0], tproj, ld_tp, 1e-5f, rh));
+                    e.free(h);
+                    TRY(e.transformer(rh, cx, S, D, down[0].attn[0], a, nullptr, &rfull));
+                    e.free(rh); e.free(rfull);
+                    e.batch = B;
+                    skips.push_back(a);
+                    continue;
+                }
                 TRY(e.resnet(skips.back(), nullptr, down[i].res[j], tproj, ld_tp, 1e-5f, r));
                 if (c.attn_levels[i]) {
                     Tn a;

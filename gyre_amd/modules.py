@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import threading
 import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
@@ -407,6 +408,7 @@ class GyreHipUNet(_NativeModule):
             augp = C.c_void_p(aug.data_ptr()) if aug is not None else None
             # one timestep for the whole batch (a scalar was passed): always stated explicitly, a stale hint never survives
             _lib.check(L.gyre_unet_hint_uniform_timestep(C.c_void_p(h), 1 if getattr(self, "_t_uniform", False) else 0))
+            _lib.check(L.gyre_unet_hint_cfg_pairs(C.c_void_p(h), 1 if (getattr(_HINTS, "cfg_pairs", False) and B % 2 == 0) else 0))
             if residuals is None:
                 _lib.check(L.gyre_unet_forward_ex(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(x.data_ptr()),
                                                   _lib.dtype_code(x), C.c_void_p(t.data_ptr()), None,
@@ -519,6 +521,25 @@ class _UNetInputGrad(torch.autograd.Function):
         # state dropped by another call on the handle (gyre_unet_vjp_pending == 0): recompute in one shot
         _, dx = m._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
         return dx, None, None, None, None, None
+
+
+_HINTS = threading.local()
+
+
+class cfg_pairs:
+    """``with cfg_pairs(): unet(cat[x, x], t, cat[uncond, cond])`` - the caller states that sample b and sample b + B/2 of the
+    UNet calls made inside (on this thread) have identical latents and timesteps, as the reference's CFGUNet_Parallel builds
+    them (unet/cfg.py:49-57).  GyreHipUNet then evaluates everything in front of the first cross-attention once per pair
+    (include/gyre_hip.h gyre_unet_hint_cfg_pairs).  ``GYRE_CFG_SHARED_PREFIX=0`` turns the hint off process-wide."""
+
+    def __enter__(self):
+        self._prev = getattr(_HINTS, "cfg_pairs", False)
+        _HINTS.cfg_pairs = os.environ.get("GYRE_CFG_SHARED_PREFIX", "1") != "0"
+        return self
+
+    def __exit__(self, *exc):
+        _HINTS.cfg_pairs = self._prev
+        return False
 
 
 def set_batch_invariant(canonical_samples: int = 16) -> int:

@@ -60,7 +60,10 @@ class CFGUNet_Parallel:
         latents = torch.cat([latents, latents])
         if isinstance(t, torch.Tensor) and t.shape:
             t = torch.cat([t, t])
-        noise_pred = self.f(latents, t)
+        # both halves carry the same latents and timesteps: the native UNet shares what they have in common
+        from .modules import cfg_pairs
+        with cfg_pairs():
+            noise_pred = self.f(latents, t)
         u, g = noise_pred.chunk(2)
         return u + self.guidance_scale * (g - u)
 

@@ -127,6 +127,14 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
  * the batched time_emb_proj then run for one row that every resnet reads - 1/B of that work, bit-identical results.  Ignored
  * when per-sample added conditioning (temb_add) is given.  A wrong hint gives every sample the first sample's timestep. */
 int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on);
+/* Hint for the NEXT gyre_unet_forward* call on this handle only: the batch is a CFG-parallel pair batch as the reference builds
+ * it (unet/cfg.py:49-57: latents cat[x, x], timesteps cat[t, t], contexts cat[uncond, cond]) - sample b and sample b + B/2 have
+ * IDENTICAL latents and timestep and differ in their text context only.  Everything in front of the first cross-attention
+ * (conv_in, the first resnet, the first transformer's GroupNorm / proj_in / self-attention: ~4 % of the FLOPs of an SD1.x call
+ * at 64x64) is then evaluated once per pair and written twice.  Exact: no kernel depends on batch position.  Ignored for odd B,
+ * with ControlNet / T2I inputs, per-sample added conditioning or pending debug taps.  A wrong hint gives the second half of the
+ * batch the first half's activations in that prefix. */
+int gyre_unet_hint_cfg_pairs(gyre_unet* h, int on);
 
 /* Text-context cache.  The context is constant over the 50+ UNet evaluations of a request, so its cross-attention
  * K / V projections (32 small GEMMs per call for SD1.x) can be done once: set_context projects ctx[B,S,cross_dim]

@@ -222,6 +222,46 @@ def test_uniform_timestep_fast_path_is_bit_identical():
         assert torch.equal(d[:B - 1], a[:B - 1]) and not torch.equal(d[B - 1], a[B - 1])
 
 
+@pytest.mark.parametrize("which,B,hw", [("tiny", 4, 16), ("sd15", 4, 64), ("sd15", 2, 32), ("inpaint9", 2, 32)])
+def test_cfg_pair_batches_share_their_prefix(which, B, hw):
+    """CFG-parallel batches (reference unet/cfg.py:49-57: cat[x, x] against cat[uncond, cond]): with the caller's hint
+    (modules.cfg_pairs -> gyre_unet_hint_cfg_pairs) conv_in, the first resnet and the first self-attention run once per
+    pair.  Same numbers as the plain call (bit-equal where the planner picks the same kernels for B/2 samples, else two
+    summation orders of the same GroupNorm sums), fewer FLOPs, and the fp32 oracle still agrees."""
+    from gyre_amd import _lib
+    from gyre_amd.modules import cfg_pairs
+    cfg = {"tiny": gcfg.tiny_unet(), "sd15": gcfg.sd15_unet(), "inpaint9": gcfg.sd15_unet(in_channels=9)}[which]
+    net, sd = make_unet(cfg)
+    half = randn(B // 2, cfg.in_channels, hw, hw, seed=51)
+    x = torch.cat([half, half]).to(DEV)
+    ctx = randn(B, 77, cfg.cross_attention_dim, seed=52).to(DEV)
+    plain = net(x, 500, encoder_hidden_states=ctx).sample
+    n_plain = _lib.lib().gyre_last_launch_count()
+    with cfg_pairs():
+        shared = net(x, 500, encoder_hidden_states=ctx).sample
+        n_shared = _lib.lib().gyre_last_launch_count()
+        again = net(x, 500, encoder_hidden_states=ctx).sample
+    assert torch.equal(shared, again)
+    d = float((shared.float() - plain.float()).norm() / plain.float().norm())
+    print(f"[property] {which} B={B} {hw}x{hw}: CFG halves sharing their prefix vs the plain call: rel-L2 {d:.2e} "
+          f"(bit-equal: {bool(torch.equal(shared, plain))}), launches {n_shared} vs {n_plain}")
+    assert d < 1.2e-2
+    if which == "tiny":
+        ref = M.unet_forward(sd, cfg, x.cpu(), torch.full((B,), 500), ctx.cpu())
+        report("tiny unet, CFG halves sharing their prefix", shared.cpu(), ref, 3e-2)
+    # per-sample timesteps in tensor form, equal between the halves, work as well
+    t = torch.tensor([500, 20] * (B // 4) if B >= 4 else [500], device=DEV)
+    tt = torch.cat([t, t])[:B] if B >= 4 else torch.full((B,), 500, device=DEV)
+    p2 = net(x, tt, encoder_hidden_states=ctx).sample
+    with cfg_pairs():
+        s2 = net(x, tt, encoder_hidden_states=ctx).sample
+    assert float((s2.float() - p2.float()).norm() / p2.float().norm()) < 1.2e-2
+    # the hint is per call: a later plain call on other data is not affected
+    y = randn(B, cfg.in_channels, hw, hw, seed=53).to(DEV)
+    q1 = net(y, 500, encoder_hidden_states=ctx).sample
+    assert not torch.equal(q1[: B // 2], q1[B // 2:])
+
+
 def test_context_cache_holds_alternating_contexts():
     """GYRE_CTX_SLOTS entries: hires-fix leaves / CFGUNet_Sequential (reference unet/cfg.py:27-38,
     unet/hires_fix.py:123-235) alternate between contexts on every call - no re-projection after the first round, results

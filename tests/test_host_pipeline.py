@@ -627,13 +627,14 @@ def test_pipeline_grafted_inpaint_tree(tiny):
         assert calls["inpaint"] > 0 and calls["base"] > calls["inpaint"], (smp, calls)
         assert pipe.last_unet_evals == calls["inpaint"] + calls["base"]
         assert out_d.shape == (2, 4, 16, 16) and bool(torch.isfinite(out_d).all()), smp
-    # DDIM keeps no history: with the graft window closed (blend start = end = 2: p = 0 always) the tree equals the plain
-    # runway-inpaint request bit for bit
+    # with the graft window closed (blend start / end beyond u = 1: p = 0 always) only the root leaf's UNet is ever evaluated
+    # (both leaves are still constructed and draw their start latents, reference build_mode order - so the images differ
+    # from the plain runway-inpaint request, whose single leaf draws alone)
     p_closed = GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp,
                             grafted_inpaint={"start": 2.0, "end": 3.0})
+    calls.update(base=0, inpaint=0)
     a = p_closed(**{**kw, "sampler": "ddim"})
-    b = GyrePipeline(base, OracleVAE(vsd, vcfg), device="cpu", inpaint_unet=inp)(**{**kw, "sampler": "ddim"})
-    assert torch.equal(a, b)
+    assert calls["base"] == 0 and calls["inpaint"] > 0 and bool(torch.isfinite(a).all())
     # hires fix above the threshold: four leaves (natural + full size, each grafted)
     calls.update(base=0, inpaint=0)
     bmask = torch.zeros(1, 1, 192, 256)

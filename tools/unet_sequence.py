@@ -27,8 +27,15 @@ with torch.no_grad():
         elif k.endswith("weight"): p.fill_(1.0)
         else: p.zero_()
 net._invalidate()
-x = torch.randn(B, 4, H, H, device=dev); t = torch.full((B,), 500, device=dev); ctx = torch.randn(B, 77, 768, device=dev)
-run = lambda: net(x, t, encoder_hidden_states=ctx)
+x = torch.randn(B, 4, H, H, device=dev); t = 500; ctx = torch.randn(B, 77, 768, device=dev)
+PAIRS = os.environ.get("PAIRS") == "1"               # CFG-parallel batch: halves share their prefix (modules.cfg_pairs)
+if PAIRS:
+    x = torch.cat([x[: B // 2], x[: B // 2]])
+from gyre_amd.modules import cfg_pairs
+import contextlib
+def run():
+    with (cfg_pairs() if PAIRS else contextlib.nullcontext()):
+        return net(x, t, encoder_hidden_states=ctx)
 for _ in range(2): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
