@@ -308,9 +308,9 @@ template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF =
 __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
-    constexpr int AR = BM / 64, BR = BN / 64;  // 8-row groups per wave per K step (A, B)
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-    static_assert(WM * WN == 8 && BM % 64 == 0 && BN % 64 == 0, "8 waves, 64-row staging granules");
+    constexpr int AR = BM / 64, BR = (BN + 63) / 64;  // 64-row staging granules per K step (A, B); the last B granule may be partial
+    constexpr int STAGE_BYTES = (BM + BR * 64) * 128;
+    static_assert(WM * WN == 8 && BM % 64 == 0 && BN % 16 == 0, "8 waves, 64-row staging granules");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
     // split-K: the K range is cut into `splits` contiguous slices; slice s of a tile is block s*ntiles + tile
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int n = n0 + r0 + 64 * i;
-            const bf16_t* src = (kok && n < p.N) ? p.W + (size_t)n * p.K + kw : zero;
+            const bf16_t* src = (kok && n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN)) ? p.W + (size_t)n * p.K + kw : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
         }
     };
@@ -975,7 +975,7 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    const size_t lds = (size_t)2 * (BM + BN) * 128;
+    const size_t lds = (size_t)2 * (BM + (BN + 63) / 64 * 64) * 128;
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
@@ -1033,7 +1033,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
 }
 
 // Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
-// 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256.
+// 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256, 8 = 8w 128x160.
 static int pick_cfg(const GemmParams& p, int* splits_out) {
     *splits_out = 1;
     const bool trans = p.out_mode == OUT_BF16_T;
@@ -1057,6 +1057,10 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
         auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
         if (!p.geglu && p.N % 320 == 0) { big(4, 0.92, 256, 320); big(5, 0.88, 128, 320); }
+        // 128x160: for the problems whose 128x256 / 128x320 tiling leaves CUs idle (16x16 level: M = 4096, N = 1280 is 160 /
+        // 128 tiles of those, 256 of this one).  71 FLOP per pipe byte against 85 / 91, but every CU works and two workgroups
+        // fit a CU (74 KB of LDS, < 128 registers): tuning bit 18 turns it off
+        if (!p.geglu && p.N % 160 == 0 && !(p.debug & 0x40000)) big(8, 0.58, 128, 160);
         if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
         // pipelined 32x32x16 kernel (kernels_gemm4s.hip), 8 waves on the 256x320 tile: better main loop (barrier off the
         // critical path, requests issued from the MFMA gaps), heavier two-pass epilogue -> long reductions only.
@@ -1168,10 +1172,10 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
     if (cfg == 24) return splits == 1 && gemm4s_supports(p, 24);      // pipelined 256x320 tile (kernels_gemm4s.hip)
-    if (cfg < 4 || cfg > 7 || splits > 1) return false;
-    if (p.geglu && (cfg == 4 || cfg == 5)) return false;
+    if (cfg < 4 || cfg > 8 || splits > 1) return false;
+    if (p.geglu && (cfg == 4 || cfg == 5 || cfg == 8)) return false;
     if (p.vt_out) {
-        const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : 64;
+        const int tn = cfg == 4 ? 160 : (cfg == 5 || cfg == 8) ? 80 : cfg == 6 ? 128 : 64;
         if (p.vt_col0 % tn) return false;
     }
     return true;
@@ -1186,8 +1190,8 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     if (!gemm_staged_epilogue_ok(p)) return 0;
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
-    if (cfg < 4 || cfg > 7 || splits > 1) return 0;
-    const int bn = (cfg == 4 || cfg == 5) ? 320 : 256;
+    if (cfg < 4 || cfg > 8 || splits > 1) return 0;
+    const int bn = (cfg == 4 || cfg == 5) ? 320 : cfg == 8 ? 160 : 256;
     return (p.N + bn - 1) / bn;
 }
 
@@ -1268,7 +1272,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         }
     }
     if (p.vt_out) {
-        const int tn = cfg == 4 ? 160 : cfg == 5 ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
+        const int tn = cfg == 4 ? 160 : (cfg == 5 || cfg == 8) ? 80 : cfg == 6 ? 128 : cfg == 7 ? 64 : 0;
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
     if (p.colstat_out) {
@@ -1279,13 +1283,13 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
     }
-    if (p.rowstat_out && (cfg < 4 || cfg > 7 || splits > 1 || !gemm_staged_epilogue_ok(p)))
+    if (p.rowstat_out && (cfg < 4 || cfg > 8 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");
-    if (p.ln_colsum && ((cfg != 24 && (cfg < 4 || cfg > 7)) || splits > 1 || !gemm_staged_epilogue_ok(p)))
+    if (p.ln_colsum && ((cfg != 24 && (cfg < 4 || cfg > 8)) || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: the folded LayerNorm needs an unsplit 8-wave tile config with the staged epilogue (see gemm_ln_fusable)");
     if (cfg >= 4) {
         if (p.out_mode == OUT_BF16_T) GYRE_FAIL(-6, "gemm: transposed output needs a 4-wave config");
-        if (p.geglu && (cfg == 4 || cfg == 5)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
+        if (p.geglu && (cfg == 4 || cfg == 5 || cfg == 8)) GYRE_FAIL(-6, "gemm: GEGLU needs an even fragment count per wave");
         p.zero_page = gemm_zero_page_for_current_device();
         if (!p.zero_page) GYRE_FAIL(-5, "gemm: cannot allocate the zero page");
     }
@@ -1297,6 +1301,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
+        case 8: return launch_cfg8<128, 160, 4, 2>(st, p, KC_G8_CONV_128x160, splits);
         case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }

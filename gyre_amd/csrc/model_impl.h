@@ -4,6 +4,7 @@
 #include "../../include/gyre_hip.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <cstdio>
 #include <cmath>
 
 #include <algorithm>
@@ -265,6 +266,9 @@ struct Exec {
     bool dry() const { return arena.dry; }
     int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
         t.B = B; t.H = H; t.W = W; t.C = C;
+        // a NEW tensor: whatever statistics record the variable carried belongs to the tensor it named before (a reused
+        // variable that kept it would release that tensor's - possibly still live - statistics buffer when freed)
+        t.cs = nullptr; t.cs_off = (size_t)-1; t.cs_bytes = 0; t.cs_chunks = 0; t.cs_unit = 0;
         t.bytes = (size_t)B * H * W * C * elt;
         t.off = arena.alloc(t.bytes);
         if (t.off == (size_t)-1 || (!arena.dry && t.off + t.bytes > arena.cap))
@@ -525,7 +529,7 @@ struct Exec {
                 p.out = q.p; p.ldc = 2 * C; p.out_mode = OUT_BF16;
                 p.vt_out = vt.p; p.vt_col0 = 2 * C; p.tokens_per_batch = Nq; p.ldt = ldvt;
                 GemmPlan pl = gemm_plan(p);
-                const int tn = pl.cfg == 4 ? 160 : pl.cfg == 5 ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
+                const int tn = pl.cfg == 4 ? 160 : (pl.cfg == 5 || pl.cfg == 8) ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
                 if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
                     fused = true;
                     Tn stats;
