@@ -1060,7 +1060,10 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         // 128x160: for the problems whose 128x256 / 128x320 tiling leaves CUs idle (16x16 level: M = 4096, N = 1280 is 160 /
         // 128 tiles of those, 256 of this one).  71 FLOP per pipe byte against 85 / 91, but every CU works and two workgroups
         // fit a CU (74 KB of LDS, < 128 registers): tuning bit 18 turns it off
-        if (!p.geglu && p.N % 160 == 0 && !(p.debug & 0x40000)) big(8, 0.58, 128, 160);
+        // (tools/gemm_sweep.py 16 64 sd15 8, cold and producer-warm regimes: beats the 128x320 tile wherever that one is
+        //  chosen - 32x32 projections 34.7 -> 28.2 us, K = 2560 84 -> 66 us - and loses to 256x320 / 256x256 where those fill
+        //  the chip, M = 65536: 41 vs 38 us)
+        if (!p.geglu && p.N % 160 == 0 && !(p.debug & 0x40000)) big(8, 0.90, 128, 160);
         if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
         // pipelined 32x32x16 kernel (kernels_gemm4s.hip), 8 waves on the 256x320 tile: better main loop (barrier off the
         // critical path, requests issued from the MFMA gaps), heavier two-pass epilogue -> long reductions only.
@@ -1086,7 +1089,7 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
             auto tryk = [&](int id, double speed, int bm, int bn) {
                 long t = tiles(bm, bn);
                 if (t >= 160 || t < 1) return;
-                int sp = (int)(256 / t);
+                int sp = (int)((id == 8 ? 512 : 256) / t);          // two 128x160 workgroups fit a CU
                 // K steps per slice: >= 8 for the 128-row tiles (tools/gemm_sweep.py at batch 2: 16 left 10 % on the table),
                 // >= 16 for the 256-row ones (8x8 level, K = 11520: 256x320 x16 slices 56 us vs 128x320 x8 slices 50 us)
                 const int min_steps = bm >= 256 ? 16 : 8;
@@ -1097,6 +1100,7 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
                 if (sc > best) { best = sc; cfg = id; *splits_out = sp; }
             };
             if (p.N % 320 == 0) tryk(5, 0.88, 128, 320);
+            if (p.N % 160 == 0 && !(p.debug & 0x40000)) tryk(8, 0.92, 128, 160);     // 8x8 convs: 60 -> 57 us (sweep)
             if (p.N % 256 == 0) tryk(7, 0.62, 128, 256);
             // very long reductions (3x3 convs over 1280+ channels at 32x32 / 16x16): the 256x320 tile's better
             // operand reuse outweighs the larger slabs - measured +3 % (K = 11520) to +10 % (K = 17280 / 23040)

@@ -254,7 +254,7 @@ def test_error_paths():
 
 
 # ---- every GEMM tile configuration, forced, on shapes with M / N / K tails -------------------------
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,K,N,bias,res", [(1000, 320, 640, True, True), (4096 + 37, 200, 1280, True, False),
                                             (513, 1280, 320 * 4, False, True)])
 def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
@@ -295,7 +295,7 @@ def test_geglu_forced_tile_config(cfg):
     report(f"geglu cfg{cfg}", y.float().cpu(), ref, TOL)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,asym,res", [
     (2, 24, 20, 320, 640, 1, 0, 0, True), (1, 16, 16, 72, 1280, 1, 1, 0, False), (2, 18, 18, 128, 1280, 2, 0, 1, False),
 ])
@@ -373,7 +373,7 @@ def test_attention_variants(variant, B, heads, Nq, Nk, D):
 
 
 def test_all_tile_configs_sum_in_the_same_order():
-    """Every production tile config (4-wave 128x128 / 256x64 / 64x64, 8-wave 256x320 / 128x320 / 256x256 / 128x256)
+    """Every production tile config (4-wave 128x128 / 256x64 / 64x64, 8-wave 256x320 / 128x320 / 256x256 / 128x256 / 128x160)
     gives BIT-identical output for the same problem: the planner may pick by problem size without changing results."""
     L = _lib.lib()
     # 3x3 conv, uniform taps, dual-source-free; Cout multiple of 320 and 256 so that all configs are legal
@@ -382,7 +382,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
     b = randn(Cout, seed=62).to(DEV)
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
         y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
@@ -397,7 +397,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     xl = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
     wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
     outs = {}
-    for cfg in (1, 2, 3, 4, 5, 6, 7):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
@@ -487,7 +487,7 @@ def test_attention_prescaled_peaked_and_drifting_max():
 
 
 @pytest.mark.parametrize("cfg,B,tokens,C", [(0, 16, 4096, 320), (4, 4, 1024, 320), (5, 2, 1024, 320), (6, 2, 1024, 640), (7, 2, 512, 640),
-                                            (0, 16, 1024, 640), (5, 3, 264, 320)])
+                                            (0, 16, 1024, 640), (5, 3, 264, 320), (8, 2, 1024, 320), (0, 16, 256, 1280)])
 def test_fused_qkv_projection(cfg, B, tokens, C):
     """Q | K | V in one GEMM launch; the V tiles go through the transposing epilogue into V^T[b][c][token]."""
     L = _lib.lib()
