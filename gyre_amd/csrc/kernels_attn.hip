@@ -631,8 +631,33 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
             off[i] = 0; kq[i] = 1 << 28;
         }
     }
+    // Tiles are requested in order (kv0 = 0, 64, 128, ...), so every lane keeps a RUNNING source pointer per DMA piece: for a
+    // tile that lies wholly inside the key range the request is the pointer itself and one 64-bit add advances it (padding
+    // rows / the ones row point at the zero page with a zero step) - the per-lane bounds test + pointer select of the general
+    // form (2 x v_cmp + 4 x v_cndmask + address arithmetic per piece: ~70 of the ~230 vector instructions of a tile) is left
+    // to the tail tile and to the past-the-end requests.
+    // (head dims up to 40 only: three pieces per wave; the nine / twelve extra registers make the D = 64 / 80 forms spill,
+    // and a counted-vmcnt kernel must not spill)
+    constexpr bool RUNPTR = D <= 40;
+    const char* pcur[NW];
+    unsigned pinc[NW];
+#pragma unroll
+    for (int i = 0; RUNPTR && i < NW; ++i) {
+        const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
+        const bool live = kq[i] < (1 << 27);
+        pcur[i] = live ? (const char*)(isk ? kb + off[i] : vb + off[i]) : (const char*)((ONES && one_row[i]) ? zero + 128 : zero);
+        pinc[i] = live ? (isk ? 64u * (unsigned)p.ldk * 2u : 128u) : 0u;
+    }
     auto issue = [&](int kv0, int st) {
         char* sbase = smem + st * STAGE + wave * 1024;
+        if (RUNPTR && kv0 + 64 <= p.Nk) {                // wave-uniform: a full tile
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                __builtin_amdgcn_global_load_lds((gbl_void_a*)pcur[i], (lds_void_a*)(sbase + i * 4096), 16, 0, 0);
+                pcur[i] += pinc[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
