@@ -77,7 +77,7 @@ _SIGS = {
     "gyre_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _i]),
     "gyre_vae_decode_vjp_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "gyre_vae_decode_vjp": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i]),
-    "gyre_prof_set_mask": (_i, [C.c_uint]),
+    "gyre_prof_set_mask": (_i, [C.c_uint64]),
     "gyre_prof_num_classes": (_i, []),
     "gyre_prof_class_name": (C.c_char_p, [_i]),
     "gyre_prof_collect": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -667,6 +667,8 @@ static int cs_red_colblock(int N, int unit) {
 }
 
 int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits) {
+    // its own class: the GEMM classes' event time (bench.py's live `roofline`) is the GEMM kernel alone, as rocprofv3 sees it
+    GyreProfScope prof_(KC_SPLITK_REDUCE, st, 0.0, (double)splits * p.M * p.N * 4.0 + (double)p.M * p.N * 2.0 * (p.residual ? 2.0 : 1.0));
     if (p.colstat_out) {
         const int CB = cs_red_colblock(p.N, p.colstat_unit);
         const int TX = CB / 8;
@@ -1028,6 +1030,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
     }
 #undef GYRE_GEMM8_GO
     GYRE_LAUNCH_CHECK();
+    prof_.stop();
     if (splits > 1) return launch_splitk_reduce(st, p, splits);
     return 0;
 }

@@ -602,6 +602,7 @@ static int launch_cfg4s(hipStream_t st, const GemmParams& p, int kcls_base, int 
     else GYRE_GEMM4S_GO(GEMM_CONV3, 0);
 #undef GYRE_GEMM4S_GO
     GYRE_LAUNCH_CHECK();
+    prof_.stop();
     if (splits > 1) return launch_splitk_reduce(st, p, splits);
     return 0;
 }

@@ -26,14 +26,15 @@ extern "C" int64_t gyre_last_launch_count(void) { return g_launches; }
 namespace {
 struct ProfRec { hipEvent_t a, b; int kclass; double flops, bytes; };
 struct ProfState {
-    unsigned mask = 0;  // bit per GyreKernelClass
+    unsigned long long mask = 0;  // bit per GyreKernelClass (KC_COUNT <= 64)
     std::vector<ProfRec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 thread_local ProfState g_prof;
+static_assert(KC_COUNT <= 64, "profiler mask is 64 bits wide");
 }  // namespace
 GyreProfScope::GyreProfScope(int kclass, hipStream_t st, double flops, double bytes) : st_(st) {
-    if (!(g_prof.mask >> kclass & 1u)) return;
+    if (!(g_prof.mask >> kclass & 1ull)) return;
     hipEvent_t a, b;
     if (!g_prof.pool.empty()) { a = g_prof.pool.back().first; b = g_prof.pool.back().second; g_prof.pool.pop_back(); }
     else { if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return; }
@@ -41,8 +42,10 @@ GyreProfScope::GyreProfScope(int kclass, hipStream_t st, double flops, double by
     slot = (int)g_prof.recs.size();
     g_prof.recs.push_back({a, b, kclass, flops, bytes});
 }
-GyreProfScope::~GyreProfScope() {
+GyreProfScope::~GyreProfScope() { stop(); }
+void GyreProfScope::stop() {
     if (slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, st_);
+    slot = -1;
 }
 static const char* kclass_name(int k) {
     static const char* n[KC_COUNT] = {
@@ -53,7 +56,8 @@ static const char* kclass_name(int k) {
         "k_gemm8<128, 160, 4, 2, 1", "(unused 1)", "(unused 2)", "(unused 3)", "k_gemm8<128, 160, 4, 2, 0",
         "k_gemm4s<192, 320, 2, 2, 1", "k_gemm4s<192, 320, 2, 2, 0", "k_gemm4s<256, 256, 2, 2, 1", "k_gemm4s<256, 256, 2, 2, 0",
         "k_gemm4s<128, 320, 2, 2, 1", "k_gemm4s<128, 320, 2, 2, 0", "k_gemm4s<128, 256, 2, 2, 1", "k_gemm4s<128, 256, 2, 2, 0", "k_gemm4s<256, 320, 4, 2, 1", "k_gemm4s<256, 320, 4, 2, 0",
-        "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other", "k_attn_bwd", "k_gn_bwd+k_ln_bwd"};
+        "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other", "k_attn_bwd", "k_gn_bwd+k_ln_bwd",
+        "k_splitk_reduce"};
     return (k >= 0 && k < KC_COUNT) ? n[k] : "?";
 }
 
@@ -328,7 +332,7 @@ int gyre_vae_decode_vjp(gyre_vae* h, void* st, const void* z, int zdt, int B, in
     return gyre_vae_run_decode_vjp(*h, false, (hipStream_t)st, z, zdt, B, hl, wl, d_img, ddt, ws, wsb, img_out, odt, dz_out, dzdt);
 }
 
-int gyre_prof_set_mask(unsigned mask) { g_prof.mask = mask; return 0; }
+int gyre_prof_set_mask(unsigned long long mask) { g_prof.mask = mask; return 0; }
 int gyre_prof_num_classes(void) { return KC_COUNT; }
 const char* gyre_prof_class_name(int k) { return kclass_name(k); }
 // Collects (and clears) the records of this thread: per class launches, total ms, algorithmic flops / bytes.

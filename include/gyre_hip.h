@@ -231,7 +231,7 @@ int gyre_vae_decode(gyre_vae* h, void* stream, const void* z_nchw, int in_dtype,
  * kernel's demangled name as rocprofv3 prints it).  collect(): after the caller synchronised the
  * stream, returns per class the number of timed launches, the summed event-to-event milliseconds and
  * the summed ALGORITHMIC flops / bytes (unpadded problem sizes) and clears the records. */
-int gyre_prof_set_mask(unsigned mask);
+int gyre_prof_set_mask(unsigned long long mask);
 int gyre_prof_num_classes(void);
 const char* gyre_prof_class_name(int kclass);
 int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* bytes);
