@@ -164,10 +164,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 const float4 val = ep_affine<LNF>(acc[i][j], bv, cv, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
                 const float4 gate = ep_affine<LNF>(acc[i][j + 1], bg, cg, LNF ? lrstd[i] : 0.f, LNF ? lrmu[i] : 0.f);
                 float4 o;
+                if (p.debug & 8) { o.x = val.x * gate.x; o.y = val.y * gate.y; o.z = val.z * gate.z; o.w = val.w * gate.w; }   // ablation: no GELU
+                else {
                 o.x = val.x * gelu_erf_f(gate.x);
                 o.y = val.y * gelu_erf_f(gate.y);
                 o.z = val.z * gelu_erf_f(gate.z);
                 o.w = val.w * gelu_erf_f(gate.w);
+                }
                 *(float4*)(my + fr * rowf + (j / 2) * 16 + 4 * fq) = o;
             }
         } else {
@@ -205,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                     for (int e = 0; e < 8; ++e) f[e] += r[e];
                 }
                 const uint4 pk = pack8(f);
-                *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pk;
+                if (!(p.debug & 16)) *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pk;       // (bit4 ablation: no stores)
                 if (RS || CS) unpack8(pk, f);     // statistics of what the consumer will read: the rounded values
                 if (RS) {
 #pragma unroll
@@ -249,6 +252,62 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
             if (col < tno) cs_wave[col] = make_float2(cs_s[c], cs_q[c]);
         }
     }
+}
+
+// GEGLU epilogue of the folded-LayerNorm FF1 (no residual, no statistics).  Column pair outer, 16-row slab inner: the column
+// constants of a (value, gate) fragment pair are read from LDS once instead of once per slab, and the MI GELU evaluations of a
+// pair are independent chains that cover each other's ds_read / transcendental latency (in the slab-outer form each chain
+// waited for its own constants: tools/ff1_ablation.py, the GELU arithmetic alone cost 52 of the 210 us of the 64x64 FF1).
+// Every slab of the wave tile has its own rows in LDS (MI * 16 rows of TN / 2 + 4 floats per wave: gemm_geglu_lnf_lds_bytes),
+// read back row-wise after the last pair.
+template <int MI, int NI, int TN>
+__device__ __forceinline__ void gemm_epilogue_geglu_lnf(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
+                                                        int fr, int fq, int lane, float* my, const float* lrstd,
+                                                        const float* lrmu, const float* lcs, const float* lbb) {
+    constexpr int tno = TN / 2, rowf = tno + 4, vec_per_row = tno / 8;
+    constexpr int NV = (16 * vec_per_row + 63) / 64;
+    const int n_out_base = n_base / 2, n_out = p.N / 2;
+#pragma unroll
+    for (int j = 0; j + 1 < NI; j += 2) {
+        const float4 bv = *(const float4*)(lbb + j * 16 + 4 * fq), bg = *(const float4*)(lbb + j * 16 + 16 + 4 * fq);
+        const float4 cv = *(const float4*)(lcs + j * 16 + 4 * fq), cg = *(const float4*)(lcs + j * 16 + 16 + 4 * fq);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float4 val = ep_affine<true>(acc[i][j], bv, cv, lrstd[i], lrmu[i]);
+            const float4 gate = ep_affine<true>(acc[i][j + 1], bg, cg, lrstd[i], lrmu[i]);
+            float4 o;
+            if (p.debug & 8) { o.x = val.x * gate.x; o.y = val.y * gate.y; o.z = val.z * gate.z; o.w = val.w * gate.w; }   // ablation: no GELU
+            else {
+                o.x = val.x * gelu_erf_f(gate.x);
+                o.y = val.y * gelu_erf_f(gate.y);
+                o.z = val.z * gelu_erf_f(gate.z);
+                o.w = val.w * gelu_erf_f(gate.w);
+            }
+            *(float4*)(my + (i * 16 + fr) * rowf + (j / 2) * 16 + 4 * fq) = o;
+        }
+    }
+    // LDS operations of one wave complete in order: the read-back below sees the writes above
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int v = lane + 64 * q;
+            if (v >= 16 * vec_per_row) break;
+            const int row = v / vec_per_row, c8 = v - row * vec_per_row;
+            const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
+            const float4 lo = *(const float4*)(my + (i * 16 + row) * rowf + c8 * 8);
+            const float4 hi = *(const float4*)(my + (i * 16 + row) * rowf + c8 * 8 + 4);
+            if (mm < p.M && nn < n_out && !(p.debug & 16)) {
+                const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                *(uint4*)((bf16_t*)p.out + (size_t)mm * p.ldc + nn) = pack8(f);
+            }
+        }
+    }
+}
+// LDS the form above needs for a BM x BN tile of 8 waves (slabs + the column constants behind them)
+static inline size_t gemm_geglu_lnf_lds_bytes(int BM, int BN, int WM, int WN) {
+    const int TM = BM / WM, TN = BN / WN;
+    return (size_t)8 * TM * (TN / 2 + 4) * 4 + (size_t)2 * BN * 4;
 }
 
 // Transposed variant for the V columns of a fused Q|K|V projection: the 16-row slab is read back column-wise, 8
@@ -311,6 +370,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     constexpr int AR = BM / 64, BR = (BN + 63) / 64;  // 64-row staging granules per K step (A, B); the last B granule may be partial
     constexpr int STAGE_BYTES = (BM + BR * 64) * 128;
     static_assert(WM * WN == 8 && BM % 64 == 0 && BN % 16 == 0, "8 waves, 64-row staging granules");
+    // the pair-outer GEGLU epilogue of the folded-LayerNorm form needs a slab per 16-row fragment (gemm_geglu_lnf_lds_bytes)
+    constexpr bool GG_SLABS = LNF && NI % 2 == 0 && (size_t)8 * TM * (TN / 2 + 4) * 4 + (size_t)2 * BN * 4 <= 160 * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
     // split-K: the K range is cut into `splits` contiguous slices; slice s of a tile is block s*ntiles + tile
@@ -480,7 +541,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         if constexpr (LNF) {
             // column constants of the tile (colsum, folded bias) go to LDS behind the epilogue slabs: the epilogue reads them
             // with ds_read_b128 instead of holding dozens of global loads in flight next to 160 live accumulators
-            float* colc = (float*)smem_raw + 8 * 16 * (TN + 4);
+            // (the GEGLU form keeps a slab per 16-row fragment: its constants sit behind MI slabs of TN / 2 + 4 floats per wave)
+            const bool gg_slabs = GG_SLABS && p.geglu && !p.residual && !(p.debug & 0x80000);
+            float* colc = (float*)smem_raw + (gg_slabs ? 8 * TM * (TN / 2 + 4) : 8 * 16 * (TN + 4));
             for (int t = tid; t < BN; t += 512) {
                 const int n = n0 + t;
                 colc[t] = n < p.N ? p.ln_colsum[n] : 0.f;
@@ -560,6 +623,13 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
             return;
         }
         if constexpr (NI % 2 == 0) {
+            if constexpr (LNF && GG_SLABS) {
+                if (p.geglu && !p.residual && !(p.debug & 0x80000)) {      // (bit 19: the slab-outer form, for A/B runs)
+                    gemm_epilogue_geglu_lnf<MI, NI, TN>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane,
+                                                        (float*)smem_raw + wave * (TM * (TN / 2 + 4)), lrstd, lrmu, lcs, lbb);
+                    return;
+                }
+            }
             if (p.geglu) { gemm_epilogue_staged<MI, NI, TN, true, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb); return; }
         }
         gemm_epilogue_staged<MI, NI, TN, false, LNF>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, lane, my, lrstd, lrmu, lcs, lbb);
@@ -977,7 +1047,9 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    const size_t lds = (size_t)2 * (BM + (BN + 63) / 64 * 64) * 128;
+    size_t lds = (size_t)2 * (BM + (BN + 63) / 64 * 64) * 128;
+    if (p.mode == GEMM_LINEAR && p.ln_colsum && p.geglu && gemm_geglu_lnf_lds_bytes(BM, BN, WM, WN) <= 160 * 1024)
+        lds = std::max(lds, gemm_geglu_lnf_lds_bytes(BM, BN, WM, WN));
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0

@@ -47,12 +47,14 @@ res = {f: ([], []) for f in flags}
 outs = {}
 for r in range(rounds):
     for f in flags:
-        L.gyre_debug_gemm_ablation(f)
+        L.gyre_debug_gemm_ablation(f & 0xffffff)
+        L.gyre_debug_force_attn_variant((f >> 24) & 15)      # bits 24-27: attention variant (8 = automatic without the 8-wave workgroups)
         res[f][0].append(timeit(lambda: net(x, t, encoder_hidden_states=ctx).sample, 5))
         res[f][1].append(timeit(lambda: vae.decode(z).sample, 2))
         if r == 0:
             outs[f] = (net(x, t, encoder_hidden_states=ctx).sample.clone(), L.gyre_last_launch_count())
 L.gyre_debug_gemm_ablation(0)
+L.gyre_debug_force_attn_variant(0)
 for f in flags:
     u, v = res[f]
     same = bool(torch.equal(outs[f][0], outs[flags[0]][0]))
