@@ -1065,7 +1065,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
     } while (0)
     if (p.colstat_out && splits == 1) {
-        if constexpr (BN == 320) {
+        if constexpr (BN == 320 || BN == 160) {
             const bool uni = (p.Cin % BK == 0) && (p.C1 % BK == 0);
 #define GYRE_GEMM8_CS(MODE_, UNI_)                                                                                  \
     do {                                                                                                            \
@@ -1080,7 +1080,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
             else GYRE_GEMM8_CS(GEMM_CONV3, false);
 #undef GYRE_GEMM8_CS
         } else {
-            GYRE_FAIL(-6, "gemm: column statistics exist for the 320-wide tiles only (see gemm_colstat_rows)");
+            GYRE_FAIL(-6, "gemm: column statistics exist for the 320- and 160-wide tiles only (see gemm_colstat_rows)");
         }
     } else if (p.mode == GEMM_LINEAR && p.rowstat_out) {
         auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, false, true>;
@@ -1289,6 +1289,7 @@ int gemm_colstat_rows(const GemmParams& p0) {
     if (splits > 1) rows = (cs_red_colblock(p.N, unit) <= 2048) ? CS_RED_ROWS : 0;     // k_splitk_reduce_cs
     else if (cfg == 4) rows = 256;
     else if (cfg == 5) rows = 128;
+    else if (cfg == 8 && p.N % 160 == 0 && 160 % unit == 0 && !(p.debug & 0x100000)) rows = 128;   // (bit 20: as before this tile had the epilogue)
     else if (cfg == 24 && p.mode == GEMM_CONV3) rows = 256;                    // pipelined 256x320 tile (kernels_gemm4s.hip)
     if (!rows || p.rows_per_sample % rows) return 0;
     return rows;
@@ -1358,7 +1359,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         GemmParams q = p0;
         q.splitk_ws = nullptr;
         const int rows = gemm_colstat_rows(q);
-        const int want = splits > 1 ? CS_RED_ROWS : cfg == 4 ? 256 : cfg == 5 ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
+        const int want = splits > 1 ? CS_RED_ROWS : cfg == 4 ? 256 : (cfg == 5 || cfg == 8) ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
     }

@@ -254,7 +254,8 @@ int gyre_debug_force_attn_variant(int v);
  * zero padding from a zero page in the pipelined kernel, bit10 = no pipelined (32x32x16) tile configs, bit11 = LayerNorm as a
  * separate pass (no fold into the consuming GEMM), bit15 = folded LayerNorm takes its row statistics from a separate pass
  * instead of the producing GEMM's epilogue, bit16 = the GEGLU FF1 keeps its separate LayerNorm, bit17 = GroupNorm keeps its own
- * statistics pass (no statistics from the producing conv / GEMM). */
+ * statistics pass (no statistics from the producing conv / GEMM), bit19 = slab-outer GEGLU epilogue of the folded-LayerNorm
+ * FF1, bit20 = no statistics epilogue on the 128x160 tile.  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
 int gyre_debug_gemm_ablation(int bits);
 
 /* ---- batch-invariant mode ------------------------------------------------

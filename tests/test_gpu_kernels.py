@@ -911,6 +911,9 @@ def _check_colstats(name, stats, y, B, rows, unit):
     (16, 64, 64, 320, 320, 2, 0, False, 0),       # downsample conv -> 32x32
     (16, 32, 32, 640, 640, 1, 1, False, 256),     # upsample conv -> 64x64
     (16, 32, 32, 1920, 640, 1, 0, True, 0),
+    (8, 64, 64, 320, 320, 1, 0, True, 128),       # 128x160 tile, unsplit (the shared prefix of a CFG batch runs at half the batch)
+    (8, 64, 64, 320, 320, 2, 0, False, 0),        # downsample conv at half the batch
+    (16, 32, 32, 320, 640, 1, 0, False, 0),
 ])
 def test_conv_emits_groupnorm_statistics(B, H, W, Cin, Cout, stride, ups, res, want_rows):
     import ctypes as C
@@ -958,7 +961,8 @@ def test_conv_emits_groupnorm_statistics(B, H, W, Cin, Cout, stride, ups, res, w
     assert torch.equal(stats[:nblk], s1)
 
 
-@pytest.mark.parametrize("B,HW,C,res", [(16, 4096, 320, True), (16, 1024, 640, True), (2, 4096, 320, True), (3, 1024, 1280, False)])
+@pytest.mark.parametrize("B,HW,C,res", [(16, 4096, 320, True), (16, 1024, 640, True), (2, 4096, 320, True), (3, 1024, 1280, False),
+                                          (8, 4096, 320, True), (8, 1024, 640, True)])
 def test_linear_emits_groupnorm_statistics(B, HW, C, res):
     """The transformer's proj_out (+ residual) feeds the next resnet's GroupNorm."""
     import ctypes as Ct
