@@ -666,12 +666,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits)
 // PY-th row, so the per-channel sums of the ROUNDED outputs accumulate in registers; they are folded rows -> channels -> units
 // through LDS in a fixed order and leave as one partial per (row block, unit).  Grid = row blocks x column blocks: as many
 // workgroups as the plain reduction has at these sizes (a one-dimensional grid of row blocks left the chip idle at small M).
+// CS_RED_ROWS rows per block, or 64 where a sample has more than 64 such blocks (the consumer's prologue adds a sample's row
+// blocks serially: model_impl.h attach_colstats takes at most 64 per sample - the 64x64 level at small batch).
 #define CS_RED_ROWS 16
-__global__ __launch_bounds__(256) void k_splitk_reduce_cs(GemmParams p, int splits, int CB, int TX, int PY) {
+static inline int cs_red_rows(int rows_per_sample) {
+    return (rows_per_sample > 64 * CS_RED_ROWS && rows_per_sample % 64 == 0) ? 64 : CS_RED_ROWS;
+}
+__global__ __launch_bounds__(256) void k_splitk_reduce_cs(GemmParams p, int splits, int CB, int TX, int PY, int R) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* red = (float2*)smem_raw;             // [PY][CB]
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int m0 = blockIdx.x * CS_RED_ROWS, nb = blockIdx.y * CB;
+    const int m0 = blockIdx.x * R, nb = blockIdx.y * CB;
     if (ty < PY && tx * 8 < CB) {
         const int n = nb + tx * 8;
         float s[8], ss[8];
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_cs(GemmParams p, int spli
             const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
             bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
         }
-        for (int r = ty; r < CS_RED_ROWS; r += PY) {
+        for (int r = ty; r < R; r += PY) {
             const int m = m0 + r;
             if (m >= p.M) break;
             float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -742,10 +747,11 @@ int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits) {
     if (p.colstat_out) {
         const int CB = cs_red_colblock(p.N, p.colstat_unit);
         const int TX = CB / 8;
-        int PY = 256 / TX; if (PY < 1) PY = 1; if (PY > CS_RED_ROWS) PY = CS_RED_ROWS;
+        const int R = cs_red_rows(p.rows_per_sample);
+        int PY = 256 / TX; if (PY < 1) PY = 1; if (PY > R) PY = R;
         const size_t lds = (size_t)PY * CB * sizeof(float2);
-        hipLaunchKernelGGL(k_splitk_reduce_cs, dim3((unsigned)((p.M + CS_RED_ROWS - 1) / CS_RED_ROWS), (unsigned)(p.N / CB)), dim3(256), lds, st,
-                           p, splits, CB, TX, PY);
+        hipLaunchKernelGGL(k_splitk_reduce_cs, dim3((unsigned)((p.M + R - 1) / R), (unsigned)(p.N / CB)), dim3(256), lds, st,
+                           p, splits, CB, TX, PY, R);
         GYRE_LAUNCH_CHECK();
         return 0;
     }
@@ -1286,7 +1292,7 @@ int gemm_colstat_rows(const GemmParams& p0) {
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
     int rows = 0;
-    if (splits > 1) rows = (cs_red_colblock(p.N, unit) <= 2048) ? CS_RED_ROWS : 0;     // k_splitk_reduce_cs
+    if (splits > 1) rows = (cs_red_colblock(p.N, unit) <= 2048) ? cs_red_rows(p.rows_per_sample) : 0;     // k_splitk_reduce_cs
     else if (cfg == 4) rows = 256;
     else if (cfg == 5) rows = 128;
     else if (cfg == 8 && p.N % 160 == 0 && 160 % unit == 0 && !(p.debug & 0x100000)) rows = 128;   // (bit 20: as before this tile had the epilogue)
@@ -1359,7 +1365,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         GemmParams q = p0;
         q.splitk_ws = nullptr;
         const int rows = gemm_colstat_rows(q);
-        const int want = splits > 1 ? CS_RED_ROWS : cfg == 4 ? 256 : (cfg == 5 || cfg == 8) ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
+        const int want = splits > 1 ? cs_red_rows(p.rows_per_sample) : cfg == 4 ? 256 : (cfg == 5 || cfg == 8) ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
     }

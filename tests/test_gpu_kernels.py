@@ -914,6 +914,7 @@ def _check_colstats(name, stats, y, B, rows, unit):
     (8, 64, 64, 320, 320, 1, 0, True, 128),       # 128x160 tile, unsplit (the shared prefix of a CFG batch runs at half the batch)
     (8, 64, 64, 320, 320, 2, 0, False, 0),        # downsample conv at half the batch
     (16, 32, 32, 320, 640, 1, 0, False, 0),
+    (2, 64, 64, 320, 320, 1, 0, True, 64),        # split K at the 64x64 level: 64-row blocks (at most 64 per sample)
 ])
 def test_conv_emits_groupnorm_statistics(B, H, W, Cin, Cout, stride, ups, res, want_rows):
     import ctypes as C
@@ -982,7 +983,7 @@ def test_linear_emits_groupnorm_statistics(B, HW, C, res):
     if rc == -6:
         pytest.skip("planner's kernel for this shape emits no column statistics")
     _lib.check(rc)
-    assert rows.value in (128, 256) and HW % rows.value == 0
+    assert rows.value in (16, 64, 128, 256) and HW % rows.value == 0
     report(f"linear {M}x{C}x{C}", y.float().cpu(), ref, TOL)
     _check_colstats(f"linear {M}x{C}x{C}", stats[:M // rows.value], y, B, rows.value, unit)
 
