@@ -103,7 +103,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
     const int kvs = (lane & 7) ^ ((4 * (w & 1) + (lane >> 4)) & 7);    // global 16-byte k-slot this lane fetches
     const bf16_t* zero = p.zero_page;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS offset of the ring
-    const bool abl_zero = p.debug & 1, abl_nodma = p.debug & 2;       // tuning ablations (results are garbage)
+    // Tuning ablations (results are garbage) exist only in builds with -DGYRE_GEMM_ABLATIONS: each test is a scalar and / branch
+    // pair per DMA piece inside the K loop, and a wave's issue slots are what bounds that loop (280 instructions around 40 MFMAs)
+#ifdef GYRE_GEMM_ABLATIONS
+    const bool abl_zero = p.debug & 1, abl_nodma = p.debug & 2, abl_a0 = p.debug & 8, abl_w0 = p.debug & 16;
+#else
+    constexpr bool abl_zero = false, abl_nodma = false, abl_a0 = false, abl_w0 = false;
+#endif
 
     // ---- per-lane DMA source state ------------------------------------------------------------------------------
     // piece i of this wave covers tile rows 8 * (w + NW * i) .. + 7
@@ -154,8 +160,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
     struct StepSrc { const char* ab; const char* wb; srd_t srd; unsigned soff, ld2; int ky, kx; bool live, live_w; };
     auto step_src = [&](int kc, bool live0) {
         StepSrc s;
-        const bool live = live0 && !(p.debug & 8);      // ablation: activations from the zero page only
-        s.live_w = live0 && !(p.debug & 16);            // ablation: weights from the zero page only
+        const bool live = live0 && !abl_a0;             // ablation: activations from the zero page only
+        s.live_w = live0 && !abl_w0;                    // ablation: weights from the zero page only
         s.live = live;
         int kw;
         if (MODE == GEMM_LINEAR) {
