@@ -191,6 +191,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
             if (MODE == GEMM_LINEAR) {
                 glds_saddr(dst + i * (NW * 1024), s.live ? +vo_a[i] : 0u, s.ab);
             } else {
+#ifdef GYRE_GEMM_ABLATIONS
+                if ((p.debug & 0x80) && (s.ky | s.kx)) return;        // ablation: activations requested on tap 0 of a chunk only (1/9)
+                if ((p.debug & 0x200) && s.kx) return;                // ablation: ... on the kx = 0 taps only (3/9)
+#endif
                 const int iy = a_y0[i] + s.ky, ix = a_x0[i] + s.kx;
                 const bool ok = ((unsigned)iy < (unsigned)Hlim) & ((unsigned)ix < (unsigned)Wlim) & s.live;
                 const unsigned pix = (unsigned)(a_sbp[i] + (iy >> ups) * p.Wi + (ix >> ups));   // meaningless when !ok
@@ -604,7 +608,9 @@ static int launch_cfg4s(hipStream_t st, const GemmParams& p, int kcls_base, int 
             GYRE_FAIL(-6, "gemm: column statistics exist for the 8-wave 256x320 pipelined tile only");
         }
     } else if (p.mode == GEMM_LINEAR) GYRE_GEMM4S_GO(GEMM_LINEAR, 0);
+#ifndef GYRE_GEMM_ABLATIONS
     else if (p.debug & 0x200) GYRE_GEMM4S_GO(GEMM_CONV3, 1);
+#endif
     else GYRE_GEMM4S_GO(GEMM_CONV3, 0);
 #undef GYRE_GEMM4S_GO
     GYRE_LAUNCH_CHECK();
