@@ -75,6 +75,48 @@ def cpu_model_name():
     return "unknown"
 
 
+class ClockSampler:
+    """Shader clock and socket power from rocm-smi, about once per second, on a host thread - informational only: the timed region
+    runs power-limited on this part (profiles/README.md), and the 2.5 PFLOP/s the fractions are priced against assumes 2.4 GHz."""
+
+    def __init__(self):
+        import re, shutil, subprocess, threading
+        self._re, self._sp, self._exe = re, subprocess, shutil.which("rocm-smi")
+        self.samples, self._stop, self._th = [], threading.Event(), None
+        if self._exe:
+            self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                o = self._sp.run([self._exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                c = self._re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", o)
+                w = self._re.search(r"Power \(W\): ([\d.]+)", o)
+                if c and w:
+                    self.samples.append((int(c.group(1)), float(w.group(1))))
+            except Exception:      # noqa: BLE001 - a monitoring hiccup must never touch the measurement
+                pass
+            self._stop.wait(1.0)
+
+    def start(self):
+        if self._th:
+            self._th.start()
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join(timeout=15)
+        s = [x for x in self.samples if x[0] > 500]          # samples taken while the GPU was busy
+        if len(s) < 2:
+            return None
+        clk, pw = statistics.median(a for a, _ in s), statistics.median(b for _, b in s)
+        return {"sclk_mhz_median": clk, "socket_w_median": pw, "samples": len(s),
+                "mfma_peak_at_that_clock_tflops": round(MFMA_PEAK_TFLOPS * clk / 2400.0, 1),
+                "note": "rocm-smi about once per second during the timed region (first GPU of the box): informational - `roofline.peak` "
+                        "and step_mfma_frac stay priced against 2.5 PFLOP/s = 2.4 GHz"}
+
+
 def cpu_baseline():
     """Bounded CPU sample of the same workload with the oracle (kind = "port"): 1 warm-up + median of 3."""
     from gyre_amd import config as gcfg, weights
@@ -257,6 +299,9 @@ def main():
     barrier()
     _lib.prof_enable(None if args.profile_all else ([dom_prefix] if dom_prefix else CANDIDATES))
     step_times = []
+    clocks = ClockSampler() if rank == 0 else None
+    if clocks:
+        clocks.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         s0 = time.perf_counter()
@@ -265,6 +310,7 @@ def main():
         step_times.append(time.perf_counter() - s0)
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_info = clocks.stop() if clocks else None
     prof = _lib.prof_collect()
     _lib.prof_enable([])
     if images is not None:
@@ -431,6 +477,8 @@ def main():
                                        "frac": round(gb / HBM_PEAK_GBPS, 4), "launches": hb[k]["launches"],
                                        "avg_launch_us": round(hb[k]["ms"] * 1e3 / hb[k]["launches"], 2),
                                        "share_of_step_time": round(hb[k]["ms"] / tot, 4)}
+        if clock_info:
+            out["clock_power"] = clock_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:
