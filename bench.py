@@ -3,7 +3,8 @@
 N MI355X of one node (BASELINE.json metric; config 2: batch 8 per GPU, bf16 compute).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: either `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` or the plain line
+   above, which then starts its own N ranks through the same launcher; fewer than N GPUs on the node = exit code 2)
 
 A "step" is one pass of the whole hot path over one batch of synthetic input: CLIP text encode ->
 51 CFG UNet evaluations (batch 16) driven by the DPM-Solver++(2M) sampler -> VAE decode of the 8
@@ -151,6 +152,26 @@ def cpu_baseline():
                       f"{c2:.0f} s/image (value)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec through torch.distributed.run with one rank per GPU on
+    127.0.0.1 and hand its exit code back.  Fails loudly when the node has fewer than N GPUs (BENCH_FORCE_DEVICE, the
+    two-ranks-on-one-GPU test hook, lifts that check)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "BENCH_FORCE_DEVICE" not in os.environ:
+        print(f"bench.py: --gpus {n} asked for but this node shows {have} GPU(s); one rank per GPU is required "
+              f"(no rank was started, nothing was measured)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,13 +193,22 @@ def main():
     n_steps = args.inference_steps or defaults[1]
     size = args.size or defaults[2]
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one rank per GPU is the only form of the N-GPU path, so launch it here
+        # (the same line the driver uses for its scaling run) instead of quietly measuring one GPU
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the torchrun wrapper: "
+                         f"`python bench.py --gpus N` starts its own ranks)")
+    if "BENCH_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node shows {torch.cuda.device_count()} GPU(s): refusing to put two ranks on one device")
     # test hooks (tests/test_gpu_bench_ranks.py runs two ranks on ONE GPU, which RCCL refuses): BENCH_FORCE_DEVICE pins the
     # device index, BENCH_DIST_BACKEND=gloo swaps the collective backend.  The driver sets neither.
     dev_index = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))

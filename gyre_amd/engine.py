@@ -378,7 +378,11 @@ class GyreUnifiedPipeline:
     def _sharded(self, pipe, request, outmask_image=None, image=None):
         from . import images as I
         from .executor import DeviceSlotExecutor
-        if self._executor is None or self._executor.pipelines[0].unet is not self.unet:
+        ex = self._executor
+        if ex is not None and (ex.source.unet is not self.unet or ex.source.vae is not self.vae
+                               or ex.source.inpaint_unet is not self.inpaint_unet or ex.stale(self._shard_devices)):
+            ex = None       # other module objects, new weights (load_state_dict / .to / .half / LoRA) or another device list
+        if ex is None:
             pipe0 = GyrePipeline(self.unet, self.vae, None, device=self.execution_device, inpaint_unet=self.inpaint_unet,
                                  grafted_inpaint=self._grafted_inpaint)
             self._executor = DeviceSlotExecutor.replicate(pipe0, self._shard_devices)

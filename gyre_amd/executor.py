@@ -30,6 +30,21 @@ import torch
 from .pipeline import GyrePipeline
 from .sharding import shard_bounds
 
+def normalize_device(d) -> torch.device:
+    """'cuda' and 'cuda:<current>' are the same slot: give every CUDA device its explicit index."""
+    d = torch.device(d)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return d
+
+
+def weights_key(pipe: GyrePipeline, devices: Sequence):
+    """What a set of replicas was made FROM: the identity and weight version (bumped by load_state_dict, .to()/.half(),
+    _invalidate()) of every native module of ``pipe`` and the normalised device list."""
+    mods = tuple(getattr(pipe, n, None) for n in ("unet", "vae", "inpaint_unet"))
+    return (tuple((id(m), getattr(m, "_weights_version", 0)) for m in mods), tuple(str(normalize_device(d)) for d in devices))
+
+
 _PER_IMAGE = ("text_embeddings", "uncond_embeddings", "input_ids", "negative_ids", "clip_input_ids", "clip_text_embeddings")
 
 
@@ -39,16 +54,19 @@ class DeviceSlotExecutor:
             raise ValueError("at least one pipeline replica is required")
         self.pipelines: List[GyrePipeline] = list(pipelines)
         self.last_unet_evals = 0
+        self.source: Optional[GyrePipeline] = None      # replicate(): the pipeline the replicas were copied from
+        self.source_key = None                          # ... and weights_key() of it at that moment
 
     # ---- construction -------------------------------------------------------------------------------------------------
     @classmethod
     def replicate(cls, pipe: GyrePipeline, devices: Sequence) -> "DeviceSlotExecutor":
         """Weights replicated: ``pipe`` serves the first device (moved there if it lives elsewhere), a deep copy of its
         modules each further one - the reference's ``clone_model`` + ``.to(device)`` per slot (pipeline_wrapper.py:114-131)."""
-        devs = [torch.device(d) for d in devices]
+        devs = [normalize_device(d) for d in devices]
+        home = normalize_device(pipe.device)
         reps = []
         for i, d in enumerate(devs):
-            if i == 0 and torch.device(pipe.device) == d:
+            if d == home and pipe not in reps:          # the source serves its own device wherever it sits in the list
                 reps.append(pipe)
                 continue
             clone = lambda m: None if m is None else copy.deepcopy(m).to(d)
@@ -60,7 +78,16 @@ class DeviceSlotExecutor:
             for attr in ("hires_fix", "hires_threshold_fraction", "hires_oos_fraction", "hires_image_oos_fraction"):
                 if hasattr(pipe, attr):
                     setattr(reps[-1], attr, getattr(pipe, attr))
-        return cls(reps)
+        ex = cls(reps)
+        ex.source, ex.source_key = pipe, weights_key(pipe, devs)
+        return ex
+
+    def stale(self, devices: Optional[Sequence] = None) -> bool:
+        """True when the source modules changed (other objects, new weights, another dtype / device) since replicate()."""
+        if self.source is None:
+            return False
+        devs = devices if devices is not None else [p.device for p in self.pipelines]
+        return weights_key(self.source, devs) != self.source_key
 
     @property
     def world(self) -> int:

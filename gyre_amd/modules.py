@@ -79,11 +79,12 @@ class _NativeModule(nn.Module):
     def _invalidate(self):
         self._dirty = True
         self._ctx_slots = []
+        # monotonically increasing: replicas of this module (executor.DeviceSlotExecutor) compare it to know they are stale
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
 
     def _apply(self, fn, *a, **k):  # .to() / .half() / .cuda(): the native copy is stale afterwards
         r = super()._apply(fn, *a, **k)
-        self._dirty = True
-        self._ctx_slots = []
+        self._invalidate()
         return r
 
     def _destroy(self):

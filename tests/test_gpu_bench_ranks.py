@@ -36,3 +36,28 @@ def test_bench_two_ranks(scaling, batch):
     assert per_rank == ([batch, batch] if scaling == "weak" else [2, 1])       # strong: the reference's batched_seeds split
     assert out["config"]["images_per_step"] == sum(per_rank)
     assert "kernel_classes" in out and out["cpu_baseline"] is None
+
+
+def test_plain_bench_line_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (what the driver's 1-GPU line looks like with N = 2) must run TWO ranks."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--inference-steps", "2",
+           "--batch", "2", "--no-class-table"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["images_per_rank"] == [2, 2]
+    assert "latency_request_split_s" in out
+
+
+def test_plain_bench_line_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert f"--gpus {n}" in r.stderr and "GPU(s)" in r.stderr

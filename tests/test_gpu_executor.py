@@ -96,3 +96,28 @@ def test_engine_option_shard_devices_fans_one_request():
     eng.set_options({"shard_devices": []})
     again, _ = eng(**wrapper_kwargs(generator=generators(seeds), **kw))
     assert torch.equal(one, again)
+
+
+def test_replicas_follow_weight_changes_of_the_engine_modules():
+    """The replica cache is keyed on the source modules' identity AND weight version: after load_state_dict (or .to / .half /
+    a LoRA merge) on the engine's UNet the other slots must not keep generating with the old weights."""
+    import functools
+    from test_gpu_engine import build_engine, generators, sample_dpmpp_2m, wrapper_kwargs
+    ucfg, vcfg = gcfg.tiny_unet(), gcfg.tiny_vae()
+    _, _, eng = build_engine(ucfg, vcfg)
+    eng.scheduler = functools.partial(sample_dpmpp_2m, warmup_lms=True, ddim_cutoff=0.1)
+    prompt, seeds = ["a", "b", "c", "d"], [5, 6, 7, 8]
+    kw = dict(prompt=prompt, width=128, height=128, num_inference_steps=4)
+    eng.set_options({"shard_devices": ["cuda", DEV]})           # 'cuda' and 'cuda:0' are one slot: no clone of the source
+    first, _ = eng(**wrapper_kwargs(generator=generators(seeds), **kw))
+    ex1 = eng._executor
+    assert ex1.pipelines[0].unet is eng.unet
+    again, _ = eng(**wrapper_kwargs(generator=generators(seeds), **kw))
+    assert eng._executor is ex1 and torch.equal(first, again)    # unchanged weights: the replicas are reused
+    sd = {k: v * 1.05 for k, v in eng.unet.state_dict().items()}
+    eng.unet.load_state_dict(sd)
+    sharded, _ = eng(**wrapper_kwargs(generator=generators(seeds), **kw))
+    assert eng._executor is not ex1                              # rebuilt from the new weights
+    eng.set_options({"shard_devices": []})
+    single, _ = eng(**wrapper_kwargs(generator=generators(seeds), **kw))
+    assert torch.equal(sharded, single) and not torch.equal(sharded, first)
