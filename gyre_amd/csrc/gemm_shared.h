@@ -25,3 +25,9 @@ int launch_splitk_reduce(hipStream_t st, const GemmParams& p, int splits);   // 
 // kernels_gemm4s.hip: tile configs 20 (192x320), 21 (256x256), 22 (128x320), 23 (128x256)
 bool gemm4s_supports(const GemmParams& p, int cfg);
 int launch_gemm4s(hipStream_t st, const GemmParams& p, int cfg, int splits);
+
+// kernels_gemm_ar.hip: tile config 30, the A-resident kernel for K = 320 / 640 linear problems (declarations the model runtime
+// needs are in kernels.h)
+bool gemm_ar_supports(const GemmParams& p);
+int launch_gemm_ar(hipStream_t st, const GemmParams& p, const void* wpk);
+int gemm_ar_nsplit(const GemmParams& p);      // N-range splits per row block = partial sums per row in rowstat_out

@@ -114,6 +114,11 @@ struct GemmParams {
     // GroupNorm over the tensor - alone or as one source of a skip concat - finishes mean / rstd from these partials
     // (GnParams::cs_x / cs_x2) and the statistics pass over the tensor disappears.
     float* colstat_out = nullptr; int colstat_unit = 0;
+    // A-resident kernel (kernels_gemm_ar.hip, tile config 30: K = 320 / 640 linear problems).  It reads W from a fragment-ordered
+    // copy: ar_ok = the caller can provide one (the planner only then picks the config; the model runtime packs per handle on
+    // first use and sets w_packed, tests pass a scratch buffer through gyre_debug_set_ar_workspace); no_ar = the caller wants a
+    // feature that kernel lacks from this launch (column statistics for a GroupNorm)
+    const void* w_packed = nullptr; int ar_ok = 0, no_ar = 0;
 };
 // rows per colstat_out row block launch_gemm would use for `p` (p.colstat_unit and p.rows_per_sample set); 0: unsupported
 int gemm_colstat_rows(const GemmParams& p);
@@ -124,6 +129,9 @@ bool gemm_ln_fusable(const GemmParams& p);
 // W'[n][k] = bf16(W[n][k] * gamma[k]); colsum[n] = sum_k W'[n][k]; bias_out[n] = sum_k beta[k] * W[n][k] + (bias ? bias[n] : 0)
 int launch_ln_fold(hipStream_t st, const bf16_t* W, int N, int K, const float* gamma, const float* beta, const float* bias,
                    bf16_t* Wf, float* colsum, float* bias_out);
+// A-resident kernel (tile config 30): bytes of / conversion into the fragment-ordered weight copy it reads (GemmParams::w_packed)
+size_t gemm_ar_packed_bytes(int N, int K);
+int launch_ar_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
 struct GemmPlan { int cfg; int splits; size_t ws_bytes; };

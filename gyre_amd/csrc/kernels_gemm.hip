@@ -1115,6 +1115,8 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
 
 // Tile-config ids (GemmParams::force_cfg): 1 = 4w 128x128, 2 = 4w 256x64, 3 = 4w 64x64,
 // 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256, 8 = 8w 128x160.
+static thread_local void* g_dbg_ar_ws = nullptr;       // gyre_debug_set_ar_workspace: packed-weight scratch of bare gyre_op_* calls
+static thread_local size_t g_dbg_ar_ws_bytes = 0;
 static int pick_cfg(const GemmParams& p, int* splits_out) {
     *splits_out = 1;
     const bool trans = p.out_mode == OUT_BF16_T;
@@ -1133,6 +1135,10 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     consider(3, 0.30, 64, 64, 4);
     consider(1, 0.55, 128, 128, 2);
     consider(2, 0.50, 256, 64, 2);
+    // A-resident kernel (kernels_gemm_ar.hip): K = 320 / 640 linear problems with enough rows to cover the chip keep their
+    // activations in registers and stream only the weights (tuning bit 21: off)
+    if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && !(p.debug & 0x200000) && p.M >= 4096 && gemm_ar_supports(p))
+        return 30;
     if (!trans && p.batch <= 1) {
         // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the
         // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
@@ -1206,6 +1212,7 @@ static thread_local int g_gemm_debug = 0;
 extern "C" int gyre_debug_gemm_ablation(int bits) { int old = g_gemm_debug; g_gemm_debug = bits; return old; }
 extern "C" int gyre_debug_force_gemm_cfg(int cfg) { int old = g_force_cfg; g_force_cfg = cfg; return old; }
 extern "C" int gyre_debug_set_splitk_workspace(void* ws, size_t bytes) { g_dbg_ws = (float*)ws; g_dbg_ws_bytes = bytes; return 0; }
+extern "C" int gyre_debug_set_ar_workspace(void* ws, size_t bytes) { g_dbg_ar_ws = ws; g_dbg_ar_ws_bytes = bytes; return 0; }
 
 static int pick_cfg_nosplit(const GemmParams& p) {
     GemmParams q = p; q.K = q.K < 2048 ? q.K : 2040;  // same tile scoring, split path disabled
@@ -1257,6 +1264,7 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
     if (cfg == 24) return splits == 1 && gemm4s_supports(p, 24);      // pipelined 256x320 tile (kernels_gemm4s.hip)
+    if (cfg == 30) return true;                                        // A-resident kernel (kernels_gemm_ar.hip)
     if (cfg < 4 || cfg > 8 || splits > 1) return false;
     if (p.geglu && (cfg == 4 || cfg == 5 || cfg == 8)) return false;
     if (p.vt_out) {
@@ -1275,6 +1283,7 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     if (!gemm_staged_epilogue_ok(p)) return 0;
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
+    if (cfg == 30) return gemm_ar_nsplit(p);          // A-resident kernel: one partial per N-range split of the row block
     if (cfg < 4 || cfg > 8 || splits > 1) return 0;
     const int bn = (cfg == 4 || cfg == 5) ? 320 : cfg == 8 ? 160 : 256;
     return (p.N + bn - 1) / bn;
@@ -1368,6 +1377,18 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         const int want = splits > 1 ? cs_red_rows(p.rows_per_sample) : cfg == 4 ? 256 : (cfg == 5 || cfg == 8) ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
+    }
+    if (cfg == 30) {
+        if (splits > 1 || !gemm_ar_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the A-resident kernel's domain (K = 320 / 640 linear, bf16 row-major output)");
+        const void* wpk = p.w_packed;
+        if (!wpk) {       // tests / tuning: pack into the caller's scratch buffer on the fly
+            if (!g_dbg_ar_ws || g_dbg_ar_ws_bytes < gemm_ar_packed_bytes(p.N, p.K))
+                GYRE_FAIL(-6, "gemm: the A-resident kernel needs the packed weight copy (GemmParams::w_packed or gyre_debug_set_ar_workspace)");
+            int rc = launch_ar_pack(st, p.W, p.N, p.K, g_dbg_ar_ws);
+            if (rc) return rc;
+            wpk = g_dbg_ar_ws;
+        }
+        return launch_gemm_ar(st, p, wpk);
     }
     if (p.rowstat_out && (cfg < 4 || cfg > 8 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");

@@ -110,6 +110,19 @@ struct Store {
         en.version = weights_version;
         return &en;
     }
+    // fragment-ordered copies of the weights the A-resident GEMM kernel reads (GemmParams::w_packed), keyed by the row-major
+    // matrix they were made from (a plain weight or its LayerNorm-folded copy); same lifetime rules
+    std::unordered_map<const void*, WtEntry> ar_cache;
+    void* ar_lookup(const void* w, size_t bytes, bool* fresh) {
+        WtEntry& en = ar_cache[w];
+        if (!en.p || en.bytes < bytes) {
+            en.p = (bf16_t*)dmalloc(bytes, false);
+            en.bytes = bytes; en.version = 0;
+        }
+        *fresh = en.p && en.version == weights_version;
+        if (en.p) en.version = weights_version;
+        return en.p;
+    }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
     // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
     bf16_t* wt_lookup(const void* w, size_t bytes, bool* fresh) {
@@ -355,6 +368,13 @@ struct Exec {
     int run_gemm(GemmParams& p) {
         if (!p.samples) p.samples = batch;
         GemmPlan pl = gemm_plan(p);
+        if (pl.cfg == 30 && !dry()) {       // A-resident kernel: packed weights, made per handle on first use
+            bool fresh = false;
+            void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh) : nullptr;
+            if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A-resident GEMM");
+            if (!fresh) TRY(launch_ar_pack(st, p.W, p.N, p.K, pk));
+            p.w_packed = pk;
+        }
         Tn ws;
         if (pl.ws_bytes) {
             TRY(alloc_raw(ws, pl.ws_bytes));
@@ -411,6 +431,7 @@ struct Exec {
         p.A = x; p.lda = lda; p.A2 = x2; p.lda2 = lda2; p.C1 = C1; p.mode = GEMM_LINEAR;
         p.W = w; p.K = K; p.N = N; p.M = M; p.bias = bias; p.residual = residual; p.ldr = ldr; p.geglu = geglu;
         p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16;
+        p.ar_ok = store != nullptr; p.no_ar = cs_for != nullptr;      // (the A-resident kernel leaves no column statistics)
         if (cs_for && !rs) TRY(attach_colstats(p, *cs_for, cs_for->H * cs_for->W));
         if (rs) {
             if (!p.samples) p.samples = batch;
@@ -464,7 +485,7 @@ struct Exec {
     int ln_linear(const Tn& x, const LnFold& ln, const bf16_t* w, int N, const float* bias, int geglu, bf16_t* y, int ldc) {
         GemmParams p;
         p.A = x.p; p.lda = x.C; p.mode = GEMM_LINEAR; p.W = w; p.K = x.C; p.N = N; p.M = x.rows(); p.bias = bias; p.geglu = geglu;
-        p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16; p.samples = batch;
+        p.out = y; p.ldc = ldc; p.out_mode = OUT_BF16; p.samples = batch; p.ar_ok = store != nullptr;
         if (ln_fusable(p)) {
             Tn stats;
             TRY(ln_fold_into(p, ln, stats));

@@ -244,6 +244,10 @@ int gyre_debug_force_gemm_cfg(int cfg);
 /* Tests / tuning only: split-K slab space for this thread's gyre_op_* calls (the model handles carve theirs from
  * the caller's workspace).  Without it the single operators run the best single-split configuration. */
 int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
+/* Tests / tuning only: scratch space (N * K * 2 bytes) where this thread's gyre_op_* calls pack the weights for the A-resident
+ * GEMM kernel (tile config 30: K = 320 / 640 linear problems; the model handles keep a packed copy per weight).  With it the
+ * planner may choose that kernel for single operators; NULL / 0 = off. */
+int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
  * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences.  Returns the
@@ -255,7 +259,8 @@ int gyre_debug_force_attn_variant(int v);
  * separate pass (no fold into the consuming GEMM), bit15 = folded LayerNorm takes its row statistics from a separate pass
  * instead of the producing GEMM's epilogue, bit16 = the GEGLU FF1 keeps its separate LayerNorm, bit17 = GroupNorm keeps its own
  * statistics pass (no statistics from the producing conv / GEMM), bit19 = slab-outer GEGLU epilogue of the folded-LayerNorm
- * FF1, bit20 = no statistics epilogue on the 128x160 tile.  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
+ * FF1, bit20 = no statistics epilogue on the 128x160 tile, bit21 = no A-resident kernel (K = 320 / 640 linear problems go to the
+ * 8-wave tiles as before).  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
 int gyre_debug_gemm_ablation(int bits);
 
 /* ---- batch-invariant mode ------------------------------------------------
