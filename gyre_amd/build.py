@@ -103,6 +103,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         base = os.path.basename(src)
         if base in RESOURCE_FILES:
             extra = [*extra, "-Rpass-analysis=kernel-resource-usage"]
+        if os.environ.get("GYRE_AR_ABLATIONS") and base == "kernels_gemm_ar.hip":   # tools/ar_ablate.py
+            extra = [*extra, "-DGYRE_AR_ABLATIONS"]
         if os.environ.get("GYRE_GEMM_ABLATIONS"):      # tuning builds: the main-loop ablation tests of the pipelined kernel (tools/conv_ablate.py)
             extra = [*extra, "-DGYRE_GEMM_ABLATIONS"]
         cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]

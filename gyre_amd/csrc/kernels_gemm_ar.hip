@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void k_ar_pack(const bf16_t* W, int N, int K, 
     out[idx] = *(const uint4*)(W + (size_t)n * K + k);
 }
 
-template <int KT, int NB, bool LNF, bool GEGLU, bool RES, bool RS>
+// ABL: timing ablations (results are garbage; builds with GYRE_AR_ABLATIONS only): 1 = no epilogue arithmetic, 2 = no MFMAs,
+// 4 = no output stores, 8 = no fragment reads (one stale fragment), 16 = no ring requests / waits
+template <int KT, int NB, bool LNF, bool GEGLU, bool RES, bool RS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wpk, int nt_total, int n_split) {
     constexpr int TB = NB * KT * 1024;          // bytes of one N tile = one ring stage
     constexpr int NS = 3;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     auto issue = [&](int tt, int slot) {
         const char* s = wsrc + (size_t)(tt < nt ? tt : 0) * TB;
         const unsigned d = lds0 + slot * TB + w * 1024;
+        if constexpr (ABL & 16) return;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) ar_glds(d + j * 8192, s + j * 8192);
     };
@@ -289,16 +292,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
         wf[1] = *(const bf16x8_t*)(sb + NB * 1024);
         static_for<0, KT>([&](auto ks_c) {
             constexpr int ks = decltype(ks_c)::value;
-            if constexpr (ks + 2 < KT) wf[(ks + 2) % 3] = *(const bf16x8_t*)(sb + (ks + 2) * NB * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % 3], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
+            if constexpr (ks + 2 < KT && !(ABL & 8)) wf[(ks + 2) % 3] = *(const bf16x8_t*)(sb + (ks + 2) * NB * 1024);
+            if constexpr (!(ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(ABL & 8) ? 0 : ks % 3], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
+            else { if constexpr (ks == 0) acc = zero16; asm volatile("" ::"v"(wf[(ABL & 8) ? 0 : ks % 3]), "v"(af[ks])); }
             // KT = 20: a stage behind every MFMA; KT = 40: behind every other one
             constexpr int S = KT == 20 ? ks : ((ks & 1) ? -1 : ks / 2);
-            if constexpr (S >= 0 && S < NSTG) epi_stage(ic<S>{}, gp, pacc, hold, rr, drain_tag);
+            if constexpr (S >= 0 && S < NSTG && !(ABL & 1)) epi_stage(ic<S>{}, gp, pacc, hold, rr, drain_tag);
+            if constexpr (S == 0 && (ABL & 1)) hold[0] = u32x4_t{__float_as_uint(pacc[0]), __float_as_uint(pacc[5]), __float_as_uint(pacc[10]), __float_as_uint(pacc[15])};
             __builtin_amdgcn_sched_barrier(0);
         });
     };
     auto store = [&](int g, const u32x4_t (&hold)[SPB]) {
         if (!mok) return;
+        if constexpr (ABL & 4) { if (hold[0][0] != 0x12345678u) return; }
         bf16_t* o = orow + g * OUTB;
 #pragma unroll
         for (int s = 0; s < SPB; ++s) *(u32x4_t*)(o + 16 * s) = hold[s];
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     using drain = std::true_type;
     // top of tile tt: its stage has landed for every wave; the slot of tile tt-1 is free -> tile tt+2 goes there
     auto top = [&](int tt, int slot_next2) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         __builtin_amdgcn_s_barrier();
     };
     auto nxt = [](int s) { return s == 2 ? 0 : s + 1; };
@@ -442,6 +448,21 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns);                           \
     } while (0)
     const bool lnf = p.ln_colsum != nullptr, rs = p.rowstat_out != nullptr;
+#ifdef GYRE_AR_ABLATIONS
+    if (p.geglu && !lnf && KT == 20 && (p.debug >> 22) & 31) {
+        const int abl = (p.debug >> 22) & 31;
+#define GYRE_AR_ABL(A_)                                                                                                  \
+        if (abl == A_) {                                                                                                 \
+            auto kern = k_gemm_ar<KT, NB, false, true, false, false, A_>;                                                \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns);                       \
+        }
+        GYRE_AR_ABL(1) GYRE_AR_ABL(2) GYRE_AR_ABL(3) GYRE_AR_ABL(4) GYRE_AR_ABL(5) GYRE_AR_ABL(8) GYRE_AR_ABL(16) GYRE_AR_ABL(7) GYRE_AR_ABL(10)
+#undef GYRE_AR_ABL
+        GYRE_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     if (p.geglu) { if (lnf) GYRE_AR_GO(true, true, false, false); else GYRE_AR_GO(false, true, false, false); }
     else if (p.residual) {
         if (rs) GYRE_AR_GO(false, false, true, true);

@@ -22,6 +22,14 @@ elif kind == "linear":
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     for _ in range(5):
         L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), None, 0, vp(y))
+elif kind == "geglu":          # M K F [AR=1: A-resident kernel]
+    M, K, F_ = map(int, sys.argv[2:5])
+    x, w, b = rnd(M, K), rnd(2 * F_, K), torch.zeros(2 * F_, device=DEV)
+    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    arws = torch.empty(2 * F_ * K * 2, dtype=torch.uint8, device=DEV)
+    if os.environ.get("AR"): L.gyre_debug_set_ar_workspace(vp(arws), arws.numel())
+    for _ in range(5):
+        L.gyre_op_linear(st(), vp(x), M, K, vp(w), F_, vp(b), None, 1, vp(y))
 elif kind == "attn":
     B, h, Nq, Nk, D = map(int, sys.argv[2:7])
     Cc = h * D
