@@ -146,15 +146,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     bf16_t* const orow = (bf16_t*)p.out + (size_t)mc * p.ldc + 8 * hi + (size_t)t0 * OUTC;
     const bf16_t* const rrow = RES ? p.residual + (size_t)mc * p.ldr + 8 * hi + (size_t)t0 * OUTC : nullptr;
 
-    // MFMAs of block b of the tile in ring slot `slot`, alone (first block of a workgroup)
-    auto mma_only = [&](int slot, int b, f32x16_t& acc) {
-        const char* sb = smem + slot * TB + b * 1024 + lane * 16;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            const bf16x8_t wf = *(const bf16x8_t*)(sb + ks * NB * 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
-        }
-    };
     // residual rows of block g (local index), requested by hand: the compiler's own vmcnt bookkeeping must not see loads
     // between the ring's requests (it would drain them); consumed behind the counted wait inside the epilogue
     u32x4_t rresA[SPB], rresB[SPB];
@@ -283,25 +274,54 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     auto epi_only = [&](int g, const f32x16_t& acc, u32x4_t (&hold)[SPB], u32x4_t (&rr)[SPB], auto drain_tag) {
         static_for<0, NSTG>([&](auto s_c) { epi_stage(s_c, g, acc, hold, rr, drain_tag); });
     };
-    // MFMAs of block b of the tile in ring slot `slot` into `acc`, with the epilogue of block gp (accumulators `pacc`) in the gaps
-    auto fused = [&](int slot, int b, f32x16_t& acc, int gp, const f32x16_t& pacc, u32x4_t (&hold)[SPB], u32x4_t (&rr)[SPB],
-                     auto drain_tag) {
-        const char* sb = smem + slot * TB + b * 1024 + lane * 16;
-        bf16x8_t wf[3];
-        wf[0] = *(const bf16x8_t*)(sb);
-        wf[1] = *(const bf16x8_t*)(sb + NB * 1024);
-        static_for<0, KT>([&](auto ks_c) {
-            constexpr int ks = decltype(ks_c)::value;
-            if constexpr (ks + 2 < KT && !(ABL & 8)) wf[(ks + 2) % 3] = *(const bf16x8_t*)(sb + (ks + 2) * NB * 1024);
-            if constexpr (!(ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(ABL & 8) ? 0 : ks % 3], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
-            else { if constexpr (ks == 0) acc = zero16; asm volatile("" ::"v"(wf[(ABL & 8) ? 0 : ks % 3]), "v"(af[ks])); }
-            // KT = 20: a stage behind every MFMA; KT = 40: behind every other one
-            constexpr int S = KT == 20 ? ks : ((ks & 1) ? -1 : ks / 2);
-            if constexpr (S >= 0 && S < NSTG && !(ABL & 1)) epi_stage(ic<S>{}, gp, pacc, hold, rr, drain_tag);
-            if constexpr (S == 0 && (ABL & 1)) hold[0] = u32x4_t{__float_as_uint(pacc[0]), __float_as_uint(pacc[5]), __float_as_uint(pacc[10]), __float_as_uint(pacc[15])};
+    using no_drain = std::false_type;
+    using drain = std::true_type;
+    // One ring stage = NB * KT = 40 MFMAs, issued as ONE stream: the weight fragment of stage i + PF is requested from LDS
+    // while stage i's MFMA issues (the two waves of a SIMD run the same code between the same barriers, so a wave's exposed
+    // LDS latency is not covered by its partner: with a prefetch distance of 2 the fragment reads and the MFMAs simply added
+    // up, 44 + 43 us of the 64x64 FF1 - tools/ar_ablate.py), and behind each MFMA sits one stage of the previous block's
+    // epilogue.
+    //   NB == 2: stages 0 .. KT-1 = block g (accumulators `a0`) beside the epilogue of block g - 1 (`a1`, when HAS_PREV),
+    //            stages KT .. 2 KT-1 = block g + 1 (`a1`) beside the epilogue of block g (`a0`)
+    //   NB == 1: the stage's single block (`a0`) beside the epilogue of block g - 1 (`a1`), one stage every other MFMA
+    constexpr int PF = KT == 20 ? 6 : 3, RING = KT == 20 ? 8 : 4, NSTREAM = NB * KT;   // (K = 640: the A slab leaves no registers for more)
+    auto fused_tile = [&](int slot, int g, f32x16_t& a0, f32x16_t& a1, u32x4_t (&h0)[SPB], u32x4_t (&h1)[SPB], u32x4_t (&r0)[SPB],
+                          u32x4_t (&r1)[SPB], auto has_prev_tag) {
+        constexpr bool HAS_PREV = decltype(has_prev_tag)::value;
+        const char* sb = smem + slot * TB + lane * 16;
+        bf16x8_t wf[RING];
+        auto frag_off = [](int i) { return NB == 2 ? ((i % KT) * 2 + i / KT) * 1024 : i * 1024; };
+        static_for<0, PF>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            wf[i % RING] = *(const bf16x8_t*)(sb + frag_off(i));
+        });
+        static_for<0, NSTREAM>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            constexpr int b = NB == 2 ? i / KT : 0, ks = NB == 2 ? i % KT : i;
+            if constexpr (i + PF < NSTREAM && !(ABL & 8)) wf[(i + PF) % RING] = *(const bf16x8_t*)(sb + frag_off(i + PF));
+            f32x16_t& acc = b == 0 ? a0 : a1;
+            constexpr int fi = (ABL & 8) ? 0 : i % RING;
+            if constexpr (!(ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
+            else { if constexpr (ks == 0) acc = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }
+            if constexpr (NB == 2) {
+                if constexpr (b == 0) {
+                    if constexpr (HAS_PREV && ks < NSTG && !(ABL & 1)) epi_stage(ic<ks>{}, g - 1, a1, h1, r1, no_drain{});
+                } else {
+                    if constexpr (ks < NSTG && !(ABL & 1)) epi_stage(ic<ks>{}, g, a0, h0, r0, no_drain{});
+                }
+                if constexpr (ks == 0 && (ABL & 1)) {
+                    if constexpr (b == 0) h1[0] = u32x4_t{__float_as_uint(a1[0]), __float_as_uint(a1[5]), __float_as_uint(a1[10]), __float_as_uint(a1[15])};
+                    else h0[0] = u32x4_t{__float_as_uint(a0[0]), __float_as_uint(a0[5]), __float_as_uint(a0[10]), __float_as_uint(a0[15])};
+                }
+            } else {
+                constexpr int S = (i & 1) ? -1 : i / 2;
+                if constexpr (HAS_PREV && S >= 0 && S < NSTG && !(ABL & 1)) epi_stage(ic<S>{}, g - 1, a1, h1, r1, no_drain{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    using has_prev = std::true_type;
+    using no_prev = std::false_type;
     auto store = [&](int g, const u32x4_t (&hold)[SPB]) {
         if (!mok) return;
         if constexpr (ABL & 4) { if (hold[0][0] != 0x12345678u) return; }
@@ -309,8 +329,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
 #pragma unroll
         for (int s = 0; s < SPB; ++s) *(u32x4_t*)(o + 16 * s) = hold[s];
     };
-    using no_drain = std::false_type;
-    using drain = std::true_type;
     // top of tile tt: its stage has landed for every wave; the slot of tile tt-1 is free -> tile tt+2 goes there
     auto top = [&](int tt, int slot_next2) {
         if constexpr (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -323,24 +341,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     // Block pairs (2q -> accA, 2q + 1 -> accB).  Pair q: [top] mma(2q) | epi(2q - 1)  ;  [top when NB == 1] mma(2q + 1) | epi(2q)
     // The stores of a block's outputs and the residual request of the NEXT epilogue go right behind a barrier, followed by
     // the tile request, so that a whole tile time lies between them and the counted wait they take part in.
-    int slot = 0;                                // ring slot of the tile the next block belongs to
-    if constexpr (NB == 2) res_issue(0, rresA);  // consumed by epi(0) below: older than tile 2's request, so that wait is counted
-    issue(2, 2);                                 // (tiles 0 and 1 are resident: prologue)
-    mma_only(0, 0, accA);                        // block 0
-    int g = 1;
+    int slot = 1;                                // ring slot of the tile the next block belongs to
     if constexpr (NB == 2) {
-        // block 1 belongs to tile 0
-        fused(0, 1, accB, 0, accA, holdA, rresA, no_drain{});
-        slot = 1; g = 2;
-        for (; g + 1 < nblk; g += 2) {           // tile g / 2: blocks g (accA) and g + 1 (accB)
+        // tile tt = blocks 2 tt (accA / holdA / rresA) and 2 tt + 1 (accB / holdB / rresB)
+        res_issue(0, rresA);                     // consumed by the epilogue of block 0 inside tile 0's stream: older than tile 2's request
+        issue(2, 2);                             // (tiles 0 and 1 are resident: prologue)
+        fused_tile(0, 0, accA, accB, holdA, holdB, rresA, rresB, no_prev{});
+        int g = 2;
+        for (; g < nblk; g += 2) {
             top(g >> 1, prv(slot));
             store(g - 2, holdA);
             if (g >= 4) store(g - 3, holdB);
             res_issue(g - 1, rresB);
             res_issue(g, rresA);
             issue((g >> 1) + 2, prv(slot));
-            fused(slot, 0, accA, g - 1, accB, holdB, rresB, no_drain{});
-            fused(slot, 1, accB, g, accA, holdA, rresA, no_drain{});
+            fused_tile(slot, g, accA, accB, holdA, holdB, rresA, rresB, has_prev{});
             slot = nxt(slot);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // past-the-end requests: nothing may land in LDS after the wave exits
@@ -350,19 +365,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
         epi_only(nblk - 1, accB, holdB, rresB, drain{});
         store(nblk - 1, holdB);
     } else {
-        slot = 1;
+        // tile = block: even blocks in accA / holdA / rresA, odd ones in accB / holdB / rresB
+        issue(2, 2);
+        fused_tile(0, 0, accA, accB, holdA, holdB, rresA, rresB, no_prev{});
+        int g = 1;
         for (; g + 1 < nblk; g += 2) {
             top(g, prv(slot));
             if (g >= 2) store(g - 2, holdB);
             res_issue(g - 1, rresA);
             issue(g + 2, prv(slot));
-            fused(slot, 0, accB, g - 1, accA, holdA, rresA, no_drain{});
+            fused_tile(slot, g, accB, accA, holdB, holdA, rresB, rresA, has_prev{});
             slot = nxt(slot);
             top(g + 1, prv(slot));
             store(g - 1, holdA);
             res_issue(g, rresB);
             issue(g + 3, prv(slot));
-            fused(slot, 0, accA, g, accB, holdB, rresB, no_drain{});
+            fused_tile(slot, g + 1, accA, accB, holdA, holdB, rresA, rresB, has_prev{});
             slot = nxt(slot);
         }
         bool lastB = false;
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
             if (g >= 2) store(g - 2, holdB);
             res_issue(g - 1, rresA);
             issue(g + 2, prv(slot));
-            fused(slot, 0, accB, g - 1, accA, holdA, rresA, no_drain{});
+            fused_tile(slot, g, accB, accA, holdB, holdA, rresB, rresA, has_prev{});
             lastB = true;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,7 +417,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
 // ---------------------------------------------------------------------------------------------------------------------------
 bool gemm_ar_supports(const GemmParams& p) {
     if (p.mode != GEMM_LINEAR || p.out_mode != OUT_BF16 || p.batch > 1) return false;
-    if (p.K != 320 && p.K != 640) return false;
+    // K = 640: the A slab takes 160 registers; only the GEGLU FF1 (the layer that gains most) has a form that fits without spills
+    if (p.K != 320 && !(p.K == 640 && p.geglu)) return false;
     if (p.A2 && p.A2 != p.A) return false;
     if (p.rowbias || p.vt_out || p.colstat_out) return false;
     const int tnw = p.K == 320 ? 64 : 32;
@@ -464,14 +483,16 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
     }
 #endif
     if (p.geglu) { if (lnf) GYRE_AR_GO(true, true, false, false); else GYRE_AR_GO(false, true, false, false); }
-    else if (p.residual) {
-        if (rs) GYRE_AR_GO(false, false, true, true);
-        else GYRE_AR_GO(false, false, true, false);
-    } else {
-        if (lnf) GYRE_AR_GO(true, false, false, false);
-        else if (rs) GYRE_AR_GO(false, false, false, true);
-        else GYRE_AR_GO(false, false, false, false);
-    }
+    else if constexpr (KT == 20) {
+        if (p.residual) {
+            if (rs) GYRE_AR_GO(false, false, true, true);
+            else GYRE_AR_GO(false, false, true, false);
+        } else {
+            if (lnf) GYRE_AR_GO(true, false, false, false);
+            else if (rs) GYRE_AR_GO(false, false, false, true);
+            else GYRE_AR_GO(false, false, false, false);
+        }
+    } else GYRE_FAIL(-6, "gemm: at K = 640 the A-resident kernel exists for the GEGLU form only");
 #undef GYRE_AR_GO
     GYRE_LAUNCH_CHECK();
     return 0;

@@ -66,6 +66,3 @@ for B in (16, 2):
     case("64x64 to_out + residual", B * 4096, 320, 320, res=True)
     case("64x64 Q|K|V as plain N=960", B * 4096, 320, 960)
     case("32x32 GEGLU FF1", B * 1024, 640, 2560, geglu=True)
-    case("32x32 to_q / proj_in", B * 1024, 640, 640)
-    case("32x32 to_out + residual", B * 1024, 640, 640, res=True)
-    case("32x32 Q|K|V as plain N=1920", B * 1024, 640, 1920)
