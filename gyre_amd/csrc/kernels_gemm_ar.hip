@@ -136,11 +136,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tiles 0 and 1 landed (and every prologue load above)
     __syncthreads();                                     // ... for every wave; constants visible
 
-    // Two accumulator blocks (32 weight rows x 32 output rows each) alternate: while the MFMAs of block g run into one, the
-    // epilogue arithmetic of block g-1 reads the other (same basic block: the scheduler interleaves the two streams)
+    // Accumulator blocks (32 weight rows x 32 output rows each).  NB == 1 (K = 640): two blocks alternate - while the MFMAs of
+    // block g run into one, the epilogue arithmetic of block g-1 reads the other.  NB == 2 (K = 320): two SETS of two blocks
+    // alternate per ring stage, and inside a stage consecutive MFMAs go to different blocks: a v_mfma whose C operand is the
+    // result of the MFMA issued just before it runs at full rate only when NOTHING is issued between the two - with the
+    // epilogue's vector instructions in the gaps every dependent MFMA held the matrix pipe ~40 cycles longer, for both waves
+    // of the SIMD (tools/ar_ablate.py: 130 - 160 cycles per MFMA stage instead of 64)
     f32x16_t accA, accB;
+    f32x16_t accX[2], accY[2];
     constexpr int SPB = GEGLU ? 1 : 2;          // 16-byte stores per lane and block
     u32x4_t holdA[SPB], holdB[SPB];             // rounded outputs of the last even / odd block, stored behind the next barrier
+    u32x4_t holdX[2][SPB], holdY[2][SPB];       // NB == 2: ... of the two blocks of the last even / odd tile
     const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int OUTB = GEGLU ? 16 : 32;       // output columns per block
     bf16_t* const orow = (bf16_t*)p.out + (size_t)mc * p.ldc + 8 * hi + (size_t)t0 * OUTC;
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     // residual rows of block g (local index), requested by hand: the compiler's own vmcnt bookkeeping must not see loads
     // between the ring's requests (it would drain them); consumed behind the counted wait inside the epilogue
     u32x4_t rresA[SPB], rresB[SPB];
+    u32x4_t rresX[2][SPB], rresY[2][SPB];
     auto res_issue = [&](int g, u32x4_t (&rr)[SPB]) {
         if constexpr (RES) {
             const bf16_t* r0 = rrow + g * OUTB;
@@ -322,6 +329,37 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     };
     using has_prev = std::true_type;
     using no_prev = std::false_type;
+    // NB == 2: one ring stage = 2 blocks x KT MFMAs as ONE stream in fragment order (k step outer, block inner: consecutive MFMAs
+    // write different accumulators), the fragment of stage i + PF2 requested while stage i issues, and behind every MFMA one
+    // stage of the PREVIOUS tile's epilogue (block 0 behind MFMAs 0 .., block 1 behind MFMAs KT ..)
+    constexpr int PF2 = (RES && RS) ? 4 : 6, RING2 = 8;
+    auto fused_tile2 = [&](int slot, int gp, f32x16_t (&cur)[2], f32x16_t (&prev)[2], u32x4_t (&hp)[2][SPB], u32x4_t (&rp)[2][SPB],
+                           auto has_prev_tag) {
+        constexpr bool HAS_PREV = decltype(has_prev_tag)::value;
+        const char* sb = smem + slot * TB + lane * 16;
+        bf16x8_t wf[RING2];
+        static_for<0, PF2>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            wf[i % RING2] = *(const bf16x8_t*)(sb + i * 1024);
+        });
+        static_for<0, 2 * KT>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            constexpr int ks = i >> 1, b = i & 1;
+            if constexpr (i + PF2 < 2 * KT && !(ABL & 8)) wf[(i + PF2) % RING2] = *(const bf16x8_t*)(sb + (i + PF2) * 1024);
+            constexpr int fi = (ABL & 8) ? 0 : i % RING2;
+            if constexpr (!(ABL & 2)) cur[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : cur[b], 0, 0, 0);
+            else { if constexpr (ks == 0) cur[b] = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }
+            if constexpr (HAS_PREV && !(ABL & 1)) {
+                if constexpr (i < NSTG) epi_stage(ic<i>{}, gp, prev[0], hp[0], rp[0], no_drain{});
+                else if constexpr (i >= KT && i - KT < NSTG) epi_stage(ic<i - KT>{}, gp + 1, prev[1], hp[1], rp[1], no_drain{});
+            }
+            if constexpr (HAS_PREV && (ABL & 1) && (i == 0 || i == KT)) {
+                constexpr int q = i == 0 ? 0 : 1;
+                hp[q][0] = u32x4_t{__float_as_uint(prev[q][0]), __float_as_uint(prev[q][5]), __float_as_uint(prev[q][10]), __float_as_uint(prev[q][15])};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
     auto store = [&](int g, const u32x4_t (&hold)[SPB]) {
         if (!mok) return;
         if constexpr (ABL & 4) { if (hold[0][0] != 0x12345678u) return; }
@@ -343,27 +381,48 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     // the tile request, so that a whole tile time lies between them and the counted wait they take part in.
     int slot = 1;                                // ring slot of the tile the next block belongs to
     if constexpr (NB == 2) {
-        // tile tt = blocks 2 tt (accA / holdA / rresA) and 2 tt + 1 (accB / holdB / rresB)
-        res_issue(0, rresA);                     // consumed by the epilogue of block 0 inside tile 0's stream: older than tile 2's request
+        // tile tt = blocks 2 tt, 2 tt + 1; even tiles use set X, odd tiles set Y.  body(tt): [top] store the outputs of tile
+        // tt - 2 (they sit in this tile's own set), request the residual rows of tile tt - 1 and ring stage tt + 2, then the
+        // MFMAs of tile tt beside the epilogue of tile tt - 1
+        auto store2 = [&](int tt, const u32x4_t (&h)[2][SPB]) { store(2 * tt, h[0]); store(2 * tt + 1, h[1]); };
+        auto body = [&](int tt, int slot_, f32x16_t (&cur)[2], f32x16_t (&prev)[2], u32x4_t (&hc)[2][SPB], u32x4_t (&hp)[2][SPB],
+                        u32x4_t (&rp)[2][SPB]) {
+            top(tt, prv(slot_));
+            if (tt >= 2) store2(tt - 2, hc);
+            res_issue(2 * tt - 2, rp[0]);
+            res_issue(2 * tt - 1, rp[1]);
+            issue(tt + 2, prv(slot_));
+            fused_tile2(slot_, 2 * tt - 2, cur, prev, hp, rp, has_prev{});
+        };
         issue(2, 2);                             // (tiles 0 and 1 are resident: prologue)
-        fused_tile(0, 0, accA, accB, holdA, holdB, rresA, rresB, no_prev{});
-        int g = 2;
-        for (; g < nblk; g += 2) {
-            top(g >> 1, prv(slot));
-            store(g - 2, holdA);
-            if (g >= 4) store(g - 3, holdB);
-            res_issue(g - 1, rresB);
-            res_issue(g, rresA);
-            issue((g >> 1) + 2, prv(slot));
-            fused_tile(slot, g, accA, accB, holdA, holdB, rresA, rresB, has_prev{});
+        fused_tile2(0, 0, accX, accY, holdY, rresY, no_prev{});
+        int tt = 1;
+        for (; tt + 1 < nt; tt += 2) {
+            body(tt, slot, accY, accX, holdY, holdX, rresX);
+            slot = nxt(slot);
+            body(tt + 1, slot, accX, accY, holdX, holdY, rresY);
             slot = nxt(slot);
         }
+        bool lastY = false;
+        if (tt < nt) {
+            body(tt, slot, accY, accX, holdY, holdX, rresX);
+            lastY = true;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // past-the-end requests: nothing may land in LDS after the wave exits
-        store(nblk - 2, holdA);
-        if (nblk >= 4) store(nblk - 3, holdB);
-        res_issue(nblk - 1, rresB);
-        epi_only(nblk - 1, accB, holdB, rresB, drain{});
-        store(nblk - 1, holdB);
+        // pending: the outputs of tile nt - 2 (in hold of the set that is NOT the last tile's), tile nt - 1 in its accumulators
+        if (lastY) {
+            store2(nt - 2, holdX);
+            res_issue(2 * nt - 2, rresY[0]); res_issue(2 * nt - 1, rresY[1]);
+            epi_only(2 * nt - 2, accY[0], holdY[0], rresY[0], drain{});
+            epi_only(2 * nt - 1, accY[1], holdY[1], rresY[1], drain{});
+            store2(nt - 1, holdY);
+        } else {
+            if (nt >= 2) store2(nt - 2, holdY);
+            res_issue(2 * nt - 2, rresX[0]); res_issue(2 * nt - 1, rresX[1]);
+            epi_only(2 * nt - 2, accX[0], holdX[0], rresX[0], drain{});
+            epi_only(2 * nt - 1, accX[1], holdX[1], rresX[1], drain{});
+            store2(nt - 1, holdX);
+        }
     } else {
         // tile = block: even blocks in accA / holdA / rresA, odd ones in accB / holdB / rresB
         issue(2, 2);
