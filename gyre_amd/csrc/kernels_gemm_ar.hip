@@ -332,7 +332,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     // NB == 2: one ring stage = 2 blocks x KT MFMAs as ONE stream in fragment order (k step outer, block inner: consecutive MFMAs
     // write different accumulators), the fragment of stage i + PF2 requested while stage i issues, and behind every MFMA one
     // stage of the PREVIOUS tile's epilogue (block 0 behind MFMAs 0 .., block 1 behind MFMAs KT ..)
-    constexpr int PF2 = (RES && RS) ? 4 : 6, RING2 = 8;
+    // (tuning variants, valid results: ABL & 32 = fragment request pinned in FRONT of the stage's MFMA, & 64 = 10-deep prefetch,
+    //  & 128 = the second wave of every SIMD at s_setprio 1, & 256 = the epilogue stage in front of the MFMA)
+    constexpr int PF2 = (ABL & 64) ? 10 : (RES && RS) ? 4 : 6, RING2 = (ABL & 64) ? 12 : 8;
+    if constexpr (ABL & 128) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     auto fused_tile2 = [&](int slot, int gp, f32x16_t (&cur)[2], f32x16_t (&prev)[2], u32x4_t (&hp)[2][SPB], u32x4_t (&rp)[2][SPB],
                            auto has_prev_tag) {
         constexpr bool HAS_PREV = decltype(has_prev_tag)::value;
@@ -346,13 +349,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
             constexpr int i = decltype(i_c)::value;
             constexpr int ks = i >> 1, b = i & 1;
             if constexpr (i + PF2 < 2 * KT && !(ABL & 8)) wf[(i + PF2) % RING2] = *(const bf16x8_t*)(sb + (i + PF2) * 1024);
+            if constexpr (ABL & 32) __builtin_amdgcn_sched_barrier(0);
             constexpr int fi = (ABL & 8) ? 0 : i % RING2;
-            if constexpr (!(ABL & 2)) cur[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : cur[b], 0, 0, 0);
-            else { if constexpr (ks == 0) cur[b] = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }
+#define GYRE_AR_MFMA()                                                                                                          \
+            do {                                                                                                                \
+                if constexpr (!(ABL & 2)) cur[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : cur[b], 0, 0, 0); \
+                else { if constexpr (ks == 0) cur[b] = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }                   \
+            } while (0)
+            if constexpr (!(ABL & 256)) GYRE_AR_MFMA();
             if constexpr (HAS_PREV && !(ABL & 1)) {
                 if constexpr (i < NSTG) epi_stage(ic<i>{}, gp, prev[0], hp[0], rp[0], no_drain{});
                 else if constexpr (i >= KT && i - KT < NSTG) epi_stage(ic<i - KT>{}, gp + 1, prev[1], hp[1], rp[1], no_drain{});
             }
+            if constexpr (ABL & 256) { __builtin_amdgcn_sched_barrier(0); GYRE_AR_MFMA(); }
+#undef GYRE_AR_MFMA
             if constexpr (HAS_PREV && (ABL & 1) && (i == 0 || i == KT)) {
                 constexpr int q = i == 0 ? 0 : 1;
                 hp[q][0] = u32x4_t{__float_as_uint(prev[q][0]), __float_as_uint(prev[q][5]), __float_as_uint(prev[q][10]), __float_as_uint(prev[q][15])};
@@ -527,8 +537,8 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
     } while (0)
     const bool lnf = p.ln_colsum != nullptr, rs = p.rowstat_out != nullptr;
 #ifdef GYRE_AR_ABLATIONS
-    if (p.geglu && !lnf && KT == 20 && (p.debug >> 22) & 31) {
-        const int abl = (p.debug >> 22) & 31;
+    if (p.geglu && !lnf && KT == 20 && (p.debug >> 22) & 1023) {
+        const int abl = (p.debug >> 22) & 1023;
 #define GYRE_AR_ABL(A_)                                                                                                  \
         if (abl == A_) {                                                                                                 \
             auto kern = k_gemm_ar<KT, NB, false, true, false, false, A_>;                                                \
@@ -536,6 +546,7 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns);                       \
         }
         GYRE_AR_ABL(1) GYRE_AR_ABL(2) GYRE_AR_ABL(3) GYRE_AR_ABL(4) GYRE_AR_ABL(5) GYRE_AR_ABL(8) GYRE_AR_ABL(16) GYRE_AR_ABL(7) GYRE_AR_ABL(10)
+        GYRE_AR_ABL(32) GYRE_AR_ABL(64) GYRE_AR_ABL(96) GYRE_AR_ABL(128) GYRE_AR_ABL(256) GYRE_AR_ABL(160) GYRE_AR_ABL(13) GYRE_AR_ABL(12) GYRE_AR_ABL(37) GYRE_AR_ABL(69)
 #undef GYRE_AR_ABL
         GYRE_LAUNCH_CHECK();
         return 0;

@@ -18,9 +18,12 @@ ev_a = torch.empty(160 << 20, dtype=torch.uint8, device=DEV); ev_b = torch.empty
 L.gyre_debug_set_ar_workspace(vp(arws), arws.numel())
 run = lambda: _lib.check(L.gyre_op_linear(st(), vp(x), M, K, vp(w), F_, vp(b), None, 1, vp(y)))
 names = {0: "full", 1: "no epilogue arithmetic", 2: "no MFMA", 3: "no epilogue, no MFMA", 4: "no stores", 5: "no epilogue, no stores",
-         8: "no fragment reads", 16: "no ring requests / waits", 7: "no epilogue / MFMA / stores", 10: "no MFMA, no fragment reads"}
+         8: "no fragment reads", 16: "no ring requests / waits", 7: "no epilogue / MFMA / stores", 10: "no MFMA, no fragment reads",
+         13: "MFMA only (no epilogue / reads / stores)", 12: "MFMA + epilogue (no reads / stores)",
+         32: "V: read pinned before MFMA", 64: "V: prefetch 10", 96: "V: read first + prefetch 10", 128: "V: setprio 1 on waves 4-7",
+         256: "V: epilogue stage before MFMA", 160: "V: read first + setprio", 37: "no epi/stores, read first", 69: "no epi/stores, prefetch 10"}
 for cold in (False, True):
-    for abl in (0, 1, 2, 3, 4, 5, 8, 16, 7, 10, 0):
+    for abl in ((0, 1, 2, 3, 4, 5, 8, 16, 7, 10, 13, 12, 0, 32, 64, 96, 128, 256, 160, 37, 69, 0) if not cold else (0, 32, 64, 96, 128, 256, 160, 0)):
         L.gyre_debug_gemm_ablation(abl << 22)
         run(); torch.cuda.synchronize()
         ts = []
