@@ -1137,7 +1137,11 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     consider(2, 0.50, 256, 64, 2);
     // A-resident kernel (kernels_gemm_ar.hip): K = 320 / 640 linear problems with enough rows to cover the chip keep their
     // activations in registers and stream only the weights (tuning bit 21: off)
-    if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && !(p.debug & 0x200000) && p.M >= 4096 && gemm_ar_supports(p))
+    // Taken where the N sweep is long enough to amortise the slab load (GEGLU FF1: N = 8 C, 216 -> 129 us at 64x64, 163 -> 124
+    // at 32x32; a plain N = 3 C: 80 -> 62 us).  The C x C projections (5 N tiles per workgroup) are HBM-bound either way and
+    // measured 5 - 7 % slower here (33 -> 35 us): they stay on the 8-wave tiles unless tuning bit 22 asks for them.
+    if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && !(p.debug & 0x200000) && p.M >= 4096 &&
+        (p.N >= 3 * p.K || (p.debug & 0x400000)) && gemm_ar_supports(p))
         return 30;
     if (!trans && p.batch <= 1) {
         // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the

@@ -537,8 +537,8 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
     } while (0)
     const bool lnf = p.ln_colsum != nullptr, rs = p.rowstat_out != nullptr;
 #ifdef GYRE_AR_ABLATIONS
-    if (p.geglu && !lnf && KT == 20 && (p.debug >> 22) & 1023) {
-        const int abl = (p.debug >> 22) & 1023;
+    if (p.geglu && !lnf && KT == 20 && (p.debug >> 23) & 511) {
+        const int abl = (p.debug >> 23) & 511;
 #define GYRE_AR_ABL(A_)                                                                                                  \
         if (abl == A_) {                                                                                                 \
             auto kern = k_gemm_ar<KT, NB, false, true, false, false, A_>;                                                \

@@ -30,6 +30,7 @@ def ar():
     def switch(on):
         torch.cuda.synchronize()
         L.gyre_debug_set_ar_workspace(vp(ws) if on else None, ws.numel() if on else 0)
+        L.gyre_debug_gemm_ablation(0x400000 if on else 0)      # bit 22: the planner takes config 30 for the C x C projections too
     yield switch
     switch(False)
 

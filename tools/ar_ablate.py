@@ -24,7 +24,7 @@ names = {0: "full", 1: "no epilogue arithmetic", 2: "no MFMA", 3: "no epilogue, 
          256: "V: epilogue stage before MFMA", 160: "V: read first + setprio", 37: "no epi/stores, read first", 69: "no epi/stores, prefetch 10"}
 for cold in (False, True):
     for abl in ((0, 1, 2, 3, 4, 5, 8, 16, 7, 10, 13, 12, 0, 32, 64, 96, 128, 256, 160, 37, 69, 0) if not cold else (0, 32, 64, 96, 128, 256, 160, 0)):
-        L.gyre_debug_gemm_ablation(abl << 22)
+        L.gyre_debug_gemm_ablation(abl << 23)
         run(); torch.cuda.synchronize()
         ts = []
         for _ in range(10):

@@ -50,9 +50,11 @@ def case(name, M, K, N, geglu=False, res=False, ln=False):
     for on in (False, True):
         torch.cuda.synchronize()
         L.gyre_debug_set_ar_workspace(vp(arws) if on else None, arws.numel() if on else 0)
+        L.gyre_debug_gemm_ablation(0x400000 if on else 0)
         run(); torch.cuda.synchronize()
         out.append(timeit(run))
     L.gyre_debug_set_ar_workspace(None, 0)
+    L.gyre_debug_gemm_ablation(0)
     fl = 2.0 * M * rows * K
     print(f"{name:34s} M={M:6d} K={K:4d} N={rows:5d}  tiles {out[0]:7.1f} us ({fl / out[0] / 1e6:6.0f} TF/s)   "
           f"a-resident {out[1]:7.1f} us ({fl / out[1] / 1e6:6.0f} TF/s)   x{out[0] / out[1]:.2f}", flush=True)
