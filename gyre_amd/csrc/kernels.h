@@ -39,6 +39,9 @@ int gn_pick_chunks(int B, int HW, int C);
 // 0 = off; n > 0: plan every split-K factor as if the batch held n samples (results then do not depend on B)
 int gemm_set_batch_invariant(int canonical_samples);
 int gemm_get_batch_invariant();
+// everything thread-local the planner's choices depend on (tuning flags, forced config, batch-invariant size, packed-weight
+// scratch) folded into one value: callers that memoise plans key on it
+long gemm_planner_state();
 int launch_groupnorm_stats(hipStream_t st, const GnParams& p);   // partial sums + finalize -> scale_shift
 int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+b)
 bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch path for small feature maps

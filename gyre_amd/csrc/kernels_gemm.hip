@@ -1234,6 +1234,9 @@ static int pick_cfg_nosplit(const GemmParams& p) {
 static thread_local int g_invariant_batch = 0;
 int gemm_set_batch_invariant(int n) { const int old = g_invariant_batch; g_invariant_batch = n < 0 ? 0 : n; return old; }
 int gemm_get_batch_invariant() { return g_invariant_batch; }
+long gemm_planner_state() {
+    return (long)(unsigned)g_gemm_debug | ((long)(g_force_cfg & 0xffff) << 32) | ((long)(g_invariant_batch & 0xfff) << 48) | ((long)(g_dbg_ar_ws ? 1 : 0) << 60);
+}
 
 static int plan_cfg(const GemmParams& p, int* splits) {
     const int inv = g_invariant_batch;

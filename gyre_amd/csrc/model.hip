@@ -98,16 +98,28 @@ int gyre_unet_finalize(gyre_unet* h, void* st) {
 size_t gyre_unet_workspace_bytes(gyre_unet* h, int B, int H, int W, int S) {
     if (!h) return 0;
     // the maximum over the forms a forward of this shape can take: text context passed or cached, CFG halves sharing their
-    // prefix or not (gyre_unet_hint_cfg_pairs) - the hints arrive after the caller sized its workspace
-    size_t peak = 0;
+    // prefix or not (gyre_unet_hint_cfg_pairs) - the hints arrive after the caller sized its workspace.
+    // The module shell asks before EVERY forward: the answer is memoised per (shape, ToMe, context form, planner state of the
+    // calling thread) - two to four dry passes of the whole graph otherwise - and a dry pass leaves the handle's hints alone.
     const bool cached_too = h->cur().valid && h->cur().B == B && h->cur().S == S;
-    for (int cached = 0; cached <= (cached_too ? 1 : 0); ++cached)
-        for (int pairs = 0; pairs <= 1; ++pairs) {
+    const std::array<long, 7> key{B, H, W, S, h->ex.tome_r, cached_too ? 1 : 0, gemm_planner_state()};
+    auto it = h->ws_memo.find(key);
+    if (it != h->ws_memo.end()) return it->second;
+    const bool hu = h->hint_uniform_t, hp = h->hint_cfg_pairs;
+    size_t peak = 0;
+    bool ok = true;
+    for (int cached = 0; ok && cached <= (cached_too ? 1 : 0); ++cached)
+        for (int pairs = 0; ok && pairs <= 1; ++pairs) {
             if (h->run(true, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, S, nullptr, 0, nullptr, 0, nullptr, cached != 0, nullptr, 0, 0,
                        nullptr, nullptr, 0, pairs))
-                return 0;
-            peak = std::max(peak, h->ex.arena.peak);
+                ok = false;
+            else
+                peak = std::max(peak, h->ex.arena.peak);
         }
+    h->hint_uniform_t = hu; h->hint_cfg_pairs = hp;     // (a pending input-gradient pair IS dropped by a dry pass: it shares the executor)
+    if (!ok) return 0;
+    if (h->ws_memo.size() > 64) h->ws_memo.clear();
+    h->ws_memo[key] = peak;
     return peak;
 }
 int gyre_unet_set_tome(gyre_unet* h, int r) {

@@ -8,6 +8,7 @@
 #include <cmath>
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -797,6 +798,7 @@ struct gyre_unet {
     UNetVjpState vjp;
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
+    std::map<std::array<long, 7>, size_t> ws_memo;   // gyre_unet_workspace_bytes: peak per (B, H, W, S, tome_r, cached context, planner state)
     bool hint_uniform_t = false;   // gyre_unet_hint_uniform_timestep: consumed by the next forward
     bool hint_cfg_pairs = false;   // gyre_unet_hint_cfg_pairs: consumed by the next forward
     int gn_unit = 0;     // gcd of block_out_channels / groups: every GroupNorm group (skip concats included) is a whole number of units

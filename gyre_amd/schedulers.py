@@ -826,6 +826,9 @@ class DiffusersLikeScheduler:
             use = 2
         else:
             use = 3
+        # the history's timesteps are read off the schedule: a leaf that starts stepping while another one has already raised
+        # lower_order_nums would read timesteps[-1] / [-2] (the END of the schedule) for its first steps
+        use = min(use, idx + 1, len(self.outputs))
         m0 = self.outputs[-1]
         out = (sigma_t / sigma_s0) * sample - (alpha_t * em1) * m0
         if use >= 2:
@@ -847,9 +850,23 @@ class DiffusersLikeScheduler:
             self.lower_order_nums += 1
         return out
 
+    def _check_history(self, history, sample: Tensor) -> None:
+        """PLMS / DPM-Solver++ keep ONE multistep history per scheduler object.  Leaves of a mode tree that share the object
+        (reference common_scheduler.py:240) may feed it together only when their latents have one shape (grafted inpaint);
+        a hires-fix tree steps a natural-size and a full-size leaf through it, and mixing their predictions cannot work -
+        the reference fails there with a shape error from deep inside the step; say what is wrong instead."""
+        for h in history:
+            if h is not None and tuple(h.shape) != tuple(sample.shape):
+                raise ValueError(f"sampler {self.kind!r} keeps a multistep history and cannot step mode-tree leaves of different "
+                                 f"latent sizes ({tuple(h.shape)} vs {tuple(sample.shape)}: hires fix) through one scheduler; use "
+                                 f"ddim or a k-diffusion sampler for this request")
+
     def step(self, eps: Tensor, t: int, sample: Tensor) -> Tensor:
         if self.solver_order:
+            self._check_history(self.outputs, sample)
             return self._dpmsolver_step(eps, t, sample)
+        if self.kind != "ddim":
+            self._check_history(list(self.ets) + [self.cur_sample], sample)
         ratio = self.T // self.n
         if self.kind == "ddim":
             prev_t = t - ratio

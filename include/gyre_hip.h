@@ -131,7 +131,9 @@ int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on);
  * it (unet/cfg.py:49-57: latents cat[x, x], timesteps cat[t, t], contexts cat[uncond, cond]) - sample b and sample b + B/2 have
  * IDENTICAL latents and timestep and differ in their text context only.  Everything in front of the first cross-attention
  * (conv_in, the first resnet, the first transformer's GroupNorm / proj_in / self-attention: ~4 % of the FLOPs of an SD1.x call
- * at 64x64) is then evaluated once per pair and written twice.  Exact: no kernel depends on batch position.  Ignored for odd B,
+ * at 64x64) is then evaluated once per pair and written twice: the two halves of a pair are IDENTICAL in that prefix, and equal
+ * to the unshared call up to bf16 summation order (the prefix is planned for B/2 samples, so its tile / split-K choice - and with
+ * it the order of the GroupNorm sums - may differ from the full batch's) - bit for bit under gyre_set_batch_invariant.  Ignored for odd B,
  * with ControlNet / T2I inputs, per-sample added conditioning or pending debug taps.  A wrong hint gives the second half of the
  * batch the first half's activations in that prefix. */
 int gyre_unet_hint_cfg_pairs(gyre_unet* h, int on);
