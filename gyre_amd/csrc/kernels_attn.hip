@@ -641,13 +641,15 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
     constexpr bool RUNPTR = D <= 40;
     const char* pcur[NW];
     unsigned pinc[NW];
+    auto reset_pointers = [&]() {
 #pragma unroll
-    for (int i = 0; RUNPTR && i < NW; ++i) {
-        const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
-        const bool live = kq[i] < (1 << 27);
-        pcur[i] = live ? (const char*)(isk ? kb + off[i] : vb + off[i]) : (const char*)((ONES && one_row[i]) ? zero + 128 : zero);
-        pinc[i] = live ? (isk ? 64u * (unsigned)p.ldk * 2u : 128u) : 0u;
-    }
+        for (int i = 0; RUNPTR && i < NW; ++i) {
+            const bool isk = (i * 4 + wave) * 64 < KG;   // wave-uniform
+            const bool live = kq[i] < (1 << 27);
+            pcur[i] = live ? (const char*)(isk ? kb + off[i] : vb + off[i]) : (const char*)((ONES && one_row[i]) ? zero + 128 : zero);
+            pinc[i] = live ? (isk ? 64u * (unsigned)p.ldk * 2u : 128u) : 0u;
+        }
+    };
     auto issue = [&](int kv0, int st) {
         char* sbase = smem + st * STAGE + wave * 1024;
         if (RUNPTR && kv0 + 64 <= p.Nk) {                // wave-uniform: a full tile
@@ -681,22 +683,23 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
     }
     f32x4_t o[QI][DO];
     float m_ref[QI], l_run[QI];
-#pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
-        m_ref[qi] = 0.f; l_run[qi] = 0.f;
-#pragma unroll
-        for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
+    // -m_ref of each query block as the MFMA's C operand, kept as a register quad for the whole run: the reference only changes
+    // in the (rare, wave-uniform) re-centring branch, so no tile has to re-materialise it (8 x v_mov + 2 x v_xor per tile before)
+    // (head dims up to 40: the eight registers make the D = 64 form spill, and a counted-vmcnt kernel must not)
+    constexpr bool CNEG = D <= 40;
+    f32x4_t cneg[QI];
 
     // B: scores of tile t (relative to the rows' reference maxima), keys past Nk masked when TAIL
     auto qk = [&](int t, f32x4_t (&s)[QI][4], auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const char* k_lds = smem + (t % NS) * STAGE;
+        if constexpr (!CNEG) {
 #pragma unroll
-        for (int qi = 0; qi < QI; ++qi) {
-            const float c0 = -m_ref[qi];
+            for (int qi = 0; qi < QI; ++qi) {
+                const float c0 = -m_ref[qi];
 #pragma unroll
-            for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
+                for (int ki = 0; ki < 4; ++ki) s[qi][ki] = f32x4_t{c0, c0, c0, c0};
+            }
         }
 #pragma unroll
         for (int ki = 0; ki < 4; ++ki) {
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
                     bf16x8_t, *(const uint4*)(k_lds + (ki * 16 + fr) * (D * 2) + (ks * 4 + fq) * 16));
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
-                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
+                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], (CNEG && ks == 0) ? cneg[qi] : s[qi][ki], 0, 0, 0);
             }
         }
         if (TAIL) {
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
                 const float delta = fmaxf(mx, lo);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 m_ref[qi] += delta;
+                if constexpr (CNEG) { const float c0 = -m_ref[qi]; cneg[qi] = f32x4_t{c0, c0, c0, c0}; }
                 l_run[qi] *= alpha;
 #pragma unroll
                 for (int ki = 0; ki < 4; ++ki)
@@ -813,9 +817,10 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
             }
         }
     };
-    // one pipeline step: cur = scores of tile t (checked), next receives tile t+1
-    auto step = [&](int t, f32x4_t (&cur)[QI][4], f32x4_t (&next)[QI][4], auto has_next, auto tail_next, auto tail_cur) {
+    // one pipeline step: cur = scores of tile t (checked when CHECK), next receives tile t+1
+    auto step = [&](int t, f32x4_t (&cur)[QI][4], f32x4_t (&next)[QI][4], auto has_next, auto tail_next, auto tail_cur, auto check_tag) {
         constexpr bool HASNEXT = decltype(has_next)::value;
+        constexpr bool CHECK = decltype(check_tag)::value;
         if (HASNEXT) {
             // tile t+1 landed (tiles t+2 .. t+PD may still be in flight), every wave is done with tile t-1
             if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,38 +832,54 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
         softmax_pack(cur, pf);
         if (HASNEXT) qk(t + 1, next, tail_next);
         pv(t, pf, tail_cur);
-        if (HASNEXT) check(false, next);
+        if (HASNEXT && CHECK) check(false, next);
     };
-
-    const int nt = (p.Nk + 63) / 64;
-#pragma unroll
-    for (int t0 = 0; t0 <= PD; ++t0) issue(t0 * 64, t0);
-    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    f32x4_t sa[QI][4], sb[QI][4];
-    if (nt == 1) qk(0, sa, std::true_type{}); else qk(0, sa, std::false_type{});
-    check(true, sa);
-
     constexpr std::true_type T{};
     constexpr std::false_type F{};
-    const int n_main = nt >= 2 ? nt - 2 : 0;
-    int t = 0;
-    for (; t + 1 < n_main; t += 2) {
-        step(t, sa, sb, T, F, F);
-        step(t + 1, sb, sa, T, F, F);
-    }
-    bool flip = false;
-    if (t < n_main) { step(t, sa, sb, T, F, F); ++t; flip = true; }
-    if (nt >= 2) {
-        if (!flip) step(t, sa, sb, T, T, F); else step(t, sb, sa, T, T, F);
-        ++t; flip = !flip;
-    }
-    if (!flip) step(t, sa, sb, F, F, T); else step(t, sb, sa, F, F, T);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end zero-page DMAs before the wave exits
+    const int nt = (p.Nk + 63) / 64;
 
+    // One pass over the keys.  CHECK = false (the first, optimistic pass): the rows are centred on the maximum of the FIRST key
+    // tile and no later tile is examined - the per-tile overflow check (16 x v_max3 + compare + branch per wave tile: every
+    // vector instruction beyond the ~4 an MFMA covers costs the SIMD ~3 cycles, tools/ubench/mfma_mix.hip) is paid by no
+    // tile.  A score more than ~127 above the first tile's maximum would overflow exp2 to inf; any smaller excess is exact
+    // floating-point arithmetic (P is rounded to bf16 relative to its own magnitude, O and the row sum stay finite).  The
+    // overflow leaves a non-finite (or zero) row sum, which the end of the pass detects; the workgroup then repeats the whole
+    // pass with CHECK = true (re-centring whenever a score exceeds the reference by 2^TAU) - never observed on SD activations,
+    // exercised by tests/test_gpu_kernels.py::test_attention_folded_softmax_recentres.
+    auto pass = [&](auto check_tag) {
+        reset_pointers();
 #pragma unroll
-    for (int qi = 0; qi < QI; ++qi) {
+        for (int qi = 0; qi < QI; ++qi) {
+            m_ref[qi] = 0.f; l_run[qi] = 0.f;
+            if constexpr (CNEG) cneg[qi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int di = 0; di < DO; ++di) o[qi][di] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t0 = 0; t0 <= PD; ++t0) issue(t0 * 64, t0);
+        if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4_t sa[QI][4], sb[QI][4];
+        if (nt == 1) qk(0, sa, std::true_type{}); else qk(0, sa, std::false_type{});
+        check(true, sa);
+
+        const int n_main = nt >= 2 ? nt - 2 : 0;
+        int t = 0;
+        for (; t + 1 < n_main; t += 2) {
+            step(t, sa, sb, T, F, F, check_tag);
+            step(t + 1, sb, sa, T, F, F, check_tag);
+        }
+        bool flip = false;
+        if (t < n_main) { step(t, sa, sb, T, F, F, check_tag); ++t; flip = true; }
+        if (nt >= 2) {
+            if (!flip) step(t, sa, sb, T, T, F, check_tag); else step(t, sb, sa, T, T, F, check_tag);
+            ++t; flip = !flip;
+        }
+        if (!flip) step(t, sa, sb, F, F, T, check_tag); else step(t, sb, sa, F, F, T, check_tag);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the past-the-end zero-page DMAs before the wave exits / the ring restarts
+    };
+    auto row_sum = [&](int qi) {
         float l;
         if (ONES) {
             l = __shfl(o[qi][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr);
@@ -867,6 +888,30 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
         }
+        return l;
+    };
+
+    __shared__ int s_redo;
+    if (tid == 0) s_redo = 0;                       // (ordered before its first read by the barriers inside pass())
+    // (D = 80 spills already; a second copy of the loop makes it worse: that form keeps the checked pass only)
+    constexpr bool OPTIMISTIC = D <= 64;
+    if (!OPTIMISTIC || p.always_check) pass(T);
+    else {
+        pass(F);
+        bool bad = false;
+#pragma unroll
+        for (int qi = 0; qi < QI; ++qi) {
+            const float l = row_sum(qi);
+            bad |= (q0 + qi * 16 + fr < p.Nq) && !(l > 0.f && l < 3.0e38f);
+        }
+        if (__any(bad) && lane == 0) s_redo = 1;
+        __syncthreads();                            // also: every wave is done reading the ring before a second pass refills it
+        if (s_redo) pass(T);                        // workgroup-uniform: the ring and its barriers are shared by the four waves
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < QI; ++qi) {
+        const float l = row_sum(qi);
         const float inv = 1.0f / l;
         const int q = q0 + qi * 16 + fr;
         if (q >= p.Nq) continue;
@@ -958,7 +1003,9 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     dim3 grid((unsigned)(((p.Nq + 64 * QI - 1) / (64 * QI)) * p.B * p.H));
     GyreProfScope prof_(KC_ATTN, st, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, zero);
+    AttnParams q = p;
+    q.always_check = g_attn_variant == 7 ? 1 : 0;        // tuning: the per-tile overflow check in every tile (as before round 4)
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q, zero);
     GYRE_LAUNCH_CHECK();
     return 0;
 }
@@ -985,7 +1032,7 @@ int launch_attention(hipStream_t st, const AttnParams& p) {
     if (p.ldq % 8 || p.ldk % 8 || p.ldvt % 8 || p.ldo % 4) GYRE_FAIL(-1, "attention: strides must be multiples of 8");
     if (p.ldvt < (p.Nk + 7) / 8 * 8) GYRE_FAIL(-1, "attention: ldvt must cover Nk rounded up to 8");
     if (p.Nk < 1 || p.Nq < 1) GYRE_FAIL(-1, "attention: empty sequence");
-    const int var = g_attn_variant == 6 ? 0 : g_attn_variant;
+    const int var = (g_attn_variant == 6 || g_attn_variant == 7) ? 0 : g_attn_variant;
     // software-pipelined folded kernel; with only a couple of key tiles (cross-attention, Nk = 77) its longer prologue
     // costs more than the overlap wins (measured 47.8 vs 41.1 us), so short key sequences stay on the v2 form
     // (48 query rows per wave, QI = 3, was tried for D = 40: 232 B/lane of spills at 2 waves/SIMD - not built)

@@ -252,8 +252,8 @@ int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
 int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
- * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences.  Returns the
- * previous value. */
+ * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic with the
+ * per-tile overflow check of the pipelined kernel in every tile (no optimistic first pass).  Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
 /* Tuning only.  Ablations (results are garbage): bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs,
  * bit2 = no epilogue.  Planner switches for same-box A/B runs (results stay valid): bit8 = default tile order, bit9 = conv

@@ -486,6 +486,42 @@ def test_attention_prescaled_peaked_and_drifting_max():
             report(f"attention prescaled v{variant} {name}", o.float().cpu(), ref, 3e-2)
 
 
+@pytest.mark.parametrize("D", [40, 64])
+@pytest.mark.parametrize("excess", [90.0, 300.0])
+def test_attention_optimistic_pass_and_its_fallback(D, excess):
+    """The pipelined kernel's first pass centres every row on the maximum of the FIRST key tile and checks no later tile.  A late
+    key whose score lies `excess` (log2 units) above that: 90 - still finite in fp32, the optimistic pass is exact; 300 - exp2
+    overflows, the row sum turns non-finite, and the workgroup repeats the pass with the per-tile check (variant 7 = that pass
+    from the start).  Both must agree with the fp32 reference and with each other."""
+    L = _lib.lib()
+    B, heads, N = 1, 2, 1024
+    C_ = heads * D
+    c = 1.4426950408889634 / math.sqrt(D)
+    q = bf16_round(randn(B, N, C_, seed=173))
+    k32 = randn(B, N, C_, seed=174)
+    # key 700 of head 0 aligned with query 5: its prescaled score exceeds every first-tile score of that row by about `excess`
+    qn = q[0, 5, :D]
+    k32[0, 700, :D] = qn * (excess / c / float(qn @ qn))
+    v = bf16_round(randn(B, N, C_, seed=175))
+    ref = attn_ref(q, k32, v, heads)
+    kpre = (k32 * c).to(torch.bfloat16).to(DEV)
+    vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
+    outs = []
+    for variant in (0, 7):
+        o = torch.full((B, N, C_), float("nan"), dtype=torch.bfloat16, device=DEV)
+        old = L.gyre_debug_force_attn_variant(variant)
+        try:
+            _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
+        finally:
+            L.gyre_debug_force_attn_variant(old)
+        assert bool(torch.isfinite(o).all())
+        report(f"attention D{D} late excess {excess} variant {variant}", o.float().cpu(), ref, 3e-2)
+        outs.append(o)
+    # rows of workgroups that never overflow take the identical arithmetic in both variants
+    assert rel_l2(outs[0].float().cpu(), outs[1].float().cpu()) < 1e-2
+    assert torch.equal(outs[0][:, 512:, D:], outs[1][:, 512:, D:])      # head 1 / other query blocks: no re-centring in either run
+
+
 @pytest.mark.parametrize("cfg,B,tokens,C", [(0, 16, 4096, 320), (4, 4, 1024, 320), (5, 2, 1024, 320), (6, 2, 1024, 640), (7, 2, 512, 640),
                                             (0, 16, 1024, 640), (5, 3, 264, 320), (8, 2, 1024, 320), (0, 16, 256, 1280)])
 def test_fused_qkv_projection(cfg, B, tokens, C):

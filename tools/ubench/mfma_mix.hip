@@ -21,7 +21,7 @@ __global__ void k(float* out, long long* cyc, float seed) {
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
     float v[16];
     for (int i = 0; i < 16; ++i) v[i] = seed + i + threadIdx.x * 0.001f;
-    f32x4 r[4] = {};
+    f32x4 r8[8] = {};
     ((float*)smem)[threadIdx.x] = seed;
     __syncthreads();
     const unsigned lp = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + lane * 16;
@@ -33,29 +33,30 @@ __global__ void k(float* out, long long* cyc, float seed) {
 #pragma unroll
             for (int j = 0; j < KV; ++j) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[(m * KV + j) & 15]));
 #pragma unroll
-            for (int j = 0; j < KR; ++j) {
-                f32x4 t;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(lp), "n"(1024 * ((0 * 4 + j) & 7)));
-                r[(m + j) & 3] = t;
-            }
+            for (int j = 0; j < KR; ++j)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r8[(m * KR + j) & 7]) : "v"(lp), "n"(1024 * ((0 * 4 + j) & 7)));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (KR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KR) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");       // the newest four reads stay in flight
     }
     long long t1 = __builtin_readcyclecounter();
     float s = 0;
-    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + r[i][0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7];
+    for (int i = 0; i < 8; ++i) s += r8[i][0];
     for (int i = 0; i < 16; ++i) s += v[i];
     out[threadIdx.x] = s;
-    if (threadIdx.x == 0) *cyc = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
 }
 template <int KV, int KR, bool MF, bool DEP>
 void run(const char* name, int waves_per_simd, float* out, long long* cyc) {
     hipFuncSetAttribute((const void*)k<KV, KR, MF, DEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<KV, KR, MF, DEP>), dim3(1), dim3(256 * waves_per_simd), 65536, 0, out, cyc, 1.0f);
     hipDeviceSynchronize();
-    long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-46s W=%d: %7.1f cycles per group of 4 MFMA slots  (%.1f per slot)\n", name, waves_per_simd, (double)c / ITER, (double)c / ITER / 4);
+    long long c[8]; hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
+    long long mx = 0; for (int i = 0; i < 4 * waves_per_simd; ++i) mx = c[i] > mx ? c[i] : mx;
+    printf("%-46s W=%d: wave 0 %6.1f, slowest wave %6.1f cycles per slot -> %5.1f cycles of the SIMD per slot of ONE wave\n", name, waves_per_simd,
+           (double)c[0] / ITER / 4, (double)mx / ITER / 4, (double)mx / ITER / 4 / waves_per_simd);
 }
 // one wave per SIMD issues MFMAs only, its partner vector instructions only
 template <int OP>
@@ -108,6 +109,9 @@ int main() {
         run<0, 1, false, false>("1 ds_read_b128 only", w, out, cyc);
         run<0, 2, false, false>("2 ds_read_b128 only", w, out, cyc);
         run<12, 1, true, false>("MFMA + 12 v_fma + 1 ds_read_b128", w, out, cyc);
+        run<8, 1, true, false>("MFMA + 8 v_fma + 1 ds_read_b128", w, out, cyc);
+        run<4, 1, true, false>("MFMA + 4 v_fma + 1 ds_read_b128", w, out, cyc);
+        run<12, 1, false, false>("12 v_fma + 1 ds_read_b128 (no MFMA)", w, out, cyc);
     }
     for (int op = 0; op < 2; ++op) {
         if (op == 0) hipLaunchKernelGGL(kpair<0>, dim3(1), dim3(512), 0, 0, out, cyc, 1.0f);
