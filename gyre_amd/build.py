@@ -105,6 +105,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             extra = [*extra, "-Rpass-analysis=kernel-resource-usage"]
         if os.environ.get("GYRE_AR_ABLATIONS") and base == "kernels_gemm_ar.hip":   # tools/ar_ablate.py
             extra = [*extra, "-DGYRE_AR_ABLATIONS"]
+        if os.environ.get("GYRE_ATTN_ABLATIONS") and base == "kernels_attn.hip":    # tools/attn_ablate.py
+            extra = [*extra, "-DGYRE_ATTN_ABLATIONS"]
         if os.environ.get("GYRE_GEMM_ABLATIONS"):      # tuning builds: the main-loop ablation tests of the pipelined kernel (tools/conv_ablate.py)
             extra = [*extra, "-DGYRE_GEMM_ABLATIONS"]
         cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]

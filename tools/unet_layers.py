@@ -13,9 +13,30 @@ if os.environ.get("GYRE_PROF_DUMP") is None:
     tot = sum(sum(v) for v in rows.values())
     print(out.stdout[-400:], out.stderr[-600:] if out.returncode else '')
     print(f"total timed {tot / 1e3:.2f} ms")
-    for (name, fl, by), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+    # one row per distinct (kernel class, algorithmic FLOPs, algorithmic bytes) = per layer shape: fractions of the 2.5 PFLOP/s dense
+    # bf16 MFMA peak and of the 8 TB/s HBM peak, and the time the shape spends ABOVE its own roof ("gap": what tuning could win at
+    # most) - sorted by that gap.  MD=path writes the table as markdown (profiles/rNN_unet_layers.md).
+    table = []
+    for (name, fl, by), v in rows.items():
         mf = float(fl.split()[0]); kb = float(by.split()[0]); t = sum(v) / len(v)
-        print(f"{name:30s} x{len(v):3d}  {sum(v):8.1f} us tot  {t:7.1f} us each  {mf / t:7.0f} TF  {kb / t / 1e3:6.2f} TB/s  [{fl}, {by}]")
+        tf, tbs = mf / t, kb / t / 1e3
+        roof = max(tf / 2500.0, tbs / 8.0)
+        table.append((sum(v) * (1.0 - min(roof, 1.0)), name, len(v), sum(v), t, tf, tbs, roof, fl, by))
+    table.sort(reverse=True)
+    for gap, name, n, st, t, tf, tbs, roof, fl, by in table:
+        print(f"{name:30s} x{n:3d}  {st:8.1f} us tot  {t:7.1f} us each  {tf:7.0f} TF ({tf / 2500:.3f})  {tbs:6.2f} TB/s ({tbs / 8:.3f})  "
+              f"gap {gap:7.1f} us  [{fl}, {by}]")
+    md = os.environ.get("MD")
+    if md:
+        with open(md, "w") as f:
+            f.write(f"Per-shape roofline of one UNet forward (`tools/unet_layers.py`, HIP events around every launch; B = "
+                    f"{os.environ.get('B', '16')}, latent {os.environ.get('LAT', '64')}; sum of timed launches {tot / 1e3:.2f} ms).  "
+                    "`mfma` = algorithmic FLOP/s over 2.5 PFLOP/s, `hbm` = algorithmic bytes/s over 8 TB/s, `gap` = time above the "
+                    "shape's own roof (total time x (1 - max of the two fractions)); sorted by gap.\n\n")
+            f.write("| kernel class | launches | us total | us each | GFLOP | MB | TFLOP/s | mfma | TB/s | hbm | gap us |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+            for gap, name, n, st, t, tf, tbs, roof, fl, by in table:
+                f.write(f"| `{name}` | {n} | {st:.1f} | {t:.1f} | {float(fl.split()[0]) / 1e3:.1f} | {float(by.split()[0]) / 1e3:.1f} | {tf:.0f} | "
+                        f"{tf / 2500:.3f} | {tbs:.2f} | {tbs / 8:.3f} | {gap:.1f} |\n")
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
