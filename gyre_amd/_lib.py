@@ -57,6 +57,8 @@ _SIGS = {
     "gyre_unet_hint_uniform_timestep": (_i, [_vp, _i]),
     "gyre_unet_hint_cfg_pairs": (_i, [_vp, _i]),
     "gyre_unet_set_tome": (_i, [_vp, _i]),
+    "gyre_unet_set_tiling": (_i, [_vp, _i]),
+    "gyre_vae_set_tiling": (_i, [_vp, _i]),
     "gyre_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz]),
     "gyre_unet_forward_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_unet_forward_ctrl": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp,

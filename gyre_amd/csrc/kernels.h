@@ -10,6 +10,8 @@ int launch_ctx_to_bf16(hipStream_t st, const void* x, int dtype, size_t n, bf16_
 // dst[o][0:inner] = dst[o][inner:2*inner] = src[o][0:inner] (bytes, multiples of 16), o < outer
 int launch_dup_batch(hipStream_t st, const void* src, void* dst, size_t outer, size_t inner_bytes);
 int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n);
+// debug (GYRE_VERIFY_HINTS=1): flag |= 1 if t[b] != t[0] for some b, |= 2 if the two halves of x (bytes_per_half each) differ
+int launch_verify_hints(hipStream_t st, const int64_t* t, int B, int check_t, const void* x, size_t bytes_per_half, int check_pairs, int* flag);
 int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);
 // out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]; x f32 [B][K], W bf16 [N][K], out f32 [B][ldo].  act_in_silu: f = SiLU,
 // and x is OVERWRITTEN with SiLU(x) (its only use on the time-embedding path)
@@ -122,6 +124,9 @@ struct GemmParams {
     // first use and sets w_packed, tests pass a scratch buffer through gyre_debug_set_ar_workspace); no_ar = the caller wants a
     // feature that kernel lacks from this launch (column statistics for a GroupNorm)
     const void* w_packed = nullptr; int ar_ok = 0, no_ar = 0;
+    // conv: circular instead of zero padding along x (bit 0) / y (bit 1) - the reference's request option "tiling"
+    // (unified_pipeline.py:1671-1712 patches every Conv2d's own padding to F.pad(mode="circular")); 4-wave tile configs only
+    int wrap = 0;
 };
 // rows per colstat_out row block launch_gemm would use for `p` (p.colstat_unit and p.rows_per_sample set); 0: unsupported
 int gemm_colstat_rows(const GemmParams& p);

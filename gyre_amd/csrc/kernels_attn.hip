@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
         }
         if (__any(bad) && lane == 0) s_redo = 1;
         __syncthreads();                            // also: every wave is done reading the ring before a second pass refills it
-        if (s_redo) pass(T);                        // workgroup-uniform: the ring and its barriers are shared by the four waves
+        if (s_redo && ABL == 0) pass(T);            // workgroup-uniform: the ring and its barriers are shared by the four waves
     }
 
 #pragma unroll

@@ -726,3 +726,24 @@ int launch_copy_probe(hipStream_t st, const void* src, void* dst, size_t bytes) 
     GYRE_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- debug: verify the caller's batch-structure hints on the device (GYRE_VERIFY_HINTS=1) ---------------------------------
+// flag[0] |= 1 when some sample's timestep differs from sample 0's (gyre_unet_hint_uniform_timestep was wrong)
+// flag[0] |= 2 when sample b and sample b + B/2 differ in any input byte (gyre_unet_hint_cfg_pairs was wrong)
+__global__ __launch_bounds__(256) void k_verify_hints(const int64_t* t, int B, int check_t, const uint32_t* x, size_t words_per_half,
+                                                      int check_pairs, int* flag) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    if (check_t && i < (size_t)B && t[i] != t[0]) bad |= 1;
+    if (check_pairs && i < words_per_half && x[i] != x[words_per_half + i]) bad |= 2;
+    if (bad) atomicOr(flag, bad);
+}
+int launch_verify_hints(hipStream_t st, const int64_t* t, int B, int check_t, const void* x, size_t bytes_per_half, int check_pairs, int* flag) {
+    if (bytes_per_half % 4) check_pairs = 0;          // (never: the boundary tensors are 2- or 4-byte types with an even element count)
+    const size_t words = check_pairs ? bytes_per_half / 4 : 0;
+    const size_t n = std::max<size_t>(words, check_t ? (size_t)B : 0);
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_verify_hints, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t, B, check_t, (const uint32_t*)x, words, check_pairs, flag);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}

@@ -880,6 +880,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
             for (int i = 0; i < AR; ++i) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                // circular padding (GemmParams::wrap: the reference's tiling option): the one row / column of padding wraps
+                // around the (upsampled) image instead of reading zeros
+                if (p.wrap & 2) iy = iy < 0 ? iy + Hlim : (iy >= Hlim && iy < 2 * Hlim ? iy - Hlim : iy);
+                if (p.wrap & 1) ix = ix < 0 ? ix + Wlim : (ix >= Wlim && ix < 2 * Wlim ? ix - Wlim : ix);
                 if (kok && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
                     if (p.ups) { iy >>= 1; ix >>= 1; }
                     size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
@@ -1135,6 +1139,8 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     consider(3, 0.30, 64, 64, 4);
     consider(1, 0.55, 128, 128, 2);
     consider(2, 0.50, 256, 64, 2);
+    // circular padding exists in the 4-wave register-staged gather only (a niche request option: correctness over speed)
+    const bool wrap_only4 = p.mode == GEMM_CONV3 && p.wrap != 0;
     // A-resident kernel (kernels_gemm_ar.hip): K = 320 / 640 linear problems with enough rows to cover the chip keep their
     // activations in registers and stream only the weights (tuning bit 21: off)
     // Taken where the N sweep is long enough to amortise the slab load (GEGLU FF1: N = 8 C, 216 -> 129 us at 64x64, 163 -> 124
@@ -1143,7 +1149,7 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && !(p.debug & 0x200000) && p.M >= 4096 &&
         (p.N >= 3 * p.K || (p.debug & 0x400000)) && gemm_ar_supports(p))
         return 30;
-    if (!trans && p.batch <= 1) {
+    if (!trans && p.batch <= 1 && !wrap_only4) {
         // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the
         // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
         auto big = [&](int id, double speed, int bm, int bn) { if (tiles(bm, bn) >= 160) consider(id, speed, bm, bn, 1); };
@@ -1385,6 +1391,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
     }
+    if (p.mode == GEMM_CONV3 && p.wrap && cfg > 3) GYRE_FAIL(-6, "gemm: circular padding (tiling) exists in the 4-wave tile configs only");
     if (cfg == 30) {
         if (splits > 1 || !gemm_ar_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the A-resident kernel's domain (K = 320 / 640 linear, bf16 row-major output)");
         const void* wpk = p.w_packed;

@@ -128,6 +128,19 @@ int gyre_unet_set_tome(gyre_unet* h, int r) {
     h->ex.tome_r = r;
     return 0;
 }
+int gyre_unet_set_tiling(gyre_unet* h, int mode) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null handle");
+    if (mode < 0 || mode > 3) GYRE_FAIL(GYRE_ERR_INVALID, "tiling: 0 = off, 1 = x, 2 = y, 3 = both");
+    h->ex.tiling = mode;
+    h->ws_memo.clear();
+    return 0;
+}
+int gyre_vae_set_tiling(gyre_vae* h, int mode) {
+    if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null handle");
+    if (mode < 0 || mode > 3) GYRE_FAIL(GYRE_ERR_INVALID, "tiling: 0 = off, 1 = x, 2 = y, 3 = both");
+    h->ex.tiling = mode;
+    return 0;
+}
 size_t gyre_op_groupnorm_bwd_workspace(int B, int HW, int C, int groups) { return gn_bwd_workspace_bytes(B, HW, C, groups); }
 int gyre_op_groupnorm_bwd(void* st, const void* x, const void* x2, int C1, int B, int HW, int C, int groups, const float* gamma,
                           const float* beta, float eps, int silu, const void* dy, const void* addend, void* ws, size_t wsb,
@@ -262,6 +275,7 @@ int gyre_unet_vjp(gyre_unet* h, void* st, const void* x, int xdt, const int64_t*
                   const float* temb_add) {
     if (!h || !x || !t || !ctx || !d_eps || !ws || !eps_out || !dx_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    if (h->ex.tiling) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "the input-gradient sweep has no circular (tiling) convolutions");
     for (int d : {xdt, cdt, ddt, odt, dxdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
     return gyre_unet_run_vjp(*h, false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, d_eps, ddt, ws, wsb, eps_out, odt, dx_out,
@@ -272,6 +286,7 @@ int gyre_unet_vjp_begin(gyre_unet* h, void* st, const void* x, int xdt, const in
                         int S, void* ws, size_t wsb, void* eps_out, int odt, const float* temb_add) {
     if (!h || !x || !t || !ctx || !ws || !eps_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
+    if (h->ex.tiling) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "the input-gradient sweep has no circular (tiling) convolutions");
     for (int d : {xdt, cdt, odt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
     return gyre_unet_vjp_forward(*h, false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, eps_out, odt, temb_add);
@@ -339,6 +354,7 @@ size_t gyre_vae_decode_vjp_workspace_bytes(gyre_vae* h, int B, int hl, int wl) {
 int gyre_vae_decode_vjp(gyre_vae* h, void* st, const void* z, int zdt, int B, int hl, int wl, const void* d_img, int ddt, void* ws,
                         size_t wsb, void* img_out, int odt, void* dz_out, int dzdt) {
     if (!h || !z || !d_img || !ws || !img_out || !dz_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (h->ex.tiling) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "the input-gradient sweep has no circular (tiling) convolutions");
     for (int d : {zdt, ddt, odt, dzdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
     return gyre_vae_run_decode_vjp(*h, false, (hipStream_t)st, z, zdt, B, hl, wl, d_img, ddt, ws, wsb, img_out, odt, dz_out, dzdt);

@@ -276,6 +276,7 @@ struct Exec {
     int batch = 0;   // samples in the current call (planner hint, see gemm_set_batch_invariant)
     int cs_unit = 0; // channels per GroupNorm-statistics unit the producers emit (0 = producers emit none; set per call)
     int tome_r = 0;  // ToMe: keys / values merged per self-attention (0 = off; reference option "tome", nonfree/tome_unet.py)
+    int tiling = 0;  // circular conv padding: bit 0 along x, bit 1 along y (reference option "tiling", unified_pipeline.py:1671-1712)
 
     bool dry() const { return arena.dry; }
     int alloc(Tn& t, int B, int H, int W, int C, size_t elt = 2) {
@@ -404,6 +405,7 @@ struct Exec {
         p.bias = w.b; p.rowbias = rowbias; p.rows_per_sample = Ho * Wo; p.ld_rowbias = ld_rowbias;
         if (residual) { p.residual = residual->p; p.ldr = residual->C; }
         p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
+        p.wrap = pad ? tiling : 0;                 // a module's OWN padding turns circular; the VAE's explicit (0,1,0,1) F.pad stays zeros
         TRY(attach_colstats(p, y, Ho * Wo));       // every conv output of the UNet feeds a GroupNorm
         return run_gemm(p);
     }
@@ -415,7 +417,7 @@ struct Exec {
         p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = x.H; p.Wo = x.W; p.stride = 1; p.pad = 1;
         p.W = w.w; p.K = 9 * x.C; p.N = w.cout; p.M = x.rows();
         p.bias = w.b; p.rows_per_sample = x.H * x.W;
-        p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = out_dtype;
+        p.out = out; p.out_mode = OUT_NCHW; p.out_dtype = out_dtype; p.wrap = tiling;
         return launch_gemm(st, p);
     }
     // y[M][N] = x[M][K] (|| x2) @ w^T + bias (+ residual); geglu halves N
@@ -799,6 +801,7 @@ struct gyre_unet {
     bool finalized = false;
     int temb_dim = 0, temb_cols = 0;
     std::map<std::array<long, 7>, size_t> ws_memo;   // gyre_unet_workspace_bytes: peak per (B, H, W, S, tome_r, cached context, planner state)
+    int* hint_flag = nullptr;      // device word of the hint verifier (GYRE_VERIFY_HINTS=1)
     bool hint_uniform_t = false;   // gyre_unet_hint_uniform_timestep: consumed by the next forward
     bool hint_cfg_pairs = false;   // gyre_unet_hint_cfg_pairs: consumed by the next forward
     int gn_unit = 0;     // gcd of block_out_channels / groups: every GroupNorm group (skip concats included) is a whole number of units
@@ -1013,6 +1016,24 @@ struct gyre_unet {
         const bool pairs = pairs_ok && (force_pairs >= 0 ? force_pairs != 0 : hint_cfg_pairs);
         hint_cfg_pairs = false;
         const int Bp = pairs ? B / 2 : B;              // batch of the shared prefix
+        // Both hints are the caller's word and a wrong one gives wrong activations, silently.  GYRE_VERIFY_HINTS=1 (debug /
+        // integration runs of a foreign C-ABI caller) checks them on the device before they are used - one compare kernel and
+        // one 4-byte read-back, i.e. a stream synchronisation per call - and fails the call instead.
+        if (!dry && (uni_t || pairs)) {
+            static const bool verify = getenv("GYRE_VERIFY_HINTS") != nullptr && getenv("GYRE_VERIFY_HINTS")[0] != '0';
+            if (verify) {
+                if (!hint_flag) hint_flag = (int*)store.dmalloc(16, true);
+                if (!hint_flag) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the hint-verification flag");
+                if (hipMemsetAsync(hint_flag, 0, 4, st) != hipSuccess) GYRE_FAIL(GYRE_ERR_HIP, "hipMemsetAsync failed");
+                const size_t elt = xdt == 0 ? 4 : 2;
+                TRY(launch_verify_hints(st, t, B, uni_t ? 1 : 0, x, (size_t)(B / 2) * c.in_channels * H * W * elt, pairs ? 1 : 0, hint_flag));
+                int bad = 0;
+                if (hipMemcpyAsync(&bad, hint_flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+                    GYRE_FAIL(GYRE_ERR_HIP, "reading the hint-verification flag failed");
+                if (bad & 1) GYRE_FAIL(GYRE_ERR_INVALID, "gyre_unet_hint_uniform_timestep was set, but the timesteps of this call differ between samples");
+                if (bad & 2) GYRE_FAIL(GYRE_ERR_INVALID, "gyre_unet_hint_cfg_pairs was set, but sample b and sample b + B/2 of this call differ in their latents");
+            }
+        }
         Tn xin, cx, emb, t1, t2, tp;
         TRY(e.alloc(xin, Bp, H, W, pad8(c.in_channels)));
         if (!cached) TRY(e.alloc(cx, B, S, 1, D));

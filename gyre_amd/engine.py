@@ -26,7 +26,7 @@ into PNG artifacts.  What this class has to honour is therefore exactly what the
   * no-op memory knobs (attention / VAE slicing, xformers): 288 GB of HBM3E, the whole batch stays resident.
 
 Features outside the native hot path raise NotImplementedError (-> gRPC UNIMPLEMENTED, services/exception_to_grpc.py):
-depth / hint images (ControlNet, T2I), textual-inversion token embeddings, tiling, brownian sampler noise.  CLIP guidance
+depth / hint images (ControlNet, T2I), textual-inversion token embeddings, brownian sampler noise.  CLIP guidance
 is implemented (gyre_amd/clipguided.py over the native input-gradient sweeps).  The safety checker stays the host module the
 manager loaded; it is RUN exactly as the reference runs it (``_safety_check``), never skipped silently.
 """
@@ -289,8 +289,10 @@ class GyreUnifiedPipeline:
             raise NotImplementedError("depth / hint conditioning (ControlNet, T2I adapters) is outside the native hot path")
         if token_embeddings:
             raise NotImplementedError("textual-inversion token embeddings are outside the native hot path")
-        if tiling:
-            raise NotImplementedError("tiling mode is not implemented natively")
+        if tiling not in (False, None, True, "x", "y", "xy"):
+            raise ValueError(f"tiling must be True, False, 'x', 'y' or 'xy', got {tiling!r}")
+        if tiling and clip_guidance_scale:
+            raise NotImplementedError("tiling together with CLIP guidance (the native input-gradient sweep has no circular convolutions)")
         if scheduler_noise_type not in (None, "normal"):
             raise NotImplementedError("only normal sampler noise is implemented (brownian needs torchsde)")
         if latents is not None:
@@ -320,6 +322,11 @@ class GyreUnifiedPipeline:
                                      approx_cutouts, no_cutouts)
         pipe.hires_fix, pipe.hires_threshold_fraction = self._hires_fix, self._hires_threshold_fraction
         pipe.hires_oos_fraction, pipe.hires_image_oos_fraction = self._hires_oos_fraction, self._hires_image_oos_fraction
+        # reference set_tiling_mode (unified_pipeline.py:1696-1712, called per request at :1845): every Conv2d of every module
+        # pads circularly for this request - the native modules switch their conv gather
+        for m in (self.unet, self.inpaint_unet, self.vae):
+            if m is not None and hasattr(m, "set_tiling"):
+                m.set_tiling(tiling or False)
         for u in (self.unet, self.inpaint_unet):
             if u is None:
                 continue
@@ -355,7 +362,7 @@ class GyreUnifiedPipeline:
                        prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
                        churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
                        sigma_max=sigma_max, **clip_kw)
-        if len(self._shard_devices) > 1 and B > 1 and not clip_kw and not lora and not self._tome:
+        if len(self._shard_devices) > 1 and B > 1 and not clip_kw and not lora and not self._tome and not tiling:
             # one request over several device slots (engine option "shard_devices"); progress / cancellation are polled once
             # per request here: the replicas run their loops concurrently and a per-step callback has no single owner.
             # (CLIP guidance couples the batch through its flat-loss stop; per-request LoRA / ToMe patch one

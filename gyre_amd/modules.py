@@ -87,6 +87,23 @@ class _NativeModule(nn.Module):
         self._invalidate()
         return r
 
+    def set_tiling(self, tiling) -> None:
+        """Circular convolutions (reference request option ``tiling``: True / "xy" / "x" / "y" / False,
+        unified_pipeline.py:1671-1712 ``set_tiling_mode`` patches every Conv2d's own padding to ``F.pad(mode="circular")``)."""
+        mode = {False: 0, None: 0, True: 3, "xy": 3, "x": 1, "y": 2}.get(tiling, -1)
+        if mode < 0:
+            raise ValueError(f"tiling must be True, False, 'x', 'y' or 'xy', got {tiling!r}")
+        self._tiling = mode
+        if self._handle is not None:
+            _lib.check(getattr(_lib.lib(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(self._handle), mode))
+            self._tiling_applied = (self._handle, mode)
+
+    def _apply_tiling(self, h) -> None:
+        mode = getattr(self, "_tiling", 0)
+        if getattr(self, "_tiling_applied", (None, 0)) != (h, mode):
+            _lib.check(getattr(_lib.lib(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(h), mode))
+            self._tiling_applied = (h, mode)
+
     def _destroy(self):
         if getattr(self, "_handle", None):
             getattr(_lib.lib(), f"gyre_{self._kind}_destroy")(C.c_void_p(self._handle))
@@ -319,6 +336,7 @@ class GyreHipUNet(_NativeModule):
                              f"got {tuple(encoder_hidden_states.shape)}")
         dev = sample.device
         h = self._sync(dev)
+        self._apply_tiling(h)
         if getattr(self, "_tome_applied", (None, None)) != (h, getattr(self, "_tome_r", 0)):
             _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
             self._tome_applied = (h, getattr(self, "_tome_r", 0))
@@ -624,6 +642,7 @@ class GyreHipVAE(_NativeModule):
             raise ValueError(f"expected image [B,{self.config.in_channels},H,W], got {tuple(x.shape)}")
         dev = x.device
         h = self._sync(dev)
+        self._apply_tiling(h)
         x = x.contiguous()
         _lib.require_gpu_tensor(x, "image")
         B, _, H, W = x.shape
@@ -648,6 +667,7 @@ class GyreHipVAE(_NativeModule):
         if z.ndim != 4 or z.shape[1] != self.config.latent_channels:
             raise ValueError(f"expected latents [B,{self.config.latent_channels},h,w], got {tuple(z.shape)}")
         h = self._sync(z.device)
+        self._apply_tiling(h)
         if torch.is_grad_enabled() and z.requires_grad:
             out = _VAEDecodeInputGrad.apply(z, self, h)
         else:

@@ -127,6 +127,9 @@ int gyre_unet_forward(gyre_unet* h, void* stream,
  * the batched time_emb_proj then run for one row that every resnet reads - 1/B of that work, bit-identical results.  Ignored
  * when per-sample added conditioning (temb_add) is given.  A wrong hint gives every sample the first sample's timestep. */
 int gyre_unet_hint_uniform_timestep(gyre_unet* h, int on);
+/* (Both hints are the caller's word.  With GYRE_VERIFY_HINTS=1 in the environment every hinted call first checks the hint on the
+ * device - one compare kernel over t / over the two halves of x, one 4-byte read-back, i.e. a stream synchronisation - and returns
+ * GYRE_ERR_INVALID with a message instead of computing on a wrong assumption: the switch for bringing up a foreign caller.) */
 /* Hint for the NEXT gyre_unet_forward* call on this handle only: the batch is a CFG-parallel pair batch as the reference builds
  * it (unet/cfg.py:49-57: latents cat[x, x], timesteps cat[t, t], contexts cat[uncond, cond]) - sample b and sample b + B/2 have
  * IDENTICAL latents and timestep and differ in their text context only.  Everything in front of the first cross-attention
@@ -159,6 +162,13 @@ int gyre_unet_select_context(gyre_unet* h, int slot);
  * against N - r keys; r is clipped to N / 2 per layer as ToMe does.  0 switches it off (default).  The matching
  * algorithm lives in the un-vendored facebookresearch/ToMe submodule; restated from the paper, parity unpinned. */
 int gyre_unet_set_tome(gyre_unet* h, int r);
+/* Circular ("tiling") convolutions: the reference's request option `tiling` (True / "x" / "y" / "xy") patches every Conv2d of the
+ * UNet and the VAE so that the module's own padding wraps around the image instead of reading zeros
+ * (gyre/pipeline/unified_pipeline.py:1671-1712) - seamless textures.  mode: 0 off, 1 along x, 2 along y, 3 both; sticky until
+ * changed.  The wrapped gather exists in the 4-wave conv kernels only, so such requests run slower; the input-gradient calls
+ * (CLIP guidance) refuse it (GYRE_ERR_UNSUPPORTED). */
+int gyre_unet_set_tiling(gyre_unet* h, int mode);
+int gyre_vae_set_tiling(gyre_vae* h, int mode);
 
 /* gyre_unet_forward_ex plus ControlNet-style residual injection - the optional keyword arguments of the reference's UNet call,
  * unet/core.py:40-64 (`down_block_additional_residuals`, `mid_block_additional_residual`) with the semantics of the in-tree

@@ -71,7 +71,34 @@ def _gn(x: Tensor, sd: SD, p: str, groups: int, eps: float) -> Tensor:
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
+# Circular ("tiling") convolutions, reference gyre/pipeline/unified_pipeline.py:1671-1694 (set_module_tiling): the module's own
+# padding is applied with F.pad(mode="circular") along x (tiling != "y") and / or y (tiling != "x"), zeros on the other axis, and
+# the convolution itself runs unpadded.  TILING is test infrastructure state: set through `tiling(mode)`.
+TILING = None
+
+
+class tiling:
+    """with tiling("xy" | "x" | "y" | True): every _conv below pads circularly as the reference's patched Conv2d does."""
+
+    def __init__(self, mode):
+        self.mode = "xy" if mode is True else mode
+
+    def __enter__(self):
+        global TILING
+        self.prev, TILING = TILING, (self.mode or None)
+        return self
+
+    def __exit__(self, *exc):
+        global TILING
+        TILING = self.prev
+        return False
+
+
 def _conv(x: Tensor, sd: SD, p: str, stride: int = 1, padding: int = 1) -> Tensor:
+    if TILING and padding:
+        x = F.pad(x, (padding, padding, 0, 0), mode="circular" if TILING != "y" else "constant")
+        x = F.pad(x, (0, 0, padding, padding), mode="circular" if TILING != "x" else "constant")
+        padding = 0
     return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
 
 

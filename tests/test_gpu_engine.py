@@ -191,7 +191,13 @@ def test_engine_cancellation_between_unet_calls(tiny_engine):
     images, _ = eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3))
     assert bool(torch.isfinite(images).all())
     with pytest.raises(NotImplementedError):              # -> gRPC UNIMPLEMENTED (services/generate.py:1162-1173)
-        eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, tiling=True))
+        eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, scheduler_noise_type="brownian"))
+    # tiling (unified_pipeline.py:1671-1712, :1845): a request option the native conv gather serves; the next request is plain again
+    tiled, _ = eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3, tiling=True))
+    again, _ = eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3))
+    assert bool(torch.isfinite(tiled).all()) and not torch.equal(tiled, images) and torch.equal(again, images)
+    with pytest.raises(ValueError):
+        eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, tiling="diagonal"))
 
 
 def test_engine_full_size_sd15_request_on_native_modules():

@@ -456,3 +456,39 @@ def test_tiny_unet_controlnet_residual_injection():
         net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[a.to(DEV) for a in adapters[:-1]])
     with pytest.raises(NotImplementedError):
         net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), adapter_states=[[adapters[0]]])
+
+
+@pytest.mark.parametrize("mode", ["xy", "x", "y"])
+def test_tiling_circular_convolutions_match_the_reference_patch(mode):
+    """Request option `tiling` (reference unified_pipeline.py:1671-1712: every Conv2d's own padding becomes F.pad(mode="circular")
+    along x and / or y): tiny UNet and VAE decode / encode against the oracle under the same patch, and the property the option
+    exists for - rolling the input along a circular axis rolls the output (no seam), which zero padding does not give."""
+    ucfg, vcfg = gcfg.tiny_unet(), gcfg.tiny_vae()
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    unet, vae = GyreHipUNet(ucfg), GyreHipVAE(vcfg)
+    unet.load_state_dict(usd); vae.load_state_dict(vsd)
+    unet, vae = unet.to(DEV), vae.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 4, 16, 24, generator=g)
+    ctx = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g)
+    t = torch.tensor([500, 500])
+    plain = unet(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+    unet.set_tiling(mode); vae.set_tiling(mode)
+    try:
+        got = unet(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+        with M.tiling(mode):
+            ref = M.unet_forward(usd, ucfg, x, t, ctx)
+            zref = M.vae_decode(vsd, vcfg, x[:1, :, :8, :12])
+        report(f"tiny UNet tiling={mode}", got, ref, 3e-2)
+        assert rel_l2(got, plain) > 1e-3                          # the option does something
+        img = vae.decode(x[:1, :, :8, :12].to(DEV)).sample.cpu()
+        report(f"tiny VAE decode tiling={mode}", img, zref, 3e-2)
+        # seamless: a circular shift of the latents along a wrapped axis shifts the result (up to bf16 rounding of the same sums)
+        sx, sy = (5 if mode != "y" else 0), (3 if mode != "x" else 0)
+        rolled = unet(torch.roll(x, (sy, sx), (2, 3)).to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+        assert rel_l2(rolled, torch.roll(got, (sy, sx), (2, 3))) < 2e-2
+    finally:
+        unet.set_tiling(False); vae.set_tiling(False)
+    back = unet(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
+    assert torch.equal(back, plain)

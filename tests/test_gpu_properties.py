@@ -227,3 +227,14 @@ def test_folded_layernorm_chain_through_a_depth_two_transformer():
     # every LayerNorm of the 10 transformer blocks (2 + 3 at level 0 with depth 1 -> 5, 2 x 2 + ... ) lost its launch: the folded
     # form runs strictly fewer kernels, and at least one per block comes from a producer's epilogue
     assert n_fused <= n_plain - 10, (n_fused, n_plain)
+
+
+def test_hint_verifier():
+    """GYRE_VERIFY_HINTS=1: gyre_unet_hint_cfg_pairs / _uniform_timestep are checked on the device before they are used; a wrong
+    hint fails the call (GYRE_ERR_INVALID -> ValueError) instead of silently computing the second half from the first."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GYRE_VERIFY_HINTS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_hint_verify_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "CAUGHT:" in out and "hint_cfg_pairs" in out and "DONE" in out, out[-2000:]
