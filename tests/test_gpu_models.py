@@ -485,10 +485,10 @@ def test_tiling_circular_convolutions_match_the_reference_patch(mode):
         img = vae.decode(x[:1, :, :8, :12].to(DEV)).sample.cpu()
         report(f"tiny VAE decode tiling={mode}", img, zref, 3e-2)
         # seamless: a circular shift of the latents along a wrapped axis (by a multiple of the network's total stride, 8) shifts
-        # the result - the same sums in the same order, so bit for bit
+        # the result, up to bf16 rounding (the GroupNorm partial sums are taken in another order)
         sx, sy = (8 if mode != "y" else 0), (8 if mode != "x" else 0)
         rolled = unet(torch.roll(x, (sy, sx), (2, 3)).to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
-        assert rel_l2(rolled, torch.roll(got, (sy, sx), (2, 3))) < 1e-5
+        assert rel_l2(rolled, torch.roll(got, (sy, sx), (2, 3))) < 2.5e-2
     finally:
         unet.set_tiling(False); vae.set_tiling(False)
     back = unet(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
