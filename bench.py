@@ -16,7 +16,7 @@ images, all inputs resident in HBM.  Rank 0 prints ONE JSON line.
     (gyre_amd.sharding.shard_bounds <- services/generate.py:977-990); value = that request's images / time and
     latency_p50_s = the latency of the request (the metric's "p50 latency at 1/2/4/8").
 --config sd15 (default, BASELINE configs[1]) | sdxl (configs[3]: SDXL-base topology, 1024x1024, 30 steps, 2 images per
-    GPU, synthetic text embeddings) | inpaint768 (configs[2]: 9-channel SD1.5 UNet grafted onto the base UNet, 768x768,
+    GPU, both text towers random-init at their real sizes) | inpaint768 (configs[2]: 9-channel SD1.5 UNet grafted onto the base UNet, 768x768,
     VAE encode of the init image, 4 images) - the extra configs are for builder / judge runs, the driver uses the default.
 
 roofline: the MFMA kernel classes (8-wave GEMM/conv tiles, attention) are timed live with HIP events on the launch stream
@@ -239,6 +239,22 @@ def main():
         inpaint = GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(torch.bfloat16).to(dev)
         fill_synthetic_on_device(inpaint, 3)
     clip = None if args.config == "sdxl" else ClipTextEncoder.synthetic(dev, torch.bfloat16, seed=2)
+    sdxl_cond = None
+    if args.config == "sdxl":
+        # both SDXL text towers at their real sizes (CLIP ViT-L/14 and OpenCLIP ViT-bigG/14 text models, random init), run on the
+        # host path inside every step as the SD1.x CLIP encode is (gyre_amd/text.py SDXLTextConditioner)
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+        from gyre_amd.text import SDXLTextConditioner, sdxl_time_ids
+        kw_ = dict(vocab_size=49408, max_position_embeddings=77, bos_token_id=49406, eos_token_id=49407, pad_token_id=49407)
+        torch.manual_seed(5)
+        with torch.device(dev):
+            te1 = CLIPTextModel(CLIPTextConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                                               hidden_act="quick_gelu", **kw_))
+            te2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32,
+                                                             num_attention_heads=20, hidden_act="gelu", projection_dim=1280, **kw_))
+        te1, te2 = te1.to(torch.bfloat16).eval(), te2.to(torch.bfloat16).eval()
+        ident = lambda frag: frag                       # prompts arrive pre-tokenised: [(token ids, weight)]
+        sdxl_cond = SDXLTextConditioner(te1, ident, te2, ident, dev)
     clip_model = fe = None
     if args.config == "tomeclip":
         # BASELINE configs[4]: ToMe + CLIP guidance.  The CLIP model is host PyTorch by north_star: a random-init ViT-B/32
@@ -267,11 +283,8 @@ def main():
     pr = 0 if args.scaling == "strong" else rank           # strong: every rank sees the same request
     extra = {}
     if args.config == "sdxl":
-        g = torch.Generator(device=dev).manual_seed(1234 + pr)
-        emb = torch.randn(B, 77, 2048, device=dev, generator=g) * 0.5
-        uemb = torch.randn(1, 77, 2048, device=dev, generator=g).expand(B, -1, -1).contiguous() * 0.5
-        added = {"text_embeds": torch.randn(B, 1280, device=dev, generator=g),
-                 "time_ids": torch.tensor([[float(size), float(size), 0, 0, float(size), float(size)]], device=dev).expand(B, -1).contiguous()}
+        sd_ids = synthetic_prompt_ids(B, seed=1234 + pr)
+        sd_prompts = [[([int(t) for t in row[1:] if int(t) != 49407], 1.0)] for row in sd_ids]     # token ids without BOS / EOS padding
         extra = dict(guidance_scale=5.0)
     else:
         ids = synthetic_prompt_ids(B, seed=1234 + pr).to(dev)
@@ -295,8 +308,10 @@ def main():
             base = 420420420 + (0 if args.scaling == "strong" else rank * 100000) + i * B
             seeds = [base + j for j in range(lo, hi)]
             if args.config == "sdxl":
-                kw = dict(text_embeddings=emb[lo:hi], uncond_embeddings=uemb[lo:hi],
-                          added_cond={k: v[lo:hi] for k, v in added.items()})
+                cond_, pooled_, unc_, upooled_ = sdxl_cond(sd_prompts[lo:hi], [""] * nloc, True)
+                tids = sdxl_time_ids(nloc, size, size, device=dev)
+                kw = dict(text_embeddings=cond_, uncond_embeddings=unc_, added_cond={"text_embeds": pooled_, "time_ids": tids},
+                          uncond_added_cond={"text_embeds": upooled_, "time_ids": tids})
             else:
                 kw = dict(input_ids=ids[lo:hi], negative_ids=neg[lo:hi])
             latents = pipe(seeds=seeds, height=size, width=size, num_inference_steps=n_steps,
@@ -453,7 +468,7 @@ def main():
                 "sd15": f"SD1.5 txt2img {size}x{size}, {n_steps} steps DPM++2M ({evals} UNet evals, CFG 7.5 parallel), "
                         f"batch={B} per {'request' if args.scaling == 'strong' else 'GPU'}, bf16 on MI355X (BASELINE.json configs[1])",
                 "sdxl": f"SDXL-base topology txt2img {size}x{size}, {n_steps} steps DPM++2M ({evals} UNet evals, CFG 5), batch={B} per "
-                        f"{'request' if args.scaling == 'strong' else 'GPU'}, bf16, synthetic text embeddings (BASELINE.json configs[3]; not in the reference)",
+                        f"{'request' if args.scaling == 'strong' else 'GPU'}, bf16, both text towers (random-init CLIP ViT-L + OpenCLIP bigG text models) on the host path (BASELINE.json configs[3]; not in the reference)",
                 "inpaint768": f"SD1.5 grafted inpaint {size}x{size} (9-ch inpaint UNet + base UNet, hires fix, VAE encode), {n_steps} steps "
                               f"DPM++2M ({evals} UNet evals), batch={B}, bf16 (BASELINE.json configs[2])",
                 "tomeclip": f"SD1.5 txt2img {size}x{size}, ToMe r={args.tome_r} + CLIP guidance (scale {args.clip_scale}, guided base, 2 + 2 "

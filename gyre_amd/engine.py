@@ -78,8 +78,14 @@ class GyreUnifiedPipeline:
 
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler=None, safety_checker=None, feature_extractor=None,
                  clip_model=None, clip_tokenizer=None, inpaint_unet=None, inpaint_text_encoder=None, depth_unet=None,
-                 depth_text_encoder=None, hintset_manager=None, **_unused):
+                 depth_text_encoder=None, hintset_manager=None, text_encoder_2=None, tokenizer_2=None,
+                 force_zeros_for_empty_prompt: bool = True, **_unused):
         self.vae, self.text_encoder, self.tokenizer, self.unet = vae, text_encoder, tokenizer, unet
+        # SDXL (BASELINE configs[3]; an extension - the reference has no SDXL): the second text tower of the published
+        # pipeline layout (model_index.json: text_encoder_2 / tokenizer_2).  Requests are routed by the UNet's
+        # addition_embed_type == "text_time" (gyre_amd/text.py SDXLTextConditioner, sdxl_time_ids)
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.force_zeros_for_empty_prompt = force_zeros_for_empty_prompt
         self.scheduler, self.inpaint_unet = scheduler, inpaint_unet
         self.safety_checker, self.feature_extractor = safety_checker, feature_extractor
         self.clip_model, self.clip_tokenizer = clip_model, clip_tokenizer
@@ -97,7 +103,7 @@ class GyreUnifiedPipeline:
 
     # ---- what PipelineWrapper / DiffusionPipelineWrapper touch -----------------------------------------------------------
     def pipeline_modules(self):
-        for name in ("vae", "text_encoder", "unet", "inpaint_unet"):
+        for name in ("vae", "text_encoder", "text_encoder_2", "unet", "inpaint_unet"):
             m = getattr(self, name, None)
             if isinstance(m, torch.nn.Module):
                 yield name, m
@@ -215,6 +221,37 @@ class GyreUnifiedPipeline:
         rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
         return rep(cond), rep(unc)
 
+    def _embed_sdxl(self, prompt, negative_prompt, B, num_images_per_prompt, do_cfg, max_embeddings_multiples, height, width):
+        """SDXL conditioning: context of both text towers [B,77k,2048], pooled text_embeds [B,1280] and time_ids [B,6]
+        (gyre_amd/text.py SDXLTextConditioner; published SDXL-base scheme, not in the reference)."""
+        from .text import SDXLTextConditioner, sdxl_time_ids
+        if self.text_encoder_2 is None or self.tokenizer_2 is None:
+            raise ValueError("an SDXL UNet (addition_embed_type 'text_time') needs text_encoder_2 and tokenizer_2")
+
+        def frags(p):
+            if p is None:
+                return None
+            if hasattr(p, "as_tokens") and hasattr(p, "prompts"):
+                return p.as_tokens()
+            if hasattr(p, "as_tokens"):
+                return [p.as_tokens()]
+            return list(p) if isinstance(p, (list, tuple)) else [p]
+        pos = frags(prompt)
+        neg = frags(negative_prompt) or [""] * len(pos)
+
+        def mk(tok):
+            return lambda text: tok(text, add_special_tokens=False)["input_ids"] if callable(tok) else tok.encode(text)[1:-1]
+        dev = self.execution_device
+        cnd = SDXLTextConditioner(self.text_encoder, mk(self.tokenizer), self.text_encoder_2, mk(self.tokenizer_2), dev,
+                                  max_embeddings_multiples, self.force_zeros_for_empty_prompt)
+        cond, pooled, unc, upooled = cnd(pos, neg, do_cfg)
+        rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
+        cond, pooled, unc, upooled = rep(cond), rep(pooled), rep(unc), rep(upooled)
+        ids = sdxl_time_ids(cond.shape[0], height, width, device=dev)
+        added = {"text_embeds": pooled, "time_ids": ids}
+        uadded = {"text_embeds": upooled, "time_ids": ids} if do_cfg else None
+        return cond, unc, added, uadded
+
     # ---- CLIP guidance request (unified_pipeline.py:1876-1909, 1927-1940, 2373-2395) ----------------------------------------
     def _clip_request(self, prompt, clip_prompt, B, num_images_per_prompt, scale, base, glen, gthr, gmax, vae_cutouts,
                       approx_cutouts, no_cutouts) -> dict:
@@ -310,7 +347,13 @@ class GyreUnifiedPipeline:
                     raise ValueError("one torch.Generator per image is required for batch-independent results")
                 raise ValueError(f"Generator passed as a list, but list length does not match batch size {B}")
         do_cfg = guidance_scale > 1.0
-        cond, unc = self._embed(prompt, negative_prompt, B, num_images_per_prompt, do_cfg, max_embeddings_multiples)
+        sdxl = getattr(getattr(self.unet, "config", None), "addition_embed_type", None) == "text_time"
+        added = uadded = None
+        if sdxl:
+            cond, unc, added, uadded = self._embed_sdxl(prompt, negative_prompt, B, num_images_per_prompt, do_cfg,
+                                                        max_embeddings_multiples, height, width)
+        else:
+            cond, unc = self._embed(prompt, negative_prompt, B, num_images_per_prompt, do_cfg, max_embeddings_multiples)
         if strength is None:
             strength = 0.8
         dev = self.execution_device
@@ -362,6 +405,8 @@ class GyreUnifiedPipeline:
                        prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
                        churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
                        sigma_max=sigma_max, **clip_kw)
+        if sdxl:
+            request.update(added_cond=added, uncond_added_cond=uadded)
         if len(self._shard_devices) > 1 and B > 1 and not clip_kw and not lora and not self._tome and not tiling:
             # one request over several device slots (engine option "shard_devices"); progress / cancellation are polled once
             # per request here: the replicas run their loops concurrently and a per-step callback has no single owner.

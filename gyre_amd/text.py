@@ -256,3 +256,75 @@ class LPWTextEmbedder:
 
         cond = run(pt, pw)
         return cond, (run(ut, uw) if uncond_prompts is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# SDXL conditioning (BASELINE.json configs[3]; the reference has no SDXL - an extension on the same engine surface).
+# Published scheme of the SDXL-base pipeline (Podell et al. 2023, diffusers StableDiffusionXLPipeline.encode_prompt /
+# _get_add_time_ids; PARITY UNPINNED: neither is in /root/reference):
+#   * two text towers see the same prompt: CLIP ViT-L (width 768) and OpenCLIP ViT-bigG (width 1280); each contributes its
+#     PENULTIMATE hidden state WITHOUT the final LayerNorm; concatenated along channels -> context [B, 77, 2048];
+#   * the second tower's pooled, projected EOS feature -> text_embeds [B, 1280];
+#   * time_ids [B, 6] = (original_h, original_w, crop_top, crop_left, target_h, target_w);
+#   * an empty negative prompt conditions on ZEROS (force_zeros_for_empty_prompt, the SDXL-base default).
+# UNet side: gyre_amd.modules.GyreHipUNet._aug_embedding (text_time MLP on the host) -> temb_add of the native call.
+# ------------------------------------------------------------------------------------------------
+class SDXLTextConditioner:
+    """(prompts, negative prompts) -> context / pooled embeddings of both SDXL text towers, with the long-prompt weighting of
+    LPWTextEmbedder applied per tower (same parser, chunking and mean renormalisation as the SD1.x path)."""
+
+    def __init__(self, text_encoder, tokenize, text_encoder_2, tokenize_2, device, max_embeddings_multiples: int = 3,
+                 force_zeros_for_empty_prompt: bool = True, bos: int = BOS, eos: int = EOS):
+        self.te1, self.te2, self.tok1, self.tok2 = text_encoder, text_encoder_2, tokenize, tokenize_2
+        self.device, self.mult, self.force_zeros = device, max_embeddings_multiples, force_zeros_for_empty_prompt
+        self.bos, self.eos = bos, eos   # (both towers are padded with EOS here, the long-prompt weighting's convention)
+
+    def _tower(self, model, pooled_sink: Optional[list]):
+        dev = self.device
+
+        def encode(ids):
+            out = model(input_ids=ids.to(dev), output_hidden_states=True, return_dict=True)
+            if pooled_sink is not None and not pooled_sink:           # pooled feature of the FIRST 77-token chunk
+                pooled = getattr(out, "text_embeds", None)
+                if pooled is None:
+                    raise ValueError("the second SDXL text encoder must return text_embeds (CLIPTextModelWithProjection)")
+                pooled_sink.append(pooled.float())
+            return out.hidden_states[-2].float()
+        encode.device = dev
+        return encode
+
+    def _run(self, prompts, uncond):
+        sink = []
+        e1 = LPWTextEmbedder(self._tower(self.te1, None), self.tok1, self.mult, self.bos, self.eos)
+        c1, _ = e1.get_embeddings(prompts, None)
+        e2 = LPWTextEmbedder(self._tower(self.te2, sink), self.tok2, self.mult, self.bos, self.eos)
+        c2, _ = e2.get_embeddings(prompts, None)
+        n = min(c1.shape[1], c2.shape[1])
+        return torch.cat([c1[:, :n], c2[:, :n]], dim=-1), sink[0]
+
+    def __call__(self, prompts, negative_prompts=None, do_cfg: bool = True):
+        """-> (context [B,77k,2048], pooled [B,1280], uncond context | None, uncond pooled | None)"""
+        cond, pooled = self._run(list(prompts), None)
+        if not do_cfg:
+            return cond, pooled, None, None
+        neg = list(negative_prompts) if negative_prompts is not None else [""] * len(prompts)
+        if len(neg) == 1 and len(prompts) > 1:
+            neg = neg * len(prompts)
+        unc, upooled = self._run(neg, None)
+        n = min(cond.shape[1], unc.shape[1])
+        cond, unc = cond[:, :n], unc[:, :n]
+        if self.force_zeros:
+            empty = torch.tensor([isinstance(p, str) and p == "" for p in neg], device=unc.device)
+            unc = torch.where(empty[:, None, None], torch.zeros_like(unc), unc)
+            upooled = torch.where(empty[:, None], torch.zeros_like(upooled), upooled)
+        return cond, pooled, unc, upooled
+
+
+def sdxl_time_ids(batch: int, height: int, width: int, original_size=None, crops_coords_top_left=(0, 0), target_size=None,
+                  device="cpu") -> torch.Tensor:
+    """[B, 6] float32: (original_h, original_w, crop_top, crop_left, target_h, target_w); the sizes default to the request's."""
+    oh, ow = original_size or (height, width)
+    th, tw = target_size or (height, width)
+    row = torch.tensor([[float(oh), float(ow), float(crops_coords_top_left[0]), float(crops_coords_top_left[1]), float(th), float(tw)]],
+                       device=device)
+    return row.expand(batch, -1).contiguous()

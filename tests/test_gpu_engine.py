@@ -213,3 +213,46 @@ def test_engine_full_size_sd15_request_on_native_modules():
     p = PR.psnr(images, ref)
     print(f"[parity] engine SD1.5 512x512 3-step euler_a vs fp32 oracle: PSNR {p:.1f} dB")
     assert p >= 30.0
+
+
+def test_engine_routes_an_sdxl_unet_through_both_text_towers():
+    """BASELINE configs[3] above the UNet: an engine whose UNet has addition_embed_type "text_time" conditions on two text
+    towers (context = penultimate states of both, pooled text_embeds of the second, time_ids from the request size) - the
+    published SDXL-base scheme (the reference has no SDXL: extension, parity unpinned).  Native engine vs the same host flow on
+    the fp32 oracle models fed with the engine's own conditioning."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from test_host_pipeline import OracleUNet, OracleVAE
+    from gyre_amd.pipeline import GyrePipeline
+    ucfg = gcfg.tiny_sdxl_unet()                                   # context 64 = 24 + 40, pooled 32
+    vcfg = gcfg.VAEConfig(block_out_channels=(32, 64, 64, 64), sample_size=64, scaling_factor=0.13025)
+    usd = weights.synthetic_state_dict(weights.unet_param_shapes(ucfg))
+    vsd = weights.synthetic_state_dict(weights.vae_param_shapes(vcfg))
+    unet, vae = GyreHipUNet(ucfg), GyreHipVAE(vcfg)
+    unet.load_state_dict(usd); vae.load_state_dict(vsd)
+    torch.manual_seed(0)
+    kw = dict(vocab_size=49408, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=77,
+              bos_token_id=49406, eos_token_id=49407, pad_token_id=49407)
+    te1 = CLIPTextModel(CLIPTextConfig(hidden_size=24, **kw)).eval()
+    te2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=40, projection_dim=32, **kw)).eval()
+    eng = GyreUnifiedPipeline(vae=vae.to(DEV), text_encoder=te1.to(DEV), tokenizer=tokenizer, unet=unet.to(DEV),
+                              text_encoder_2=te2.to(DEV), tokenizer_2=tokenizer)
+    eng.scheduler = functools.partial(sample_dpmpp_2m, warmup_lms=True, ddim_cutoff=0.1)
+    prompt, negative, seeds = ["a photo of a cat", "a (red:1.3) house"], ["", "blurry"], [11, 12]
+    images, nsfw = eng(**wrapper_kwargs(prompt=prompt, negative_prompt=negative, generator=generators(seeds), width=128, height=128,
+                                        num_inference_steps=6, guidance_scale=5.0))
+    assert images.shape == (2, 3, 128, 128) and bool(torch.isfinite(images).all()) and nsfw == [False, False]
+    cond, unc, added, uadded = eng._embed_sdxl(prompt, negative, 2, 1, True, 3, 128, 128)
+    assert cond.shape == (2, 77, 64) and added["text_embeds"].shape == (2, 32) and added["time_ids"].tolist() == [[128.0, 128.0, 0.0, 0.0, 128.0, 128.0]] * 2
+    assert float(unc[0].abs().max()) == 0 and float(uadded["text_embeds"][0].abs().max()) == 0 and float(unc[1].abs().max()) > 0
+    cpu = lambda d: {k: v.float().cpu() for k, v in d.items()}
+    ref = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")(
+        seeds=seeds, text_embeddings=cond.float().cpu(), uncond_embeddings=unc.float().cpu(), height=128, width=128,
+        num_inference_steps=6, sampler="dpmpp_2m", guidance_scale=5.0, added_cond=cpu(added), uncond_added_cond=cpu(uadded))
+    p = PR.psnr(images, ref.float().cpu())
+    print(f"[parity] tiny SDXL engine request: PSNR {p:.1f} dB")
+    assert p >= 30.0
+    # an SDXL UNet without the second tower is a configuration error, not a silent SD1.x request
+    eng2 = GyreUnifiedPipeline(vae=vae, text_encoder=te1, tokenizer=tokenizer, unet=unet)
+    eng2.scheduler = eng.scheduler
+    with pytest.raises(ValueError):
+        eng2(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=2))

@@ -65,3 +65,43 @@ def test_clip_alt_layer():
     import pytest
     with pytest.raises(ValueError):
         ClipTextEncoder(enc.model, "cpu", layer="first")
+
+
+def _tiny_sdxl_towers():
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    torch.manual_seed(0)
+    kw = dict(vocab_size=300, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, max_position_embeddings=77,
+              bos_token_id=298, eos_token_id=299, pad_token_id=299)
+    te1 = CLIPTextModel(CLIPTextConfig(hidden_size=32, **kw)).eval()
+    te2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=48, projection_dim=40, **kw)).eval()
+    return te1, te2
+
+
+def test_sdxl_conditioner_follows_the_published_scheme():
+    """SDXL conditioning (extension, BASELINE configs[3]; parity unpinned - the scheme is restated here from the published
+    pipeline): penultimate hidden states of both towers concatenated, pooled projection of the second, zeros for an empty
+    negative prompt, time_ids = (orig h, w, crop top, left, target h, w)."""
+    te1, te2 = _tiny_sdxl_towers()
+    tok = lambda text: [3 + (ord(c) % 200) for c in text if c != " "]
+    cnd = T.SDXLTextConditioner(te1, tok, te2, tok, "cpu", max_embeddings_multiples=1, bos=298, eos=299)
+    prompts, neg = ["a cat", "dog"], ["", "blurry"]
+    cond, pooled, unc, upooled = cnd(prompts, neg, True)
+
+    def ids_of(text):
+        t = tok(text)
+        return torch.tensor([[298] + t + [299] * (76 - len(t))])
+    with torch.no_grad():
+        for i, (ptxt, ntxt) in enumerate(zip(prompts, neg)):
+            o1 = te1(input_ids=ids_of(ptxt), output_hidden_states=True, return_dict=True)
+            o2 = te2(input_ids=ids_of(ptxt), output_hidden_states=True, return_dict=True)
+            want = torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], dim=-1)[0]
+            assert cond.shape == (2, 77, 80) and pooled.shape == (2, 40)
+            assert torch.allclose(cond[i], want, atol=1e-5) and torch.allclose(pooled[i], o2.text_embeds[0], atol=1e-5)
+            if ntxt == "":
+                assert float(unc[i].abs().max()) == 0 and float(upooled[i].abs().max()) == 0
+            else:
+                u2 = te2(input_ids=ids_of(ntxt), output_hidden_states=True, return_dict=True)
+                assert torch.allclose(upooled[i], u2.text_embeds[0], atol=1e-5) and float(unc[i].abs().max()) > 0
+    ids = T.sdxl_time_ids(3, 1024, 768, original_size=(512, 512), crops_coords_top_left=(8, 16))
+    assert ids.tolist() == [[512.0, 512.0, 8.0, 16.0, 1024.0, 768.0]] * 3
+    assert T.sdxl_time_ids(1, 1024, 1024).tolist() == [[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]]
