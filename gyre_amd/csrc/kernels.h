@@ -49,6 +49,10 @@ int launch_groupnorm_apply(hipStream_t st, const GnParams& p);   // y = act(a*x+
 bool gn_use_small(int HW, int C, int C1, int G);                 // one-launch path for small feature maps
 bool gn_accepts_colstats(const GnParams& p);                     // cs_unit / shapes fit the producer-statistics form of the apply
 int launch_groupnorm_small(hipStream_t st, const GnParams& p);
+// GroupNorm (affine only) folded into the Linear / 1x1 conv W[N][C] (+ bias) that consumes it: per sample b the scaled weights
+// Wf[b][N][C] (bf16) and the bias row bf[b][N] (fp32); statistics from p.cs_x (producer column statistics) or p.partial
+// (launch_groupnorm_stats).  Consumed by a GEMM with GemmParams::w_sample_stride = N * C and rowbias = bf.
+int launch_gn_fold(hipStream_t st, const GnParams& p, const bf16_t* W, const float* bias, int N, bf16_t* Wf, float* bf);
 int launch_layernorm(hipStream_t st, const bf16_t* x, int M, int C, const float* gamma, const float* beta, float eps,
                      bf16_t* y);
 // stats[m] = (rstd, rstd * mean) of row m: the input of a GEMM with the LayerNorm folded in (GemmParams::ln_stats)
@@ -124,6 +128,10 @@ struct GemmParams {
     // first use and sets w_packed, tests pass a scratch buffer through gyre_debug_set_ar_workspace); no_ar = the caller wants a
     // feature that kernel lacks from this launch (column statistics for a GroupNorm)
     const void* w_packed = nullptr; int ar_ok = 0, no_ar = 0;
+    // per-SAMPLE weights (8-wave tile configs 4 - 8, linear mode): rows of sample b = row / rows_per_sample read W + b *
+    // w_sample_stride (elements); row blocks never straddle a sample (gemm_per_sample_w_ok).  The GroupNorm folded into a
+    // Transformer2D's proj_in (launch_gn_fold); the per-sample bias travels as `rowbias`
+    size_t w_sample_stride = 0;
     // conv: circular instead of zero padding along x (bit 0) / y (bit 1) - the reference's request option "tiling"
     // (unified_pipeline.py:1671-1712 patches every Conv2d's own padding to F.pad(mode="circular")); 4-wave tile configs only
     int wrap = 0;
@@ -132,6 +140,8 @@ struct GemmParams {
 int gemm_colstat_rows(const GemmParams& p);
 // number of N tiles (= partial sums per row) launch_gemm would emit into rowstat_out for `p`; 0: this problem cannot
 int gemm_rowstat_parts(const GemmParams& p);
+// true when launch_gemm would run `p` on a kernel that reads per-sample weights (w_sample_stride; rows_per_sample set)
+bool gemm_per_sample_w_ok(const GemmParams& p);
 // true when launch_gemm would run `p` (ln_colsum set or not) on a kernel that supports the folded LayerNorm
 bool gemm_ln_fusable(const GemmParams& p);
 // W'[n][k] = bf16(W[n][k] * gamma[k]); colsum[n] = sum_k W'[n][k]; bias_out[n] = sum_k beta[k] * W[n][k] + (bias ? bias[n] : 0)

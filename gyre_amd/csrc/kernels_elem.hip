@@ -505,6 +505,93 @@ int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
 }
 
 // ------------------------------------------------------------------------------
+// GroupNorm folded into the 1x1 / Linear that consumes it (the affine-only norm in front of a Transformer2D's proj_in):
+//   proj_in(GN(x))[b, p, n] = sum_k W[n][k] (a[b][k] x[b,p,k] + s[b][k]) + bias[n]
+//                           = sum_k (W[n][k] a[b][k]) x[b,p,k]  +  (bias[n] + sum_k W[n][k] s[b][k])
+// with a[b][k] = rstd[b, g(k)] gamma[k], s[b][k] = beta[k] - mean[b, g(k)] a[b][k]: per SAMPLE a C x C weight matrix (bf16,
+// rounded once after the fp32 scaling) and a bias row - 3.3 MB at C = 320 for 16 samples against the 84 MB the apply pass
+// reads and writes at 64 x 64.  The statistics are finished in the prologue exactly as k_gn_apply_fin does (from the
+// producer's column statistics or from k_gn_partial's partials, same order); workgroup (row block, sample) then writes its
+// rows of W'_b and bias'_b.  The GEMM reads W'_b through GemmParams::w_sample_stride and bias'_b as its per-sample row bias.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_fold(GnParams p, const bf16_t* __restrict__ W, const float* __restrict__ bias, int N,
+                                                 bf16_t* __restrict__ Wf, float* __restrict__ bf, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ab = (float*)smem_raw;                 // [2][C]
+    float* red_s = ab + 2 * p.C;                  // [256]
+    float* red_q = red_s + 256;
+    float* mean_s = red_q + 256;
+    float* rstd_s = mean_s + 256;
+    const int n = blockIdx.y;
+    const int cpg = p.C / p.G;
+    {
+        const float cnt = (float)p.HW * (float)cpg;
+        int parts = 256 / p.G;
+        if (parts < 1) parts = 1;
+        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+        float a = 0.f, b = 0.f;
+        if (p.cs_x) {
+            const int unit = p.cs_unit, nu = p.C / unit, u0 = g * cpg / unit, u1 = (g + 1) * cpg / unit;
+            if (part < parts)
+                for (int ch = part; ch < p.cs_x_chunks; ch += parts) {
+                    const float2* src = (const float2*)p.cs_x + ((size_t)n * p.cs_x_chunks + ch) * nu;
+                    for (int u = u0; u < u1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
+                }
+        } else if (part < parts)
+            for (int ch = part; ch < p.nchunks; ch += parts) {
+                const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
+                a += src[0]; b += src[1];
+            }
+        red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
+        __syncthreads();
+        if (threadIdx.x < p.G) {
+            float sa = 0.f, sb = 0.f;
+            for (int q = 0; q < parts; ++q) { sa += red_s[q * p.G + g]; sb += red_q[q * p.G + g]; }
+            const float mean = sa / cnt;
+            const float var = fmaxf(sb / cnt - mean * mean, 0.f);
+            mean_s[g] = mean;
+            rstd_s[g] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            const int gg = c / cpg;
+            const float aa = rstd_s[gg] * p.gamma[c];
+            ab[c] = aa;
+            ab[p.C + c] = p.beta[c] - mean_s[gg] * aa;
+        }
+        __syncthreads();
+    }
+    // one wave per weight row: 8 channels per lane and step, the shift term reduced over the wave in a fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_end = min(N, (int)(blockIdx.x + 1) * rows_per_block);
+    for (int r = blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
+        const bf16_t* wr = W + (size_t)r * p.C;
+        bf16_t* wo = Wf + ((size_t)n * N + r) * p.C;
+        float acc = 0.f;
+        for (int c = lane * 8; c < p.C; c += 512) {
+            float f[8];
+            unpack8(*(const uint4*)(wr + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc = fmaf(f[j], ab[p.C + c + j], acc); f[j] *= ab[c + j]; }
+            *(uint4*)(wo + c) = pack8(f);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) bf[(size_t)n * N + r] = acc + (bias ? bias[r] : 0.f);
+    }
+}
+int launch_gn_fold(hipStream_t st, const GnParams& p, const bf16_t* W, const float* bias, int N, bf16_t* Wf, float* bf) {
+    if (p.C % 8 || p.C % p.G || p.G > 256 || p.C1 != p.C) GYRE_FAIL(-1, "gn_fold: one source, C a multiple of 8 and of the groups");
+    if (p.cs_x && (p.cs_unit <= 0 || (p.C / p.G) % p.cs_unit || p.cs_x_chunks <= 0)) GYRE_FAIL(-1, "gn_fold: bad producer statistics");
+    const int rows_per_block = 32;
+    const size_t lds = ((size_t)2 * p.C + 4 * 256) * sizeof(float);
+    GyreProfScope prof_(KC_GN_APPLY, st, 0.0, (double)p.B * N * p.C * 2.0 + (double)N * p.C * 2.0);
+    hipLaunchKernelGGL(k_gn_fold, dim3((N + rows_per_block - 1) / rows_per_block, p.B), dim3(256), lds, st, p, W, bias, N, Wf, bf, rows_per_block);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------
 // GroupNorm(+SiLU) in ONE launch for small feature maps (16x16 / 8x8 UNet levels): one workgroup per
 // (sample, group) loads its HW x (C/G) slab once into registers (8-byte vectors), reduces mean, then the
 // centred sum of squares (true two-pass variance), normalises and writes.  Replaces three latency-bound

@@ -412,6 +412,8 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     }
     const int Hlim = p.ups ? (p.Hup ? p.Hup : 2 * p.Hi) : p.Hi, Wlim = p.ups ? (p.Wup ? p.Wup : 2 * p.Wi) : p.Wi;
     const bf16_t* zero = p.zero_page;
+    // per-sample weights (GemmParams::w_sample_stride: a GroupNorm folded into this layer): the tile's rows belong to ONE sample
+    const bf16_t* wbase = p.W + (p.w_sample_stride ? (size_t)(m0 / p.rows_per_sample) * p.w_sample_stride : (size_t)0);
 
     auto issue_stage = [&](int kc, int s) {
         char* sbase = smem_raw + s * STAGE_BYTES + wave * 1024;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int n = n0 + r0 + 64 * i;
-            const bf16_t* src = (kok && n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN)) ? p.W + (size_t)n * p.K + kw : zero;
+            const bf16_t* src = (kok && n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN)) ? wbase + (size_t)n * p.K + kw : zero;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
         }
     };
@@ -1262,6 +1264,20 @@ static bool gemm_staged_epilogue_ok(const GemmParams& p) {
     return p.out_mode == OUT_BF16 && (n_out % 8) == 0 && (p.ldc % 8) == 0 && (!p.residual || (p.ldr % 8) == 0) &&
            (((size_t)p.out | (size_t)p.residual) & 15) == 0;
 }
+bool gemm_per_sample_w_ok(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    if (g_force_cfg || p.force_cfg || (p.debug & 0x40000000) || g_invariant_batch > 0) return false;   // bit 30: GroupNorm keeps its apply pass
+    if (p.mode != GEMM_LINEAR || p.A2 || p.batch > 1 || p.geglu || p.vt_out || p.ln_colsum || p.rows_per_sample <= 0 ||
+        p.M % p.rows_per_sample || p.K % 8 || p.N % 8)
+        return false;
+    if (!gemm_staged_epilogue_ok(p)) return false;
+    int splits = 1;
+    const int cfg = plan_cfg(p, &splits);
+    if (cfg < 4 || cfg > 8 || splits > 1) return false;
+    const int bm = (cfg == 4 || cfg == 6) ? 256 : 128;
+    return p.rows_per_sample % bm == 0;
+}
 bool gemm_ln_fusable(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;
@@ -1291,7 +1307,7 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;
     if (g_force_cfg || p.force_cfg || (p.debug & 0x8800) || g_invariant_batch > 0) return 0;    // bit 15: separate statistics pass
-    if (p.mode != GEMM_LINEAR || p.A2 || p.rowbias || p.geglu || p.vt_out || p.ln_colsum || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 8)
+    if (p.mode != GEMM_LINEAR || p.A2 || p.geglu || p.vt_out || p.ln_colsum || p.batch > 1 || p.M <= 0 || p.K % 8 || p.N % 8)
         return 0;
     if (!gemm_staged_epilogue_ok(p)) return 0;
     int splits = 1;
@@ -1356,7 +1372,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             p.vt_col0 <= 0 || p.vt_col0 >= p.N || p.N % 8)
             GYRE_FAIL(-1, "gemm: bad fused Q|K|V arguments");
     }
-    if (p.rowstat_out && (p.ln_colsum || p.mode != GEMM_LINEAR || p0.A2 || p.geglu || p.vt_out || p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
+    if (p.rowstat_out && (p.ln_colsum || p.mode != GEMM_LINEAR || p0.A2 || p.geglu || p.vt_out || p.out_mode != OUT_BF16 || p.batch > 1))
         GYRE_FAIL(-1, "gemm: row statistics come from a plain single-source linear problem with bf16 row-major output");
     if (p.ln_colsum && (p.mode != GEMM_LINEAR || p0.A2 || !p.bias || (!p.ln_stats && p.ln_nparts <= 0) || (p.ln_nparts > 0 && !p.ln_parts) ||
                         p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
@@ -1390,6 +1406,11 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         const int want = splits > 1 ? cs_red_rows(p.rows_per_sample) : cfg == 4 ? 256 : (cfg == 5 || cfg == 8) ? 128 : (cfg == 24 && p.mode == GEMM_CONV3) ? 256 : -1;
         if (rows <= 0 || rows != want)
             GYRE_FAIL(-6, "gemm: column statistics are not available for this problem / tile configuration (see gemm_colstat_rows)");
+    }
+    if (p.w_sample_stride) {
+        const int bm = (cfg == 4 || cfg == 6) ? 256 : 128;
+        if (cfg < 4 || cfg > 8 || splits > 1 || p.mode != GEMM_LINEAR || p.rows_per_sample % bm || p.M % p.rows_per_sample)
+            GYRE_FAIL(-6, "gemm: per-sample weights need an unsplit 8-wave tile config whose row blocks do not straddle samples (gemm_per_sample_w_ok)");
     }
     if (p.mode == GEMM_CONV3 && p.wrap && cfg > 3) GYRE_FAIL(-6, "gemm: circular padding (tiling) exists in the 4-wave tile configs only");
     if (cfg == 30) {

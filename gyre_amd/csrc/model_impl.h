@@ -455,6 +455,49 @@ struct Exec {
         p.out = y; p.out_mode = OUT_BF16_T; p.tokens_per_batch = tokens; p.ldt = ldt;
         return launch_gemm(st, p);
     }
+    // y = Linear(GroupNorm(x)) with the (affine-only) norm folded into per-sample weights (launch_gn_fold): the normalised tensor
+    // is never written.  Taken at the large maps, where the apply pass costs more than B copies of the C x C weights (64 x 64:
+    // 84 MB against 3.3 MB; 32 x 32: 42 against 13; 16 x 16 would be 10 against 52) and the planner's kernel reads per-sample
+    // weights; *folded tells the caller whether it happened.
+    int gn_fold_linear(const Tn& x, const float* g, const float* b, float eps, const bf16_t* w, const float* bias, int N, Tn& y,
+                       RowStatBuf* rs, bool* folded) {
+        *folded = false;
+        const int C = x.C, HW = x.H * x.W, M = x.rows();
+        if (!store || (size_t)x.B * N * C * 2 > (size_t)M * C * 2 || gn_use_small(HW, C, C, groups) || C % groups) return 0;
+        GemmParams p;
+        p.A = x.p; p.lda = C; p.mode = GEMM_LINEAR; p.W = w; p.K = C; p.N = N; p.M = M; p.samples = batch;
+        p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16; p.rows_per_sample = HW; p.ld_rowbias = N;
+        p.rowbias = (const float*)(uintptr_t)256;              // (planning only: any aligned non-null value)
+        if (!gemm_per_sample_w_ok(p)) return 0;
+        Tn ws, wf, bfv;
+        TRY(alloc_raw(ws, gn_workspace_bytes(x.B, HW, C, groups)));
+        TRY(alloc_raw(wf, (size_t)x.B * N * C * 2));
+        TRY(alloc_raw(bfv, (size_t)x.B * N * sizeof(float)));
+        if (rs) {
+            rs->nparts = gemm_rowstat_parts(p);
+            if (rs->nparts > 0) TRY(alloc_raw(rs->t, (size_t)rs->nparts * M * 2 * sizeof(float)));
+        }
+        if (!dry()) {
+            GnParams gp;
+            gp.x = x.p; gp.x2 = x.p; gp.C1 = C; gp.B = x.B; gp.HW = HW; gp.C = C; gp.G = groups;
+            gp.gamma = g; gp.beta = b; gp.eps = eps; gp.silu = 0;
+            gp.nchunks = gn_pick_chunks(x.B, HW, C);
+            gp.partial = (float*)ws.p;
+            gp.scale_shift = (float*)((char*)ws.p + align_up((size_t)x.B * gp.nchunks * groups * 2 * sizeof(float), 256));
+            if (x.cs_chunks > 0) {
+                gp.cs_unit = x.cs_unit;
+                if (gn_accepts_colstats(gp)) { gp.cs_x = x.cs; gp.cs_x_chunks = x.cs_chunks; }
+            }
+            if (!gp.cs_x) TRY(launch_groupnorm_stats(st, gp));      // partials (the fold kernel finishes them)
+            TRY(launch_gn_fold(st, gp, w, bias, N, wf.p, (float*)bfv.p));
+            p.W = wf.p; p.w_sample_stride = (size_t)N * C; p.bias = nullptr; p.rowbias = (const float*)bfv.p;
+            if (rs && rs->nparts > 0) p.rowstat_out = (float*)rs->t.p;
+            TRY(launch_gemm(st, p));
+        }
+        free(ws); free(wf); free(bfv);
+        *folded = true;
+        return 0;
+    }
     int layernorm(const Tn& x, const float* g, const float* b, Tn& y) {
         TRY(alloc(y, x.B, x.H, x.W, x.C));
         if (dry()) return 0;
@@ -642,11 +685,15 @@ struct Exec {
         const int C = w.c;
         Tn x = x_in;
         Tn a, h;
-        TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
-        TRY(alloc(h, B, x.H, x.W, C));
         RowStatBuf rs_h;                 // statistics of the current block input, when its producer could leave them
-        TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C, sv ? nullptr : &rs_h));
-        free(a);
+        TRY(alloc(h, B, x.H, x.W, C));
+        bool folded = false;
+        if (!sv) TRY(gn_fold_linear(x, w.ng, w.nb, 1e-6f, w.pin, w.pinb, C, h, &rs_h, &folded));
+        if (!folded) {
+            TRY(groupnorm(x, nullptr, w.ng, w.nb, 1e-6f, 0, a));
+            TRY(linear(a.p, C, nullptr, 0, 0, M, C, w.pin, C, w.pinb, nullptr, 0, 0, h.p, C, sv ? nullptr : &rs_h));
+            free(a);
+        }
         if (sv) sv->blocks.assign(w.blocks.size(), TBlockSave());
         for (size_t bi = 0; bi < w.blocks.size(); ++bi) {
             const TBlockW& bw = w.blocks[bi];
