@@ -916,7 +916,10 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
         }
         if (__any(bad) && lane == 0) s_redo = 1;
         __syncthreads();                            // also: every wave is done reading the ring before a second pass refills it
-        if (s_redo && ABL == 0) pass(T);            // workgroup-uniform: the ring and its barriers are shared by the four waves
+        if (s_redo && ABL == 0) {                   // workgroup-uniform: the ring and its barriers are shared by the four waves
+            if (p.redo_counter && tid == 0) atomicAdd(p.redo_counter, 1u);      // (tuning: how often does it happen?)
+            pass(T);
+        }
     }
 
 #pragma unroll
@@ -956,6 +959,20 @@ static const bf16_t* attn_zero_page() {
     return (const bf16_t*)p;
 }
 
+// tuning: device counter of workgroups that repeated their pass with the per-tile check (GYRE_ATTN_COUNT_REDO=1; one per process)
+static unsigned* attn_redo_counter(bool create) {
+    static unsigned* ctr = nullptr;
+    static const bool on = getenv("GYRE_ATTN_COUNT_REDO") != nullptr;
+    if (on && !ctr && create) { if (hipMalloc((void**)&ctr, 4) != hipSuccess) ctr = nullptr; else (void)hipMemset(ctr, 0, 4); }
+    return ctr;
+}
+extern "C" long gyre_debug_attn_redo_count() {
+    unsigned* c = attn_redo_counter(true);
+    if (!c) return -1;
+    unsigned v = 0;
+    if (hipMemcpy(&v, c, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)v;
+}
 static thread_local int g_attn_variant = 0;  // tests / tuning: 0 auto, 1 = v1, 2 = v2 plain, 3 = v2 folded, 4 = v2 QI=4 (D <= 32), 5 = v3,
                                              // 6 = auto without the several-query-blocks-per-workgroup form of short key sequences
 extern "C" int gyre_debug_force_attn_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
@@ -1015,6 +1032,7 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
                         2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk));
     AttnParams q = p;
     q.always_check = (g_attn_variant & 255) == 7 ? 1 : 0;        // tuning: the per-tile overflow check in every tile (as before round 4)
+    q.redo_counter = attn_redo_counter(false);
 #ifdef GYRE_ATTN_ABLATIONS
     if constexpr (D == 40) {
         const int abl = g_attn_variant >> 8;              // gyre_debug_force_attn_variant(abl << 8)

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void k_ar_pack(const bf16_t* W, int N, int K, 
 
 // ABL: timing ablations (results are garbage; builds with GYRE_AR_ABLATIONS only): 1 = no epilogue arithmetic, 2 = no MFMAs,
 // 4 = no output stores, 8 = no fragment reads (one stale fragment), 16 = no ring requests / waits
-template <int KT, int NB, bool LNF, bool GEGLU, bool RES, bool RS, int ABL = 0>
+// VT: the fused Q | K | V projection of a self-attention (GemmParams::vt_out): weight rows >= vt_col0 are the V projection, whose
+// 32 x 32 output blocks leave TRANSPOSED - V^T[b][channel][token], what the attention kernel streams - through a 2 KB
+// per-wave LDS patch (16 x ds_write_b16 per lane, read back as two 16-byte rows of 8 tokens)
+template <int KT, int NB, bool LNF, bool GEGLU, bool RES, bool RS, int ABL = 0, bool VT = false>
 __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wpk, int nt_total, int n_split) {
     constexpr int TB = NB * KT * 1024;          // bytes of one N tile = one ring stage
     constexpr int NS = 3;
@@ -86,6 +89,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
     float* cbias = (float*)(smem + NS * TB);    // [nt * TNW] bias of this workgroup's weight rows (zeros when absent)
     float* ccols = cbias + nt * TNW;            // [nt * TNW] LNF: column sums of the gamma-folded weights
+    // VT: this wave's transposition patch [32 channels][32 tokens] bf16, and the first V block of this workgroup's range
+    bf16_t* const vscr = (bf16_t*)(smem + NS * TB + (size_t)nt * TNW * 4 * (LNF ? 2 : 1)) + w * 1024;
+    const int vblk0 = VT ? p.vt_col0 / 32 - t0 * NB : (1 << 30);       // local block index >= vblk0: a V block
 
     // ---- ring: request tile tt (local index) into slot `slot`; past-the-end requests re-read tile 0 (never consumed) so that
     // the in-flight count stays uniform
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     float4 kb0, kb1, kc0, kc1;           // bias / folded-LayerNorm column sums of the two 4-channel runs being processed
     float eo[8];                         // GEGLU: the block's 8 outputs; else: the two runs on their way to one 16-byte store
     float ev = 0.f, eg = 0.f, ez = 0.f, ep = 0.f;
-    constexpr int NSTG = GEGLU ? 19 : 8;
+    constexpr int NSTG = GEGLU ? 19 : (VT ? 9 : 8);
     auto epi_stage = [&](auto s_c, int g, const f32x16_t& acc, u32x4_t (&hold)[SPB], u32x4_t (&rr)[SPB], auto drain_tag) {
         constexpr int S = decltype(s_c)::value;
         constexpr int WAITN = decltype(drain_tag)::value ? 0 : PPW;   // DRAIN: nothing younger than the residual request is in flight
@@ -268,13 +274,28 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
 #pragma unroll
                 for (int i = 0; i < 4; ++i) eo[4 + i] = aff(acc[8 * half + 4 + i], f4(kb0, i), f4(kc0, i));
                 if constexpr (half == 0) run_consts(2);
+            } else if constexpr (S == 8) {
+                // (VT only) V block: every value of the block sits in the patch; two 16-byte rows of 8 tokens per lane come back
+                if (g >= vblk0) {
+                    hold[0] = *(const u32x4_t*)(vscr + (lane >> 2) * 32 + (lane & 3) * 8);
+                    hold[1] = *(const u32x4_t*)(vscr + (16 + (lane >> 2)) * 32 + (lane & 3) * 8);
+                }
             } else if constexpr (q == 2) {
                 if constexpr (RES && half == 0) {
                     if constexpr (SPB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rr[0]), "+v"(rr[1]) : "n"(WAITN) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr[0]) : "n"(WAITN) : "memory");
                 }
-                swap_runs();
-            } else pack_to(half);
+                if (VT && g >= vblk0) {
+                    // channel n = 8 (2 half + r) + 4 hi + i of run r, token l31 (a wave's LDS operations complete in order)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vscr[(16 * half + 4 * hi + i) * 32 + l31] = f32_to_bf16(eo[i]);
+                        vscr[(16 * half + 8 + 4 * hi + i) * 32 + l31] = f32_to_bf16(eo[4 + i]);
+                    }
+                } else swap_runs();
+            } else {
+                if (!(VT && g >= vblk0)) pack_to(half);
+            }
         }
     };
     // the epilogue of block g alone (last block of a workgroup)
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
     // stage of the PREVIOUS tile's epilogue (block 0 behind MFMAs 0 .., block 1 behind MFMAs KT ..)
     // (tuning variants, valid results: ABL & 32 = fragment request pinned in FRONT of the stage's MFMA, & 64 = 10-deep prefetch,
     //  & 128 = the second wave of every SIMD at s_setprio 1, & 256 = the epilogue stage in front of the MFMA)
-    constexpr int PF2 = (ABL & 64) ? 10 : (RES && RS) ? 4 : 6, RING2 = (ABL & 64) ? 12 : 8;
+    constexpr int PF2 = (ABL & 64) ? 10 : ((RES && RS) || VT) ? 4 : 6, RING2 = (ABL & 64) ? 12 : VT ? 6 : 8;
     if constexpr (ABL & 128) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     auto fused_tile2 = [&](int slot, int gp, f32x16_t (&cur)[2], f32x16_t (&prev)[2], u32x4_t (&hp)[2][SPB], u32x4_t (&rp)[2][SPB],
                            auto has_prev_tag) {
@@ -371,6 +392,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
         });
     };
     auto store = [&](int g, const u32x4_t (&hold)[SPB]) {
+        if constexpr (VT) {
+            if (g >= vblk0) {       // V^T[(b * Cv + c) * ldt + token]: lane = (channel lane >> 2 (+16), tokens 8 (lane & 3) ..)
+                const int row0 = bm * 256 + w * 32;                     // first row (= b * tokens + token) of this wave's block
+                if (row0 >= p.M) return;                                // (M is a multiple of 32: tokens_per_batch % 32 == 0)
+                const int bb = row0 / p.tokens_per_batch, tok0 = row0 - bb * p.tokens_per_batch;
+                const int cv = (t0 * NB + g) * 32 - p.vt_col0, Cv = p.N - p.vt_col0;
+                bf16_t* o = p.vt_out + ((size_t)bb * Cv + cv + (lane >> 2)) * p.ldt + tok0 + (lane & 3) * 8;
+                *(u32x4_t*)o = hold[0];
+                *(u32x4_t*)(o + (size_t)16 * p.ldt) = hold[1];
+                return;
+            }
+        }
         if (!mok) return;
         if constexpr (ABL & 4) { if (hold[0][0] != 0x12345678u) return; }
         bf16_t* o = orow + g * OUTB;
@@ -489,7 +522,10 @@ bool gemm_ar_supports(const GemmParams& p) {
     // K = 640: the A slab takes 160 registers; only the GEGLU FF1 (the layer that gains most) has a form that fits without spills
     if (p.K != 320 && !(p.K == 640 && p.geglu)) return false;
     if (p.A2 && p.A2 != p.A) return false;
-    if (p.rowbias || p.vt_out || p.colstat_out) return false;
+    if (p.rowbias || p.colstat_out) return false;
+    if (p.vt_out && (p.K != 320 || p.geglu || p.residual || p.rowstat_out || p.vt_col0 % 64 || p.tokens_per_batch % 32 || p.ldt % 8 ||
+                     p.M % 32 || ((size_t)p.vt_out & 15)))
+        return false;
     const int tnw = p.K == 320 ? 64 : 32;
     if (p.N % tnw || p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8)) return false;
     if ((((size_t)p.A | (size_t)p.out | (size_t)p.residual) & 15) != 0) return false;
@@ -522,7 +558,7 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
     const int ns = gemm_ar_nsplit(p);
     const int grid = tiles_m * ns;
     const int nt_max = (nt + ns - 1) / ns;
-    const size_t lds = (size_t)3 * NB * KT * 1024 + (size_t)nt_max * 32 * NB * 4 * (p.ln_colsum ? 2 : 1);
+    const size_t lds = (size_t)3 * NB * KT * 1024 + (size_t)nt_max * 32 * NB * 4 * (p.ln_colsum ? 2 : 1) + (p.vt_out ? 8 * 2048 : 0);
     if (lds > 160 * 1024) GYRE_FAIL(-6, "gemm: the A-resident kernel's column constants exceed LDS for this N");
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     GyreProfScope prof_(KC_GEMM_AR, st, 2.0 * p.M * (double)p.N * p.K,
@@ -536,6 +572,20 @@ static int launch_ar_t(hipStream_t st, const GemmParams& p, const void* wpk) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns);                           \
     } while (0)
     const bool lnf = p.ln_colsum != nullptr, rs = p.rowstat_out != nullptr;
+    if (p.vt_out) {
+        if constexpr (KT == 20) {
+            if (lnf) { auto kern = k_gemm_ar<KT, NB, true, false, false, false, 0, true>;
+                       static std::atomic<unsigned long long> ad{0};
+                       if (gyre_lds_attr_needed(ad)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns); }
+            else { auto kern = k_gemm_ar<KT, NB, false, false, false, false, 0, true>;
+                   static std::atomic<unsigned long long> ad{0};
+                   if (gyre_lds_attr_needed(ad)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, (const char*)wpk, nt, ns); }
+            GYRE_LAUNCH_CHECK();
+            return 0;
+        } else GYRE_FAIL(-6, "gemm: the fused Q|K|V form of the A-resident kernel exists for K = 320 only");
+    }
 #ifdef GYRE_AR_ABLATIONS
     if (p.geglu && !lnf && KT == 20 && (p.debug >> 23) & 511) {
         const int abl = (p.debug >> 23) & 511;

@@ -367,16 +367,20 @@ struct Exec {
         return 0;
     }
     // runs one GEMM launch, giving it split-K slab space from the arena when the planner wants it
+    // A-resident kernel (tile config 30): the packed weight copy, made per handle on first use (and after any weight change)
+    int prep_ar(GemmParams& p) {
+        if (dry() || gemm_plan(p).cfg != 30) return 0;
+        bool fresh = false;
+        void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh) : nullptr;
+        if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A-resident GEMM");
+        if (!fresh) TRY(launch_ar_pack(st, p.W, p.N, p.K, pk));
+        p.w_packed = pk;
+        return 0;
+    }
     int run_gemm(GemmParams& p) {
         if (!p.samples) p.samples = batch;
         GemmPlan pl = gemm_plan(p);
-        if (pl.cfg == 30 && !dry()) {       // A-resident kernel: packed weights, made per handle on first use
-            bool fresh = false;
-            void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh) : nullptr;
-            if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A-resident GEMM");
-            if (!fresh) TRY(launch_ar_pack(st, p.W, p.N, p.K, pk));
-            p.w_packed = pk;
-        }
+        TRY(prep_ar(p));
         Tn ws;
         if (pl.ws_bytes) {
             TRY(alloc_raw(ws, pl.ws_bytes));
@@ -595,8 +599,11 @@ struct Exec {
                 p.A = xq.p; p.lda = C; p.mode = GEMM_LINEAR; p.W = w.wqk; p.K = C; p.N = 3 * C; p.M = B * Nq; p.samples = B;
                 p.out = q.p; p.ldc = 2 * C; p.out_mode = OUT_BF16;
                 p.vt_out = vt.p; p.vt_col0 = 2 * C; p.tokens_per_batch = Nq; p.ldt = ldvt;
+                p.ar_ok = store != nullptr;
+                if (dry()) { p.out = (void*)(uintptr_t)256; p.vt_out = (bf16_t*)(uintptr_t)256; p.A = (const bf16_t*)(uintptr_t)256; }  // (planning: aligned non-null)
                 GemmPlan pl = gemm_plan(p);
-                const int tn = pl.cfg == 4 ? 160 : (pl.cfg == 5 || pl.cfg == 8) ? 80 : pl.cfg == 6 ? 128 : pl.cfg == 7 ? 64 : 0;
+                // (config 30 = the A-resident kernel: its 64-row weight tiles line up with the V columns whenever 2 C % 64 == 0)
+                const int tn = pl.cfg == 4 ? 160 : (pl.cfg == 5 || pl.cfg == 8) ? 80 : pl.cfg == 6 ? 128 : (pl.cfg == 7 || pl.cfg == 30) ? 64 : 0;
                 if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
                     fused = true;
                     Tn stats;
@@ -607,7 +614,10 @@ struct Exec {
                         TRY(normalise());
                         p.A = xq.p;
                     }
-                    if (!dry()) TRY(launch_gemm(st, p));
+                    if (!dry()) {
+                        TRY(prep_ar(p));
+                        TRY(launch_gemm(st, p));
+                    }
                     free(stats);
                 }
             }

@@ -265,6 +265,9 @@ int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
  * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic with the
  * per-tile overflow check of the pipelined kernel in every tile (no optimistic first pass).  Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
+/* Tuning only: with GYRE_ATTN_COUNT_REDO=1 in the environment, the number of attention workgroups that have repeated their pass with
+ * the per-tile overflow check so far in this process (the first call creates the counter; -1: counting is off). */
+long gyre_debug_attn_redo_count(void);
 /* Tuning only.  Ablations (results are garbage): bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs,
  * bit2 = no epilogue.  Planner switches for same-box A/B runs (results stay valid): bit8 = default tile order, bit9 = conv
  * zero padding from a zero page in the pipelined kernel, bit10 = no pipelined (32x32x16) tile configs, bit11 = LayerNorm as a
