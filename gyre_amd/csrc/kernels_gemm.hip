@@ -1267,7 +1267,7 @@ static bool gemm_staged_epilogue_ok(const GemmParams& p) {
 bool gemm_per_sample_w_ok(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;
-    if (g_force_cfg || p.force_cfg || (p.debug & 0x40000000) || g_invariant_batch > 0) return false;   // bit 30: GroupNorm keeps its apply pass
+    if (g_force_cfg || p.force_cfg || (p.debug & 0x1000) || g_invariant_batch > 0) return false;   // bit 12: GroupNorm keeps its apply pass
     if (p.mode != GEMM_LINEAR || p.A2 || p.batch > 1 || p.geglu || p.vt_out || p.ln_colsum || p.rows_per_sample <= 0 ||
         p.M % p.rows_per_sample || p.K % 8 || p.N % 8)
         return false;

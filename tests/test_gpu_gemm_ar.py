@@ -181,3 +181,37 @@ def test_rows_are_independent_and_repeatable(ar):
         ys.append(y)
     assert torch.equal(ys[0], ys[1])
     assert torch.equal(ys[0][:8192], ys[2]) and torch.equal(ys[0][:4096 + 64], ys[3])
+
+
+@pytest.mark.parametrize("B,tokens,ln", [(16, 4096, True), (2, 4096, True), (4, 4096, False), (3, 1056, True), (9, 1024, False)])
+def test_fused_qkv_with_transposed_v(ar, B, tokens, ln):
+    """Q | K | V of a self-attention as one launch of the A-resident kernel: Q | K row-major, the V blocks transposed through
+    the per-wave LDS patch into V^T[b][c][token]; with and without the folded LayerNorm, one and several N-range splits."""
+    L = _lib.lib()
+    C, M = 320, B * tokens
+    x, g, b = _ln_inputs(M, C, 100)
+    w = bf16_round(randn(3 * C, C, seed=103) / math.sqrt(C))
+    ref = F.linear(F.layer_norm(x, (C,), g, b, 1e-5) if ln else x, w)
+    xd, wd = to_dev_bf16(x), repack_linear(w)
+    outs = []
+    for on in (True, False):
+        ar(on)
+        qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+        rcs = []
+        if ln:
+            ws = torch.empty(L.gyre_op_ln_linear_workspace(3 * C, C, M), dtype=torch.uint8, device=DEV)
+            call = lambda: rcs.append(L.gyre_op_ln_linear(st(), vp(xd), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(wd), 3 * C, None, 0,
+                                                          tokens, vp(vt), tokens, None, 0, vp(ws), ws.numel(), vp(qk)))
+        else:
+            call = lambda: rcs.append(L.gyre_op_qkv(st(), vp(xd), M, C, vp(wd), tokens, vp(qk), vp(vt), tokens))
+        names = _classes(call)
+        if not on and rcs[0] == -6:
+            continue
+        _lib.check(rcs[0])
+        assert ("k_gemm_ar" in names) == on, names
+        report(f"ar qkv QK part B{B} T{tokens} ln={ln} ar={on}", qk.float().cpu(), ref[:, :2 * C], TOL)
+        report(f"ar qkv V^T part B{B} T{tokens} ln={ln} ar={on}", vt.float().cpu(), ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1), TOL)
+        outs.append((qk, vt))
+    if len(outs) == 2:
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

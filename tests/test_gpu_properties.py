@@ -243,7 +243,7 @@ def test_hint_verifier():
 def test_groupnorm_folded_into_proj_in_matches_the_apply_pass():
     """The affine-only GroupNorm in front of every Transformer2D's proj_in rides inside that GEMM at the 64x64 / 32x32 levels
     (per-sample scaled weights, launch_gn_fold): the same function as normalise-then-project up to one bf16 rounding placed
-    elsewhere.  Full SD1.5 UNet call with and without the fold (tuning bit 30), and against each other per sample position."""
+    elsewhere.  Full SD1.5 UNet call with and without the fold (tuning bit 12), and against each other per sample position."""
     cfg = gcfg.sd15_unet()
     net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -263,16 +263,16 @@ def test_groupnorm_folded_into_proj_in_matches_the_apply_pass():
     L = _lib.lib()
     launches = {}
     outs = {}
-    for bits in (0, 0x40000000):
+    for bits in (0, 0x1000):
         L.gyre_debug_gemm_ablation(bits)
         try:
             outs[bits] = net(x, t, encoder_hidden_states=ctx).sample.float().cpu()
             launches[bits] = L.gyre_last_launch_count()
         finally:
             L.gyre_debug_gemm_ablation(0)
-    d = float((outs[0] - outs[0x40000000]).norm() / outs[0x40000000].norm())
-    print(f"[property] GroupNorm folded into proj_in vs apply pass: rel-L2 {d:.2e}; launches {launches[0]} vs {launches[0x40000000]}")
-    assert d < 1.5e-2 and launches[0] < launches[0x40000000]
+    d = float((outs[0] - outs[0x1000]).norm() / outs[0x1000].norm())
+    print(f"[property] GroupNorm folded into proj_in vs apply pass: rel-L2 {d:.2e}; launches {launches[0]} vs {launches[0x1000]}")
+    assert d < 1.5e-2 and launches[0] < launches[0x1000]
     # batch equivariance survives (per-sample weights follow their sample)
     perm = torch.tensor([2, 0, 3, 1], device=DEV)
     again = net(x[perm], t, encoder_hidden_states=ctx[perm]).sample.float().cpu()
