@@ -265,7 +265,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
                 kb0 = *(const float4*)(cbias + g * 32 + 4 * hi + 8 * j);
                 if constexpr (LNF) kc0 = *(const float4*)(ccols + g * 32 + 4 * hi + 8 * j);
             };
-            if constexpr (q == 0) {
+            if constexpr (S == 8) {
+                // (VT only) V block: every value of the block sits in the patch; two 16-byte rows of 8 tokens per lane come back
+                if (g >= vblk0) {
+                    hold[0] = *(const u32x4_t*)(vscr + (lane >> 2) * 32 + (lane & 3) * 8);
+                    hold[1] = *(const u32x4_t*)(vscr + (16 + (lane >> 2)) * 32 + (lane & 3) * 8);
+                }
+            } else if constexpr (q == 0) {
                 if constexpr (S == 0) run_consts(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) eo[i] = aff(acc[8 * half + i], f4(kb0, i), f4(kc0, i));
@@ -274,12 +280,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
 #pragma unroll
                 for (int i = 0; i < 4; ++i) eo[4 + i] = aff(acc[8 * half + 4 + i], f4(kb0, i), f4(kc0, i));
                 if constexpr (half == 0) run_consts(2);
-            } else if constexpr (S == 8) {
-                // (VT only) V block: every value of the block sits in the patch; two 16-byte rows of 8 tokens per lane come back
-                if (g >= vblk0) {
-                    hold[0] = *(const u32x4_t*)(vscr + (lane >> 2) * 32 + (lane & 3) * 8);
-                    hold[1] = *(const u32x4_t*)(vscr + (16 + (lane >> 2)) * 32 + (lane & 3) * 8);
-                }
             } else if constexpr (q == 2) {
                 if constexpr (RES && half == 0) {
                     if constexpr (SPB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rr[0]), "+v"(rr[1]) : "n"(WAITN) : "memory");
