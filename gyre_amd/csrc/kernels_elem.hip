@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256) void k_gn_fold(GnParams p, const bf16_t* __res
 int launch_gn_fold(hipStream_t st, const GnParams& p, const bf16_t* W, const float* bias, int N, bf16_t* Wf, float* bf) {
     if (p.C % 8 || p.C % p.G || p.G > 256 || p.C1 != p.C) GYRE_FAIL(-1, "gn_fold: one source, C a multiple of 8 and of the groups");
     if (p.cs_x && (p.cs_unit <= 0 || (p.C / p.G) % p.cs_unit || p.cs_x_chunks <= 0)) GYRE_FAIL(-1, "gn_fold: bad producer statistics");
-    const int rows_per_block = 32;
+    // one row per wave: the row loop is a chain of dependent global round trips (32 rows per workgroup took 13 us for 3.4 MB);
+    // the statistics prologue is cheap enough to repeat in every workgroup
+    const int rows_per_block = 4;
     const size_t lds = ((size_t)2 * p.C + 4 * 256) * sizeof(float);
     GyreProfScope prof_(KC_GN_APPLY, st, 0.0, (double)p.B * N * p.C * 2.0 + (double)N * p.C * 2.0);
     hipLaunchKernelGGL(k_gn_fold, dim3((N + rows_per_block - 1) / rows_per_block, p.B), dim3(256), lds, st, p, W, bias, N, Wf, bf, rows_per_block);

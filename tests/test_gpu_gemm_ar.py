@@ -183,7 +183,7 @@ def test_rows_are_independent_and_repeatable(ar):
     assert torch.equal(ys[0][:8192], ys[2]) and torch.equal(ys[0][:4096 + 64], ys[3])
 
 
-@pytest.mark.parametrize("B,tokens,ln", [(16, 4096, True), (2, 4096, True), (4, 4096, False), (3, 1056, True), (9, 1024, False)])
+@pytest.mark.parametrize("B,tokens,ln", [(16, 4096, True), (2, 4096, True), (4, 4096, False), (5, 1056, True), (9, 1024, False)])
 def test_fused_qkv_with_transposed_v(ar, B, tokens, ln):
     """Q | K | V of a self-attention as one launch of the A-resident kernel: Q | K row-major, the V blocks transposed through
     the per-wave LDS patch into V^T[b][c][token]; with and without the folded LayerNorm, one and several N-range splits."""
