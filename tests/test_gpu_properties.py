@@ -241,7 +241,7 @@ def test_hint_verifier():
 
 
 def test_groupnorm_folded_into_proj_in_matches_the_apply_pass():
-    """The affine-only GroupNorm in front of every Transformer2D's proj_in rides inside that GEMM at the 64x64 / 32x32 levels
+    """The affine-only GroupNorm in front of every Transformer2D's proj_in rides inside that GEMM at the 64x64 level
     (per-sample scaled weights, launch_gn_fold): the same function as normalise-then-project up to one bf16 rounding placed
     elsewhere.  Full SD1.5 UNet call with and without the fold (tuning bit 12), and against each other per sample position."""
     cfg = gcfg.sd15_unet()

@@ -27,6 +27,7 @@ with torch.no_grad():
         elif k.endswith("weight"): p.fill_(1.0)
         else: p.zero_()
 net._invalidate()
+L.gyre_debug_gemm_ablation(int(os.environ.get("FLAGS", "0"), 0))          # planner debug bits (include/gyre_hip.h)
 x = torch.randn(B, 4, H, H, device=dev); t = 500; ctx = torch.randn(B, 77, 768, device=dev)
 PAIRS = os.environ.get("PAIRS") == "1"               # CFG-parallel batch: halves share their prefix (modules.cfg_pairs)
 if PAIRS:
