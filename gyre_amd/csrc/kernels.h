@@ -150,6 +150,8 @@ int launch_ln_fold(hipStream_t st, const bf16_t* W, int N, int K, const float* g
 // A-resident kernel (tile config 30): bytes of / conversion into the fragment-ordered weight copy it reads (GemmParams::w_packed)
 size_t gemm_ar_packed_bytes(int N, int K);
 int launch_ar_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
+size_t gemm_wr_packed_bytes(int N, int K);          // the W-resident kernel's fragment order (tile config 31)
+int launch_wr_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
 struct GemmPlan { int cfg; int splits; size_t ws_bytes; };

@@ -114,14 +114,16 @@ struct Store {
     // fragment-ordered copies of the weights the A-resident GEMM kernel reads (GemmParams::w_packed), keyed by the row-major
     // matrix they were made from (a plain weight or its LayerNorm-folded copy); same lifetime rules
     std::unordered_map<const void*, WtEntry> ar_cache;
-    void* ar_lookup(const void* w, size_t bytes, bool* fresh) {
+    std::unordered_map<const void*, int> ar_kind;      // which kernel's order the copy is in (tile config 30 / 31)
+    void* ar_lookup(const void* w, size_t bytes, bool* fresh, int kind = 30) {
         WtEntry& en = ar_cache[w];
         if (!en.p || en.bytes < bytes) {
             en.p = (bf16_t*)dmalloc(bytes, false);
             en.bytes = bytes; en.version = 0;
         }
-        *fresh = en.p && en.version == weights_version;
-        if (en.p) en.version = weights_version;
+        int& k = ar_kind[w];
+        *fresh = en.p && en.version == weights_version && k == kind;
+        if (en.p) { en.version = weights_version; k = kind; }
         return en.p;
     }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
@@ -369,11 +371,13 @@ struct Exec {
     // runs one GEMM launch, giving it split-K slab space from the arena when the planner wants it
     // A-resident kernel (tile config 30): the packed weight copy, made per handle on first use (and after any weight change)
     int prep_ar(GemmParams& p) {
-        if (dry() || gemm_plan(p).cfg != 30) return 0;
+        if (dry()) return 0;
+        const int cfg = gemm_plan(p).cfg;
+        if (cfg != 30 && cfg != 31) return 0;
         bool fresh = false;
-        void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh) : nullptr;
-        if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A-resident GEMM");
-        if (!fresh) TRY(launch_ar_pack(st, p.W, p.N, p.K, pk));
+        void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh, cfg) : nullptr;
+        if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A- / W-resident GEMM");
+        if (!fresh) TRY(cfg == 30 ? launch_ar_pack(st, p.W, p.N, p.K, pk) : launch_wr_pack(st, p.W, p.N, p.K, pk));
         p.w_packed = pk;
         return 0;
     }
