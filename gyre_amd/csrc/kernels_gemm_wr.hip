@@ -1,4 +1,4 @@
-// "W-resident" bf16 MFMA GEMM for the square projections of the Transformer2D blocks (K = 320 / 640, N a multiple of 320:
+// "W-resident" bf16 MFMA GEMM for the square projections of the Transformer2D blocks (K = 320, N a multiple of 320:
 // to_out, to_q of the cross-attention, proj_in / proj_out at the 64x64 and 32x32 UNet levels):
 //
 //   C[M][N] = epilogue( A[M][K] * W[N][K]^T )          same contract as k_gemm8 (linear mode, bf16 row-major out)
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_wr(GemmParams p, const uint4* w
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 bool gemm_wr_supports(const GemmParams& p) {
     if (p.mode != GEMM_LINEAR || p.out_mode != OUT_BF16 || p.batch > 1 || p.geglu || p.vt_out) return false;
-    if (p.K != 320 && !(p.K == 640 && (p.debug & 0x4000000))) return false;     // (K = 640: 400 weight registers, two forms still spill - tuning bit 26)
+    if (p.K != 320) return false;          // (K = 640: 400 weight registers per wave - three of the five forms spill; not instantiated)
     if (p.A2 && p.A2 != p.A) return false;
     if (p.rowbias || p.colstat_out || p.w_sample_stride) return false;
     if (p.N % 320 || p.M % 16 || p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8)) return false;
@@ -383,6 +383,5 @@ static int launch_wr_t(hipStream_t st, const GemmParams& p, const void* wpk) {
 int launch_gemm_wr(hipStream_t st, const GemmParams& p, const void* wpk) {
     if (!gemm_wr_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the W-resident kernel's domain");
     if (!wpk) GYRE_FAIL(-6, "gemm: the W-resident kernel needs the packed weight copy");
-    if (p.K == 320) return launch_wr_t<320>(st, p, wpk);
-    return launch_wr_t<640>(st, p, wpk);
+    return launch_wr_t<320>(st, p, wpk);
 }

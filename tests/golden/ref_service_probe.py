@@ -135,9 +135,12 @@ def main():
     plain, _ = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, **kw)
     guided, _ = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, clip_guidance_scale=0.3, **kw)
     out["l1_clip_guidance"] = [list(guided.shape), float((guided - plain).abs().max()) > 1e-3, bool(torch.isfinite(guided).all())]
-    # unsupported feature -> NotImplementedError (mapped to gRPC UNIMPLEMENTED by the reference)
+    # tiling (circular convolution padding, unified_pipeline.py:1671-1712) is served; together with CLIP guidance it is not:
+    # unsupported combination -> NotImplementedError (mapped to gRPC UNIMPLEMENTED by the reference)
+    tiled, _ = wrapper(sampler=generation_pb2.SAMPLER_K_EULER, tiling=True, **kw)
+    out["l1_tiling"] = [list(tiled.shape), bool(torch.isfinite(tiled).all())]     # (its effect on the images: tests/test_gpu_engine.py)
     try:
-        wrapper(sampler=generation_pb2.SAMPLER_K_EULER, tiling=True, **kw)
+        wrapper(sampler=generation_pb2.SAMPLER_K_EULER, tiling=True, clip_guidance_scale=0.3, **kw)
         out["l1_unsupported"] = "no error"
     except NotImplementedError:
         out["l1_unsupported"] = "NotImplementedError"

@@ -39,6 +39,7 @@ def test_reference_wrapper_and_grpc_servicer_run_over_the_native_engine_class():
     assert out["l1_equals_direct"]                                       # same tensors as calling the host pipeline directly
     assert out["l1_ddim_img2img"] == [[2, 3, 128, 128], "ddim"]
     assert out["l1_cancelled"] and out["l1_unsupported"] == "NotImplementedError"
+    assert out["l1_tiling"] == [[2, 3, 128, 128], True]                      # tiling=True is served (the engine's own option check)
     assert out["l1_clip_guidance"] == [[2, 3, 128, 128], True, True]   # clip_guidance_scale reaches the native engine (a16)
     # level 2: the reference's gRPC servicer
     assert "l2_error" not in out, out.get("l2_trace")
