@@ -1177,8 +1177,16 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         // K = 1280 / N = 320 linear +13 % (not taken).  The 4-wave one-wave-per-SIMD forms (configs 20-23) win isolated
         // benchmarks (8192^3: 1325 vs 1048 TFLOP/s) but lose 4-15 % inside the UNet; they stay test / tuning configs.
         const int nk_ = (p.K + BK - 1) / BK;
-        if (!(p.debug & 0x400) && p.N % 320 == 0 && (p.mode == GEMM_CONV3 ? nk_ >= 20 : nk_ >= 32) && gemm4s_supports(p, 24))
+        if (!(p.debug & 0x400) && p.N % 320 == 0 && (p.mode == GEMM_CONV3 ? nk_ >= 20 : nk_ >= 32) && gemm4s_supports(p, 24)) {
             big(24, 1.00, 256, 320);
+            // 3x3 convs with K >= 2880 whose 256x320 tiling has 128 - 159 tiles (the 48x48 level of a 768 px request at batch 8:
+            // M = 18432, N = 640 -> 144 tiles; no split factor fits): the pipelined tile on 56 % of the CUs still beats the 128x160
+            // tile on all of them by 20 - 30 % (tools/gemm_sweep.py 8 96 sd15, round 4: K = 5760 218 -> 174 us, K = 11520 403 -> 302;
+            // UNet forward at 96x96 latents, batch 8: 26.96 -> 26.38 ms).  Lowering the 128x160 tile's constant for ALL long convs
+            // instead was measured too: no gain at 96x96 and an extra split-K launch at 64x64 - not adopted
+            // (tuning bit 23: rule off)
+            if (!(p.debug & 0x800000) && p.mode == GEMM_CONV3 && nk_ >= 45 && tiles(256, 320) >= 128 && tiles(256, 320) < 160) consider(24, 1.25, 256, 320, 1);
+        }
         // GEGLU FF1 (N = 8C, K = C): the 320-wide 8-wave tile of the 16x16x32 kernel has an odd fragment count per wave and
         // cannot pair value / gate columns, the pipelined kernel's 32-wide fragments can.  Taken only where the WEIGHTS are
         // the big operand (N > M: the 16x16 level, 26 MB of weights against 10 MB of activations; 140 -> 109 us cold, UNet
