@@ -497,7 +497,7 @@ def main():
             out["step_mfma_frac_note"] = ("EXECUTED FLOPs / time / 2.5 PFLOP/s: algorithmic 0.803 TFLOP per UNet sample-forward x all "
                                           "evaluations, minus what the two halves of every CFG-parallel call share (everything in front "
                                           "of the first cross-attention is evaluated once per (uncond, cond) pair: 2.55 % of a call; "
-                                          "bit-level equivalent, GYRE_CFG_SHARED_PREFIX=0 turns it off; "
+                                          "identical between the two halves, equal to the unshared call up to bf16 summation order (bit for bit under batch-invariant planning), GYRE_CFG_SHARED_PREFIX=0 turns it off; "
                                           "step_mfma_frac_reference_formulation counts those FLOPs as if executed twice); the "
                                           "cross-attention K/V projections of the text context run once per request (context cache: "
                                           "<0.5 % of the counted FLOPs are not executed on 50 of the 51 evaluations)")

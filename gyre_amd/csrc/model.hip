@@ -457,6 +457,8 @@ int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, con
 // GYRE_ERR_UNSUPPORTED when that kernel cannot).  ws: split-K slab space (gyre_op_gemm_splitk_bytes; may be null when 0).
 static int op_colstats_go(hipStream_t st, GemmParams& p, int unit, int rps, float* stats_out, size_t stats_bytes, void* ws,
                           size_t ws_bytes, int* rows_out) {
+    if (unit <= 0 || rps <= 0 || p.M <= 0 || p.N <= 0 || p.M % rps || p.N % unit)
+        GYRE_FAIL(GYRE_ERR_INVALID, "colstats: unit and rows per sample must be positive and divide N and M");
     p.colstat_unit = unit; p.rows_per_sample = rps;
     const int rows = gemm_colstat_rows(p);
     if (rows_out) *rows_out = rows;
@@ -471,6 +473,7 @@ static int op_colstats_go(hipStream_t st, GemmParams& p, int unit, int rps, floa
     return launch_gemm(st, p);
 }
 size_t gyre_op_gemm_splitk_bytes(int conv, int M, int N, int K, int B) {
+    if (M <= 0 || N <= 0 || K <= 0 || (conv && K % 9)) return 0;
     GemmParams p;
     p.mode = conv ? GEMM_CONV3 : GEMM_LINEAR; p.M = M; p.N = N; p.K = K; p.Cin = conv ? K / 9 : 0; p.lda = conv ? K / 9 : K;
     p.ldc = N; p.ldr = N; p.samples = B; p.out_mode = OUT_BF16;
@@ -481,6 +484,8 @@ int gyre_op_conv3x3_colstats(void* st, const void* x, int B, int Hi, int Wi, int
                              const void* residual, int stride, int ups, int unit, void* y, float* stats_out, size_t stats_bytes,
                              void* ws, size_t ws_bytes, int* rows_out) {
     if (!x || !w || !y || !stats_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2) || unit <= 0)
+        GYRE_FAIL(GYRE_ERR_INVALID, "conv3x3_colstats: sizes and unit must be positive, stride 1 or 2");
     const int Hin = ups ? 2 * Hi : Hi, Win = ups ? 2 * Wi : Wi;
     const int Ho = (Hin + 2 - 3) / stride + 1, Wo = (Win + 2 - 3) / stride + 1;
     GemmParams p;
@@ -494,6 +499,8 @@ int gyre_op_linear_colstats(void* st, const void* x, int M, int K, const void* w
                             int rows_per_sample, int unit, void* y, float* stats_out, size_t stats_bytes, void* ws, size_t ws_bytes,
                             int* rows_out) {
     if (!x || !w || !y || !stats_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (M <= 0 || K <= 0 || N <= 0 || rows_per_sample <= 0 || unit <= 0 || M % rows_per_sample || N % unit)
+        GYRE_FAIL(GYRE_ERR_INVALID, "linear_colstats: M, K, N, rows_per_sample and unit must be positive, rows_per_sample must divide M and unit N");
     GemmParams p;
     p.A = (const bf16_t*)x; p.lda = K; p.mode = GEMM_LINEAR; p.W = (const bf16_t*)w; p.K = K;
     p.N = N; p.M = M; p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = N; p.samples = M / rows_per_sample;

@@ -308,7 +308,9 @@ size_t gyre_op_groupnorm_workspace(int B, int HW, int C, int groups);
  * planner picks (returned through rows_out; GYRE_ERR_UNSUPPORTED when that kernel cannot: then the consumer runs its own
  * statistics pass); unit divides every GroupNorm group that will read the tensor - alone or as part of a skip concat.
  * gyre_op_groupnorm_colstats is the consumer: no statistics pass, mean / rstd are finished from the partials of x (and x2) in
- * the prologue of the one launch that normalises.  workspace of the producers: gyre_op_gemm_splitk_bytes (0 = none). */
+ * the prologue of the one launch that normalises.  workspace of the producers: gyre_op_gemm_splitk_bytes (0 = none; for a conv
+ * it assumes the square stride-1 geometry sqrt(M / B) x sqrt(M / B) - any other conv: pass at least 4 * 16 * M * N bytes, the largest
+ * split factor's slabs).  Non-positive sizes, a unit / rows_per_sample of 0 or one that does not divide N / M: GYRE_ERR_INVALID. */
 size_t gyre_op_gemm_splitk_bytes(int conv, int M, int N, int K, int B);
 int gyre_op_conv3x3_colstats(void* stream, const void* x, int B, int Hi, int Wi, int Cin, const void* w_repacked, int Cout,
                              const float* bias, const void* residual, int stride, int ups, int unit, void* y, float* stats_out,

@@ -1085,3 +1085,19 @@ def test_unet_with_and_without_producer_statistics_full_size():
     # batch equivariance survives: permuting the samples permutes the result bit-exactly
     p = net(x.flip(0).contiguous(), t.flip(0).contiguous(), encoder_hidden_states=ctx.flip(0).contiguous()).sample
     assert torch.equal(p.flip(0), a)
+
+
+def test_colstats_entry_points_reject_bad_integers():
+    """rows_per_sample = 0 used to reach an integer division (SIGFPE); now every size is checked up front."""
+    import ctypes as C
+    L = _lib.lib()
+    x = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(320, 320, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros(4096, dtype=torch.float32, device=DEV)
+    rows = C.c_int(0)
+    for rps, unit in ((0, 10), (256, 0), (100, 10), (256, 7)):
+        rc = L.gyre_op_linear_colstats(st(), vp(x), 256, 320, vp(w), 320, None, None, rps, unit, vp(y), vp(stats), stats.numel() * 4,
+                                       None, 0, C.byref(rows))
+        assert rc == -1, (rps, unit, rc)
+    assert L.gyre_op_gemm_splitk_bytes(1, 0, 320, 2880, 1) == 0 and L.gyre_op_gemm_splitk_bytes(1, 4096, 320, 2881, 1) == 0
