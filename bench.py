@@ -314,7 +314,12 @@ def main():
                           uncond_added_cond={"text_embeds": upooled_, "time_ids": tids})
             else:
                 kw = dict(input_ids=ids[lo:hi], negative_ids=neg[lo:hi])
-            latents = pipe(seeds=seeds, height=size, width=size, num_inference_steps=n_steps,
+            # per-image generators: on the execution device like the reference's wrapper (pipeline_wrapper.py:246) where the per-step
+            # draws are TENSORS (the graft's blend maps of config 3: a CPU generator costs a synchronous host-to-device copy per draw);
+            # on the host where the draws are SCALARS the host needs at once (the cut-out sizes of config 5: a device generator costs
+            # a device-to-host read-back per cut-out).  DPM++2M itself draws nothing per step.
+            gen_dev = str(dev) if args.config == "inpaint768" else "cpu"
+            latents = pipe(seeds=seeds, height=size, width=size, num_inference_steps=n_steps, generator_device=gen_dev,
                            **{"guidance_scale": 7.5, "sampler": "dpmpp_2m", "output_type": "latent", **extra, **kw})
             images = pipe.vae_decode(latents)
         if world > 1:

@@ -1473,6 +1473,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         case 8: return launch_cfg8<128, 160, 4, 2>(st, p, KC_G8_CONV_128x160, splits);
+        case 11: return launch_cfg8<256, 160, 4, 2>(st, p, KC_G8_X1, splits);        // tuning only (tools/cfg_compare.py): not in the planner
         case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }

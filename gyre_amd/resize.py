@@ -51,6 +51,23 @@ def _weight_matrix(in_size: int, scale: float) -> torch.Tensor:
     return m
 
 
+_DEVICE_CACHE: dict = {}
+
+
+def _device_matrices(in_size: int, scale: float, device):
+    """(matrix, its transpose) as fp32 ON `device`, cached: the hires fix resamples the same two sizes on every step of a request, and
+    a host-built matrix costs a pageable host-to-device copy - a stream sync that drains the launch queue - per call (measured:
+    1.5 s of a 2.5 s inpaint-768 step were spent blocked in those copies)."""
+    key = (in_size, scale, str(device))
+    hit = _DEVICE_CACHE.get(key)
+    if hit is None:
+        if len(_DEVICE_CACHE) > 256:
+            _DEVICE_CACHE.clear()
+        m = _weight_matrix(in_size, scale).to(device, torch.float32)
+        hit = _DEVICE_CACHE[key] = (m, m.t().contiguous())
+    return hit
+
+
 def resize_lanczos2(x: torch.Tensor, scale: float) -> torch.Tensor:
     """Resize the last two dims of x by ``scale`` (same factor both ways), lanczos2, replicate pad, no antialias."""
     if scale <= 0:
@@ -58,9 +75,8 @@ def resize_lanczos2(x: torch.Tensor, scale: float) -> torch.Tensor:
     if scale == 1:
         return x.clone()
     h, w = x.shape[-2], x.shape[-1]
-    mh = _weight_matrix(h, float(scale)).to(x.device, torch.float32)
-    mw = _weight_matrix(w, float(scale)).to(x.device, torch.float32)
-    mwt = mw.t().contiguous()
+    mh, _ = _device_matrices(h, float(scale), x.device)
+    _, mwt = _device_matrices(w, float(scale), x.device)
     xf = x.to(torch.float32)
     if xf.ndim < 4:
         return torch.matmul(torch.matmul(mh, xf), mwt).to(x.dtype)

@@ -14,6 +14,9 @@ prof = cProfile.Profile()
 argv = [a for a in sys.argv[1:]]
 sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-class-table"] + argv
 import bench as _b    # noqa: E402  (imports only)
+if os.environ.get("BITS"):       # planner tuning bits (per thread; bench runs on this one)
+    from gyre_amd import _lib as _l
+    _l.lib().gyre_debug_gemm_ablation(int(os.environ["BITS"], 0))
 orig_perf = time.perf_counter
 src = open(_b.__file__).read()
 # run main() with the profiler wrapped around the timed loop: the warm-up ends with barrier(); enable there
