@@ -26,6 +26,7 @@ import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
+import math
 import torch
 from torch import nn
 
@@ -310,16 +311,27 @@ class GyreHipUNet(_NativeModule):
         if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
             raise ValueError("this UNet needs added_cond_kwargs={'text_embeds': [B,D], 'time_ids': [B,6]}")
         c = self.config
-        te, ids = added_cond_kwargs["text_embeds"].to(dev, torch.float32), added_cond_kwargs["time_ids"].to(dev)
+        te_in, ids_in = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+        # the conditioning of a request does not change between its steps: keep the last result (keyed by the very tensors and their
+        # in-place version counters), so the 31 evaluations of a request run the little MLP once
+        key = (te_in.data_ptr(), te_in._version, tuple(te_in.shape), ids_in.data_ptr(), ids_in._version, tuple(ids_in.shape), B, str(dev),
+               getattr(self, "_weights_version", 0))
+        memo = getattr(self, "_aug_memo", None)
+        if memo is not None and memo[0] == key:
+            return memo[1]
+        te, ids = te_in.to(dev, torch.float32), ids_in.to(dev)
         half = c.addition_time_embed_dim // 2
-        freq = torch.exp(-torch.log(torch.tensor(10000.0, device=dev)) * torch.arange(half, device=dev) / (half - c.freq_shift))
+        # (math.log on the host: torch.tensor(10000.0, device=dev) is a pageable host-to-device copy - a stream sync per UNet call)
+        freq = torch.exp(torch.arange(half, device=dev, dtype=torch.float32) * (-math.log(10000.0) / (half - c.freq_shift)))
         ang = ids.flatten()[:, None].float() * freq[None]
         emb = torch.cat([torch.cos(ang), torch.sin(ang)] if c.flip_sin_to_cos else [torch.sin(ang), torch.cos(ang)], dim=-1)
         a = torch.cat([te, emb.reshape(B, -1)], dim=-1)
         ae = self.add_embedding
         a = torch.nn.functional.linear(a, ae.linear_1.weight.float(), ae.linear_1.bias.float())
         a = torch.nn.functional.linear(torch.nn.functional.silu(a), ae.linear_2.weight.float(), ae.linear_2.bias.float())
-        return a.contiguous()
+        a = a.contiguous()
+        self._aug_memo = (key, a, te_in, ids_in)          # (the inputs are kept alive so that their addresses cannot be reused)
+        return a
 
     def _prepare(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals,
                  mid_block_additional_residual, adapter_states):
