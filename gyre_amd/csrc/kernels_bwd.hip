@@ -22,10 +22,25 @@
 // Stage 1 sums g and g*xh per (sample, pixel chunk, group); stage 2 reduces the chunks in a fixed order; stage 3 applies.
 // ------------------------------------------------------------------------------
 #define GNB_MAXV 4
+// d silu / du = s (1 + u (1 - s)), s = sigmoid(u): hardware reciprocal and exp2 (the IEEE division of 1 / (1 + e^-u) was a
+// ten-instruction sequence per value, as in the forward kernels' silu_f)
 __device__ __forceinline__ float silu_grad_f(float u) {
-    const float s = 1.0f / (1.0f + __expf(-u));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
     return s * fmaf(u, 1.0f - s, 1.0f);
 }
+// group of channel c + j for the 8 consecutive channels of one vector (cpg channels per group): one division per vector when a
+// group is at least as wide as the vector (every UNet / VAE GroupNorm: cpg >= 4 ... 40), else per channel
+__device__ __forceinline__ void gn_groups8(int c, int cpg, int (&grp)[8]) {
+    const int g0 = c / cpg, r0 = c - g0 * cpg;
+    if (cpg >= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) grp[j] = g0 + (r0 + j >= cpg ? 1 : 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) grp[j] = (c + j) / cpg;
+    }
+}
+template <int NV>      // channel vectors per thread: 1 for C <= 2048
 __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, int PY, int pix_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [PY][C][2]
@@ -33,16 +48,33 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, i
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int CV = p.C / 8, C2 = p.C - p.C1, cpg = p.C / p.G;
     const int p0 = chunk * pix_per_chunk, p1 = min(p.HW, p0 + pix_per_chunk);
-    float s[GNB_MAXV][8], ss[GNB_MAXV][8];
+    float s[NV][8], ss[NV][8];
 #pragma unroll
-    for (int v = 0; v < GNB_MAXV; ++v)
+    for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[v][j] = 0.f; ss[v][j] = 0.f; }
     if (ty < PY) {
+        // per-channel constants of this thread's vectors, read once (they were re-read - and the group index re-divided - per pixel)
+        float ka[NV][8], kb[NV][8], kg[NV][8], km[NV][8], kr[NV][8];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int cv = tx + v * TX;
+            if (cv < CV) {
+                const int c = cv * 8;
+                const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
+                int grp[8];
+                gn_groups8(c, cpg, grp);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* mr = p.mean_rstd + ((size_t)n * p.G + grp[j]) * 2;
+                    ka[v][j] = sc[j]; kb[v][j] = sc[p.C + j]; kg[v][j] = p.gamma[c + j]; km[v][j] = mr[0]; kr[v][j] = mr[1];
+                }
+            }
+        }
         for (int pix = p0 + ty; pix < p1; pix += PY) {
             const size_t gp = (size_t)n * p.HW + pix;
 #pragma unroll
-            for (int v = 0; v < GNB_MAXV; ++v) {
+            for (int v = 0; v < NV; ++v) {
                 const int cv = tx + v * TX;
                 if (cv < CV) {
                     const int c = cv * 8;
@@ -50,20 +82,18 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, i
                     float f[8], d[8];
                     unpack8(*(const uint4*)src, f);
                     unpack8(*(const uint4*)(p.dy + gp * p.C + c), d);
-                    const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float* mr = p.mean_rstd + ((size_t)n * p.G + (c + j) / cpg) * 2;
-                        const float u = fmaf(sc[j], f[j], sc[p.C + j]);
-                        const float g = d[j] * (p.silu ? silu_grad_f(u) : 1.0f) * p.gamma[c + j];
+                        const float u = fmaf(ka[v][j], f[j], kb[v][j]);
+                        const float g = d[j] * (p.silu ? silu_grad_f(u) : 1.0f) * kg[v][j];
                         s[v][j] += g;
-                        ss[v][j] = fmaf(g, (f[j] - mr[0]) * mr[1], ss[v][j]);
+                        ss[v][j] = fmaf(g, (f[j] - km[v][j]) * kr[v][j], ss[v][j]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int v = 0; v < GNB_MAXV; ++v) {
+        for (int v = 0; v < NV; ++v) {
             const int cv = tx + v * TX;
             if (cv < CV) {
 #pragma unroll
@@ -114,9 +144,11 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdParams p, size_t tota
     const bool has_add = first && p.addend;
     if (has_add) unpack8(*(const uint4*)(p.addend + gp * p.C1 + c), ad);
     const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
+    int grp8[8];
+    gn_groups8(c, cpg, grp8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int grp = (c + j) / cpg;
+        const int grp = grp8[j];
         const float* mr = p.mean_rstd + ((size_t)n * p.G + grp) * 2;
         const float* cf = p.coef + ((size_t)n * p.G + grp) * 2;
         const float u = fmaf(sc[j], f[j], sc[p.C + j]);
@@ -159,7 +191,10 @@ int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
     const int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
     const size_t lds = (size_t)PY * p.C * 2 * sizeof(float);
     if (lds > 160 * 1024) GYRE_FAIL(-6, "groupnorm_bwd: LDS budget exceeded");
-    hipLaunchKernelGGL(k_gn_bwd_partial, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    const int nv = (CV + TX - 1) / TX;
+    if (nv == 1) hipLaunchKernelGGL(k_gn_bwd_partial<1>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    else if (nv == 2) hipLaunchKernelGGL(k_gn_bwd_partial<2>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    else hipLaunchKernelGGL(k_gn_bwd_partial<GNB_MAXV>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
     GYRE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(p.B), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
