@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
 }
 
 template <int NDB, int DS, int RT>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(AttnBwdParams p) {
+__device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
     constexpr int ROWS = 32 * RT, TS = ROWS + 4;
     constexpr int MAXIT = (ROWS * (DS * 2) + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -973,6 +973,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(AttnBwdParams p) {
         }
 }
 
+template <int NDB, int DS, int RT>
+__global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
+// D <= 48: the body fits 128 registers without spilling, so FOUR workgroups share a CU instead of three - the loop has no software
+// pipelining of its own (LDS fragment reads sit right in front of the MFMAs that use them), more resident waves are what hides them
+template <int NDB, int DS, int RT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attn_bwd_dq_lds_o4(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
+
 bool attn_bwd_needs_transposes(int D) { return D > 160; }
 size_t attn_bwd_stats_bytes(int B, int H, int Nq) {
     const size_t npad = (size_t)(Nq + 31) / 32 * 32;
@@ -1001,6 +1008,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     GYRE_LAUNCH_CHECK();
     if (lds_path) {
         const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : 3));
+        static const bool occ3 = getenv("GYRE_ABW_OCC3") != nullptr;        // tuning: the three-workgroups-per-CU build of the dQ kernel
         // 32-row LDS tiles: 64-row tiles (RT = 2) were measured slower (2.71 vs 2.14 ms at N = 4096, D = 40: fewer resident
         // workgroups outweigh the halved barrier count)
         const size_t lds = 2 * attn_bwd_stage_bytes(p.D, 1);
@@ -1015,7 +1023,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
             GYRE_LAUNCH_CHECK();                                                                                      \
         } while (0)
         switch (sel) {
-            case 0: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); break;
+            case 0: if (occ3) GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); else GYRE_ABW_GO((k_attn_bwd_dq_lds_o4<2, 3, 1>), gq); break;
             case 1: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 4, 1>), gq); break;
             case 2: GYRE_ABW_GO((k_attn_bwd_dq_lds<3, 6, 1>), gq); break;
             default: GYRE_ABW_GO((k_attn_bwd_dq_lds<5, 10, 1>), gq); break;
