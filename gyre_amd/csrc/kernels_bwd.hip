@@ -810,17 +810,28 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qs, rs, rt * 32 + col, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(DOs, rs, rt * 32 + col, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
             }
+            // (whole tiles - all but the last of a ragged problem - skip the per-element range tests: wave-uniform branch)
+            const bool whole = (qb * ROWS + rt * 32 + 32) <= p.Nq && (k0 + 32) <= p.Nk;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = rt * 32 + 8 * g + 4 * hi;
                 const float4 l4 = *(const float4*)(sts + ql), d4 = *(const float4*)(sts + ROWS + ql);
                 const float l[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+                if (whole) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (qb * ROWS + ql + r) < p.Nq && key < p.Nk;
-                    const float pr = ok ? __builtin_amdgcn_exp2f(s[4 * g + r] * p.alpha - l[r]) : 0.f;
-                    s[4 * g + r] = pr;
-                    dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + r], p.alpha, -l[r]));
+                        s[4 * g + r] = pr;
+                        dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (qb * ROWS + ql + r) < p.Nq && key < p.Nk;
+                        const float pr = ok ? __builtin_amdgcn_exp2f(fmaf(s[4 * g + r], p.alpha, -l[r])) : 0.f;
+                        s[4 * g + r] = pr;
+                        dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+                    }
                 }
             }
 #pragma unroll
@@ -942,11 +953,16 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vs, rs, rt * 32 + col, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
             }
+            if (kb * ROWS + rt * 32 + 32 <= p.Nk) {          // whole key tile: no per-element range test
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(s[r] * p.alpha - lse2) : 0.f;
-                s[r] = pr * (dp[r] - delta);
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.alpha, -lse2)) * (dp[r] - delta);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(fmaf(s[r], p.alpha, -lse2)) : 0.f;
+                    s[r] = pr * (dp[r] - delta);
+                }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
