@@ -1229,6 +1229,9 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
             }
         }
     }
+    // small problems (the planner's answer is one of the register-staged 4-wave tiles): the 4-stage LDS-DMA ring of
+    // kernels_gemm_sm.hip hides the per-K-step memory latency those kernels expose (tuning bit 5: off)
+    if (cfg <= 3 && *splits_out == 1 && !trans && !(p.debug & 0x20) && gemm_sm_supports(p)) cfg = 32;
     return cfg;
 }
 
@@ -1454,6 +1457,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         }
         return launch_gemm_wr(st, p, wpk);
     }
+    if (cfg == 32) {
+        if (splits > 1) GYRE_FAIL(-6, "gemm: the small-problem kernel has no split-K form");
+        return launch_gemm_sm(st, p);
+    }
     if (p.rowstat_out && (cfg < 4 || cfg > 8 || splits > 1 || !gemm_staged_epilogue_ok(p)))
         GYRE_FAIL(-6, "gemm: row statistics need an unsplit 8-wave tile config with the staged epilogue (see gemm_rowstat_parts)");
     if (p.ln_colsum && ((cfg != 24 && (cfg < 4 || cfg > 8)) || splits > 1 || !gemm_staged_epilogue_ok(p)))
@@ -1473,7 +1480,6 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         case 8: return launch_cfg8<128, 160, 4, 2>(st, p, KC_G8_CONV_128x160, splits);
-        case 11: return launch_cfg8<256, 160, 4, 2>(st, p, KC_G8_X1, splits);        // tuning only (tools/cfg_compare.py): not in the planner
         case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);
         default: GYRE_FAIL(-1, "gemm: unknown tile config");
     }
