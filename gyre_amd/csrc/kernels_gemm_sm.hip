@@ -14,6 +14,8 @@
 // past-the-end requests re-read step 0 into a free slot so that the in-flight count stays uniform.  No spills allowed
 // (build.py checks it).  The epilogue stages the fp32 tile through the (then idle) ring and writes whole 128-byte rows.
 //
+// (An eight-stage ring for grids of at most one workgroup per CU was measured: 10.1 -> 10.6 us at M = 512, N = K = 1280 - what is left
+// is launch and prologue, not the K chain.)
 // Same K order on one accumulator as every other tile config.
 // Replaces the cuBLAS GEMMs behind torch.nn.Linear in the third-party UNet the reference calls at
 // gyre/pipeline/unet/core.py:274 (BasicTransformerBlock to_q / to_k / to_v / to_out, proj_in / proj_out at the deep levels).
