@@ -1231,7 +1231,13 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     }
     // small problems (the planner's answer is one of the register-staged 4-wave tiles): the 4-stage LDS-DMA ring of
     // kernels_gemm_sm.hip hides the per-K-step memory latency those kernels expose (tuning bit 5: off)
-    if (cfg <= 3 && *splits_out == 1 && !trans && !(p.debug & 0x20) && gemm_sm_supports(p)) cfg = 32;
+    if (!trans && !(p.debug & 0x20) && gemm_sm_supports(p)) {
+        if (cfg <= 3 && *splits_out == 1) cfg = 32;
+        // ... and the long-K linear problems with few rows (FF2 of the deep levels at batch 1 - 2: M = 2048, K = 2560 -> 320 tiles of
+        // 64x64; M = 512, K = 5120 -> 160) that were cut into K slices: one launch instead of slices + reduction, 30.8 -> 26.4 us
+        // and 32.0 -> 25.2 us (tools/sm_bench.py, FORCE=32); with more tiles the 128x160 slices win (M = 4096: 27.9 vs 32.1)
+        else if (*splits_out > 1 && p.mode == GEMM_LINEAR && tiles(64, 64) <= 512 && !(p.debug & 0x40)) { cfg = 32; *splits_out = 1; }
+    }
     return cfg;
 }
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("M,K,N,res,bias", [(2048, 640, 640, True, True), (512, 1280, 1280, False, True), (154, 768, 320, False, False),
                                             (77, 768, 1280, False, False), (4096 + 8, 320, 320, True, True), (1, 64, 64, False, True),
-                                            (63, 128, 192, True, False), (1024, 2560, 640, True, True)])
+                                            (63, 128, 192, True, False), (1024, 2560, 640, True, True), (512, 5120, 1280, True, True)])
 def test_small_problem_kernel_matches_the_4_wave_kernel(M, K, N, res, bias):
     L = _lib.lib()
     x = (randn(M, K, seed=1) * 1.3).to(torch.bfloat16).to(DEV)
@@ -39,6 +39,9 @@ def test_small_problem_kernel_matches_the_4_wave_kernel(M, K, N, res, bias):
         pytest.skip(f"the planner keeps a larger tile for this shape: {names[1]}")
     assert "k_gemm_sm" not in names[0]
     assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0], outs[1])
+    if "k_splitk_reduce" in names[0]:        # the old path cut K into slices (fp32 slabs): same sums in another order
+        assert (outs[0].float() - outs[1].float()).abs().max().item() < 0.0625
+    else:
+        assert torch.equal(outs[0], outs[1])
     ref = x.float() @ w0.to(torch.bfloat16).float().to(DEV).T + (b0.to(DEV) if bias else 0) + (r.float() if res else 0)
     assert (outs[1].float() - ref).abs().max().item() < 0.08
