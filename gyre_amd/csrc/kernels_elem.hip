@@ -357,32 +357,6 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
     float* rstd_s = mean_s + 256;                 // [256]
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int cpg = p.C / p.G;
-    // everything the prologue does not depend on is requested FIRST, so that its round trip runs under the statistics' one: the affine
-    // parameters of this thread's channels (c = tid + 256 i) and this thread's first pixel-row vectors
-    constexpr int GN_CPT = 10;                               // channels per thread: C <= 2560 (the widest skip concat)
-    float pre_g[GN_CPT], pre_b[GN_CPT];
-#pragma unroll
-    for (int i = 0; i < GN_CPT; ++i) {
-        const int c = threadIdx.x + 256 * i;
-        pre_g[i] = c < p.C ? p.gamma[c] : 0.f;
-        pre_b[i] = c < p.C ? p.beta[c] : 0.f;
-    }
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int CV = p.C / 8, C2 = p.C - p.C1;
-    const int p0 = chunk * pix_per_chunk;
-    const int p1 = min(p.HW, p0 + pix_per_chunk);
-    uint4 first[GN_MAXV];
-    if (ty < PY && p0 + ty < p1) {
-        const size_t gp = (size_t)n * p.HW + p0 + ty;
-#pragma unroll
-        for (int v = 0; v < GN_MAXV; ++v) {
-            const int cv = tx + v * TX;
-            if (cv < CV) {
-                const int c = cv * 8;
-                first[v] = *(const uint4*)(c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1));
-            }
-        }
-    }
     {
         const float cnt = (float)p.HW * (float)cpg;
         int parts = 256 / p.G;
@@ -426,27 +400,18 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
             rstd_s[g] = rsqrtf(var + p.eps);
         }
         __syncthreads();
-        if (p.C <= 256 * GN_CPT) {
-#pragma unroll
-            for (int i = 0; i < GN_CPT; ++i) {
-                const int c = threadIdx.x + 256 * i;
-                if (c < p.C) {
-                    const int gg = c / cpg;
-                    const float aa = rstd_s[gg] * pre_g[i];
-                    ab[c] = aa;
-                    ab[p.C + c] = pre_b[i] - mean_s[gg] * aa;
-                }
-            }
-        } else {
-            for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-                const int gg = c / cpg;
-                const float aa = rstd_s[gg] * p.gamma[c];
-                ab[c] = aa;
-                ab[p.C + c] = p.beta[c] - mean_s[gg] * aa;
-            }
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            const int gg = c / cpg;
+            const float aa = rstd_s[gg] * p.gamma[c];
+            ab[c] = aa;
+            ab[p.C + c] = p.beta[c] - mean_s[gg] * aa;
         }
         __syncthreads();
     }
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int CV = p.C / 8, C2 = p.C - p.C1;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(p.HW, p0 + pix_per_chunk);
     if (ty >= PY) return;
     for (int pix = p0 + ty; pix < p1; pix += PY) {
         const size_t gp = (size_t)n * p.HW + pix;
@@ -457,7 +422,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
                 const int c = cv * 8;
                 const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
                 float f[8];
-                unpack8(pix == p0 + ty ? first[v] : *(const uint4*)src, f);
+                unpack8(*(const uint4*)src, f);
                 const float4 a0 = *(const float4*)(ab + c), a1 = *(const float4*)(ab + c + 4);
                 const float4 b0 = *(const float4*)(ab + p.C + c), b1 = *(const float4*)(ab + p.C + c + 4);
                 const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
