@@ -1422,7 +1422,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         }
     }
     if (p.vt_out) {
-        const int tn = cfg == 4 ? 160 : (cfg == 5 || cfg == 8) ? 80 : cfg == 6 ? 128 : (cfg == 7 || cfg == 30) ? 64 : 0;
+        const int tn = cfg == 4 ? 160 : (cfg == 5 || cfg == 8) ? 80 : cfg == 6 ? 128 : (cfg == 7 || cfg == 30 || cfg == 32) ? 64 : 0;
         if (!tn || splits > 1 || p.vt_col0 % tn) GYRE_FAIL(-6, "gemm: fused Q|K|V needs an 8-wave tile config whose wave tiles align with the V columns");
     }
     if (p.colstat_out) {

@@ -2,7 +2,7 @@
 // projections of the 32x32 / 16x16 / 8x8 UNet levels at batch 1 - 8 (M = 128 ... 4096), the text-context K / V projections
 // (M = 77 B), i.e. everything the planner used to give to the register-staged 4-wave kernel (k_gemm<64, 64, ...>):
 //
-//   C[M][N] = bf16( A[M][K] * W[N][K]^T + bias (+ residual) )
+//   C[M][N] = bf16( A[M][K] * W[N][K]^T + bias (+ residual) )        (+ the fused Q | K | V form: V columns leave transposed)
 //
 // Those launches are LATENCY-bound, not bandwidth- or MFMA-bound: 1.7 GFLOP and 6 - 16 MB took 15 - 24 us because the old
 // kernel fetches a K step (global -> registers -> LDS), waits for it, multiplies, and only then fetches the next one - about a
@@ -96,6 +96,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         tile[m * ROWF + wn * 32 + l31] = acc[r];
     }
     __syncthreads();
+    if (p.vt_out && n0 >= p.vt_col0) {
+        // V columns of a fused Q | K | V projection leave TRANSPOSED: vt_out[(b * Cv + channel) * ldt + token] (what the attention
+        // kernel streams); a thread packs 8 consecutive tokens of one channel, 8 lanes cover 128 contiguous bytes of a V^T row
+        const int cv_total = p.N - p.vt_col0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i, col = v >> 3, t8 = v & 7;
+            const int m = m0 + 8 * t8, n = n0 + col;
+            if (m >= p.M) continue;
+            const float bb = p.bias ? p.bias[n] : 0.f;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = tile[(8 * t8 + e) * ROWF + col] + bb;
+            const int b = m / p.tokens_per_batch, t = m - b * p.tokens_per_batch;
+            *(uint4*)(p.vt_out + ((size_t)b * cv_total + (n - p.vt_col0)) * p.ldt + t) = pack8(f);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int v = tid + 256 * i, row = v >> 3, c8 = v & 7;
@@ -118,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
 }
 
 bool gemm_sm_supports(const GemmParams& p) {
-    if (p.mode != GEMM_LINEAR || p.out_mode != OUT_BF16 || p.batch > 1 || p.geglu || p.vt_out) return false;
+    if (p.mode != GEMM_LINEAR || p.out_mode != OUT_BF16 || p.batch > 1 || p.geglu) return false;
+    if (p.vt_out && (p.vt_col0 <= 0 || p.vt_col0 % 64 || p.tokens_per_batch <= 0 || p.tokens_per_batch % 8 || p.ldt % 8 || p.M % 8 ||
+                     p.residual || ((size_t)p.vt_out & 15)))
+        return false;
     if (p.A2 && p.A2 != p.A) return false;
     if (p.rowbias || p.colstat_out || p.rowstat_out || p.ln_colsum || p.w_sample_stride) return false;
     if (p.K % 64 || p.K < 64 || p.N % 64 || p.M < 1 || p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8)) return false;

@@ -609,7 +609,7 @@ struct Exec {
                 if (dry()) { p.out = (void*)(uintptr_t)256; p.vt_out = (bf16_t*)(uintptr_t)256; p.A = (const bf16_t*)(uintptr_t)256; }  // (planning: aligned non-null)
                 GemmPlan pl = gemm_plan(p);
                 // (config 30 = the A-resident kernel: its 64-row weight tiles line up with the V columns whenever 2 C % 64 == 0)
-                const int tn = pl.cfg == 4 ? 160 : (pl.cfg == 5 || pl.cfg == 8) ? 80 : pl.cfg == 6 ? 128 : (pl.cfg == 7 || pl.cfg == 30) ? 64 : 0;
+                const int tn = pl.cfg == 4 ? 160 : (pl.cfg == 5 || pl.cfg == 8) ? 80 : pl.cfg == 6 ? 128 : (pl.cfg == 7 || pl.cfg == 30 || pl.cfg == 32) ? 64 : 0;
                 if (tn && pl.splits == 1 && (2 * C) % tn == 0) {
                     fused = true;
                     Tn stats;

@@ -45,3 +45,38 @@ def test_small_problem_kernel_matches_the_4_wave_kernel(M, K, N, res, bias):
         assert torch.equal(outs[0], outs[1])
     ref = x.float() @ w0.to(torch.bfloat16).float().to(DEV).T + (b0.to(DEV) if bias else 0) + (r.float() if res else 0)
     assert (outs[1].float() - ref).abs().max().item() < 0.08
+
+
+@pytest.mark.parametrize("B,tokens,C", [(2, 1024, 640), (2, 256, 1280), (1, 64, 1280), (3, 1024, 640)])
+def test_fused_qkv_with_transposed_v_on_the_small_kernel(B, tokens, C):
+    """Q | K | V of a deep-level self-attention at small batch as ONE launch of the small-problem kernel: Q | K row-major, the V
+    tiles transposed into V^T[b][channel][token] (gyre_op_qkv); before, such shapes had no fused form at all (two launches)."""
+    L = _lib.lib()
+    M = B * tokens
+    x = (randn(M, C, seed=21) * 1.1).to(torch.bfloat16)
+    w0 = (randn(3 * C, C, seed=22) / math.sqrt(C)).to(torch.bfloat16)
+    ref = x.float() @ w0.float().T
+    xd, wd = x.to(DEV), repack_linear(w0.float())
+    qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.prof_enable(None)
+    try:
+        _lib.check(L.gyre_op_qkv(st(), vp(xd), M, C, vp(wd), tokens, vp(qk), vp(vt), tokens))
+        torch.cuda.synchronize()
+        names = set(_lib.prof_collect())
+    finally:
+        _lib.prof_enable([])
+    if "k_gemm_sm" not in names:
+        pytest.skip(f"the planner has a larger fused tile for this shape: {names}")
+    assert names == {"k_gemm_sm"}, names
+    assert (qk.float().cpu() - ref[:, :2 * C]).abs().max().item() < 0.06
+    assert (vt.float().cpu() - ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)).abs().max().item() < 0.06
+    # the unfused pair of launches computes the same sums in the same order
+    L.gyre_debug_gemm_ablation(0x20)
+    try:
+        qk2 = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        rc = L.gyre_op_linear(st(), vp(xd), M, C, vp(wd), 2 * C, None, None, 0, vp(qk2))
+    finally:
+        L.gyre_debug_gemm_ablation(0)
+    if rc == 0:
+        assert torch.equal(qk, qk2)
