@@ -47,20 +47,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
 
     // ---- ring requests: wave w fetches pieces 2w, 2w + 1 (rows 16w .. 16w + 15) of the A half and of the W half of every stage;
     // lane l' of a piece: row 8 * piece + (l' >> 3), slot l' & 7 holds chunk slot ^ ((row >> 1) & 7)
+    // Two-source rows (the 1x1 shortcut of an up-path resnet reads the concatenation [x | skip] without materialising it): K steps
+    // below C1 / 64 come from A, the others from A2 (GemmParams::A2, lda2, C1 - whole 64-channel steps of one source)
     const char* src[PPW];
+    const char* src2[2];
+    const int k1 = p.C1 / 64;                                        // first K step of the second source (= nk for one source)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 16 * w + 8 * i + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        src[i] = (const char*)(p.A + (size_t)min(m0 + row, p.M - 1) * p.lda) + chunk * 16;          // rows past M re-read row M - 1 (never stored)
+        const int mr = min(m0 + row, p.M - 1);                        // rows past M re-read row M - 1 (never stored)
+        src[i] = (const char*)(p.A + (size_t)mr * p.lda) + chunk * 16;
+        src2[i] = (const char*)(p.A2 + (size_t)mr * p.lda2) + chunk * 16 - (size_t)k1 * 128;
         src[2 + i] = (const char*)(p.W + (size_t)min(n0 + row, p.N - 1) * p.K) + chunk * 16;
     }
     auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
         const int kk = kt < nk ? kt : 0;                            // past-the-end: re-read step 0 (never consumed)
         const unsigned dst = lds0 + slot * STAGE + (2 * w) * 1024;
+        const bool second = kk >= k1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            sm_glds(dst + i * 1024, src[i] + (size_t)kk * 128);
+            sm_glds(dst + i * 1024, (second ? src2[i] : src[i]) + (size_t)kk * 128);
             sm_glds(dst + WOFF + i * 1024, src[2 + i] + (size_t)kk * 128);
         }
     };
@@ -140,7 +147,7 @@ bool gemm_sm_supports(const GemmParams& p) {
     if (p.vt_out && (p.vt_col0 <= 0 || p.vt_col0 % 64 || p.tokens_per_batch <= 0 || p.tokens_per_batch % 8 || p.ldt % 8 || p.M % 8 ||
                      p.residual || ((size_t)p.vt_out & 15)))
         return false;
-    if (p.A2 && p.A2 != p.A) return false;
+    if (p.A2 && p.A2 != p.A && (p.C1 <= 0 || p.C1 >= p.K || p.C1 % 64 || p.lda2 % 8 || ((size_t)p.A2 & 15))) return false;
     if (p.rowbias || p.colstat_out || p.rowstat_out || p.ln_colsum || p.w_sample_stride) return false;
     if (p.K % 64 || p.K < 64 || p.N % 64 || p.M < 1 || p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8)) return false;
     if ((((size_t)p.A | (size_t)p.W | (size_t)p.out | (size_t)p.residual) & 15) != 0 || (((size_t)p.bias) & 15) != 0) return false;
