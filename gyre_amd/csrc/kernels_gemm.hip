@@ -1319,6 +1319,10 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     if (cfg == 24) return splits == 1 && gemm4s_supports(p, 24);      // pipelined 256x320 tile (kernels_gemm4s.hip)
     if (cfg == 30) return true;                                        // A-resident kernel (kernels_gemm_ar.hip)
     if (cfg == 31) return true;                                        // W-resident kernel (kernels_gemm_wr.hip)
+    // small-problem kernel (kernels_gemm_sm.hip): has the fold and the row statistics, but OFF unless tuning bit 7 asks: 47 launches
+    // fewer per UNet call at batch 2 (402 -> 355) and the call 6.01 -> 6.10 ms (batch 4: 7.66 -> 7.78) - the LayerNorm launches it
+    // removes are cheaper than the statistics loops and folded epilogues it adds
+    if (cfg == 32) return !p.geglu && (p.debug & 0x80);
     if (cfg < 4 || cfg > 8 || splits > 1) return false;
     if (p.geglu && (cfg == 4 || cfg == 5 || cfg == 8)) return false;
     if (p.vt_out) {
@@ -1339,6 +1343,7 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     const int cfg = plan_cfg(p, &splits);
     if (cfg == 30) return gemm_ar_nsplit(p);          // A-resident kernel: one partial per N-range split of the row block
     if (cfg == 31) return gemm_wr_parts(p);           // W-resident kernel: one partial per wave and column panel
+    if (cfg == 32) return (p.debug & 0x80) ? p.N / 64 : 0;   // small-problem kernel: one partial per 64-column tile (tuning bit 7, see gemm_ln_fusable)
     if (cfg < 4 || cfg > 8 || splits > 1) return 0;
     const int bn = (cfg == 4 || cfg == 5) ? 320 : cfg == 8 ? 160 : 256;
     return (p.N + bn - 1) / bn;

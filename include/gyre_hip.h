@@ -280,7 +280,8 @@ long gyre_debug_attn_redo_count(void);
  * kernels_gemm_wr.hip) for the K = 320 linear problems with N a multiple of 320 below 3 K (measured: no gain), bit23 = no pipelined 256x320 tile
  * for 3x3 convs whose grid of it has 128 - 159 workgroups (the 48x48 level of a 768 px request), bit5 = no small-problem kernel
  * (tile config 32, kernels_gemm_sm.hip): small linear problems go to the register-staged 4-wave tiles as before, bit6 = it does not take
- * the long-K few-row linear problems from the split-K path.  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
+ * the long-K few-row linear problems from the split-K path, bit7 = folded LayerNorm / row statistics also in it (measured slower than the
+ * separate LayerNorm pass small problems keep by default).  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
 int gyre_debug_gemm_ablation(int bits);
 
 /* ---- batch-invariant mode ------------------------------------------------
