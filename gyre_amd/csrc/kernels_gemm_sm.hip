@@ -2,7 +2,12 @@
 // projections of the 32x32 / 16x16 / 8x8 UNet levels at batch 1 - 8 (M = 128 ... 4096), the text-context K / V projections
 // (M = 77 B), i.e. everything the planner used to give to the register-staged 4-wave kernel (k_gemm<64, 64, ...>):
 //
-//   C[M][N] = bf16( A[M][K] * W[N][K]^T + bias (+ residual) )        (+ the fused Q | K | V form: V columns leave transposed)
+//   C[M][N] = bf16( A[M][K] * W[N][K]^T + bias (+ residual) )
+//
+// plus the forms the model's deep levels need at small batch: the fused Q | K | V of a self-attention (GemmParams::vt_out: tiles at
+// or behind vt_col0 leave transposed, V^T[b][channel][token]), two-source rows (A | A2: the 1x1 shortcut over a skip concatenation),
+// the long-K few-row problems the planner used to cut into K slices, and - behind tuning bit 7, measured slower than the separate
+// LayerNorm pass - the folded LayerNorm (ln_colsum) and per-row statistics of the output (rowstat_out, one partial per N tile).
 //
 // Those launches are LATENCY-bound, not bandwidth- or MFMA-bound: 1.7 GFLOP and 6 - 16 MB took 15 - 24 us because the old
 // kernel fetches a K step (global -> registers -> LDS), waits for it, multiplies, and only then fetches the next one - about a
