@@ -1171,6 +1171,9 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         //  the chip, M = 65536: 41 vs 38 us)
         if (!p.geglu && p.N % 160 == 0 && !(p.debug & 0x40000)) big(8, 0.90, 128, 160);
         if (p.N % 256 == 0) { big(6, 0.95, 256, 256); big(7, 0.62, 128, 256); }
+        // 256x128 (config 12): 3x3 convs into 128 channels - the 512x512 level of the VAE decoder, 25 % of a decode - had no 8-wave
+        // tile (N = 128 is no multiple of 160 / 256 / 320) and ran on the register-staged 128x128 tile at 0.20 - 0.22 of the MFMA peak
+        if (p.mode == GEMM_CONV3 && !p.geglu && p.N % 128 == 0 && p.N % 256 != 0 && p.N % 160 != 0 && !(p.debug & 0x40000)) big(12, 0.90, 256, 128);
         // pipelined 32x32x16 kernel (kernels_gemm4s.hip), 8 waves on the 256x320 tile: better main loop (barrier off the
         // critical path, requests issued from the MFMA gaps), heavier two-pass epilogue -> long reductions only.
         // Measured in the UNet (tools/unet_layers.py, r02): 3x3 convs at 64x64 -3...-7 % time, K = 2560 linears -19 %, the
@@ -1489,6 +1492,9 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         case 4: return launch_cfg8<256, 320, 4, 2>(st, p, KC_G8_CONV_256x320, splits);
         case 5: return launch_cfg8<128, 320, 2, 4>(st, p, KC_G8_CONV_128x320, splits);
         case 6: return launch_cfg8<256, 256, 4, 2>(st, p, KC_G8_CONV_256x256, splits);
+        case 12:
+            if (p.mode != GEMM_CONV3) GYRE_FAIL(-6, "gemm: the 256x128 tile is a convolution config");
+            return launch_cfg8<256, 128, 4, 2>(st, p, KC_G8_X1, splits);
         case 7: return launch_cfg8<128, 256, 2, 4>(st, p, KC_G8_CONV_128x256, splits);
         case 8: return launch_cfg8<128, 160, 4, 2>(st, p, KC_G8_CONV_128x160, splits);
         case 20: case 21: case 22: case 23: case 24: return launch_gemm4s(st, p, cfg, splits);

@@ -53,7 +53,7 @@ static const char* kclass_name(int k) {
         "k_gemm<128, 128, 2, 2, 0", "k_gemm<256, 64, 4, 1, 0", "k_gemm<64, 64, 2, 2, 0",
         "k_gemm8<256, 320, 4, 2, 1", "k_gemm8<128, 320, 2, 4, 1", "k_gemm8<256, 256, 4, 2, 1", "k_gemm8<128, 256, 2, 4, 1",
         "k_gemm8<256, 320, 4, 2, 0", "k_gemm8<128, 320, 2, 4, 0", "k_gemm8<256, 256, 4, 2, 0", "k_gemm8<128, 256, 2, 4, 0",
-        "k_gemm8<128, 160, 4, 2, 1", "(unused 1)", "(unused 2)", "(unused 3)", "k_gemm8<128, 160, 4, 2, 0",
+        "k_gemm8<128, 160, 4, 2, 1", "k_gemm8<256, 128, 4, 2, 1", "(unused 2)", "(unused 3)", "k_gemm8<128, 160, 4, 2, 0",
         "k_gemm4s<192, 320, 2, 2, 1", "k_gemm4s<192, 320, 2, 2, 0", "k_gemm4s<256, 256, 2, 2, 1", "k_gemm4s<256, 256, 2, 2, 0",
         "k_gemm4s<128, 320, 2, 2, 1", "k_gemm4s<128, 320, 2, 2, 0", "k_gemm4s<128, 256, 2, 2, 1", "k_gemm4s<128, 256, 2, 2, 0", "k_gemm4s<256, 320, 4, 2, 1", "k_gemm4s<256, 320, 4, 2, 0",
         "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other", "k_attn_bwd", "k_gn_bwd+k_ln_bwd",

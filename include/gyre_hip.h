@@ -250,7 +250,8 @@ int gyre_prof_collect(int64_t* launches, double* ms, double* flops, double* byte
 
 /* Tests / tuning only: force the GEMM tile configuration of this thread's following launches
  * (0 = automatic; 1 = 4-wave 128x128, 2 = 4-wave 256x64, 3 = 4-wave 64x64, 4 = 8-wave 256x320,
- * 5 = 8-wave 128x320, 6 = 8-wave 256x256, 7 = 8-wave 128x256; bits 8-15 = split-K factor for the 8-wave
+ * 5 = 8-wave 128x320, 6 = 8-wave 256x256, 7 = 8-wave 128x256 (8 = 128x160, 12 = 256x128 convolutions only, 20 - 24 pipelined forms,
+ * 30 / 31 A- / W-resident, 32 small-problem kernel); bits 8-15 = split-K factor for the 8-wave
  * configs, 0/1 = none).  Returns the previous value. */
 int gyre_debug_force_gemm_cfg(int cfg);
 /* Tests / tuning only: split-K slab space for this thread's gyre_op_* calls (the model handles carve theirs from
