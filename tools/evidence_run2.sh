@@ -1,0 +1,10 @@
+set -x
+O=$GRAFT_REPO_ROOT/gpurun_out/r04x
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+bash tools/profile_bench.sh r04 > $O/profile.log 2>&1
+cd $GRAFT_REPO_ROOT
+MD=$O/unet_layers.md python tools/unet_layers.py > $O/unet_layers.txt 2>&1
+B=2 MD=$O/unet_layers_b2.md python tools/unet_layers.py > $O/unet_layers_b2.txt 2>&1
+for c in sdxl inpaint768; do python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err; done
+echo done
