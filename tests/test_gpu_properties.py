@@ -277,3 +277,52 @@ def test_groupnorm_folded_into_proj_in_matches_the_apply_pass():
     perm = torch.tensor([2, 0, 3, 1], device=DEV)
     again = net(x[perm], t, encoder_hidden_states=ctx[perm]).sample.float().cpu()
     assert torch.equal(again, outs[0][perm.cpu()])
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_small_problem_kernel_inside_the_unet_matches_the_4_wave_path(B):
+    """At small batch the deep levels' linear layers run on the small-problem kernel (tile config 32: plain / residual projections,
+    the fused Q | K | V with transposed V, the two-source 1x1 shortcuts of the up path, the long-K problems that used to be cut into
+    K slices).  Full SD1.5 UNet call with the kernel on and off (tuning bit 5): the same function - bit for bit where no split-K
+    plan changed, else up to the order of a few fp32 sums - and it IS what runs."""
+    cfg = gcfg.sd15_unet()
+    net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.ndim > 1:
+                p.copy_(torch.randn(p.shape, device=DEV, generator=g, dtype=torch.float32) / p[0].numel() ** 0.5)
+            elif k.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    net._invalidate()
+    x = torch.randn(B, 4, 64, 64, device=DEV, generator=g)
+    ctx = torch.randn(B, 77, 768, device=DEV, generator=g)
+    t = torch.full((B,), 400, device=DEV)
+    L = _lib.lib()
+    outs, names, launches = {}, {}, {}
+    for bits in (0, 0x40, 0x20):
+        L.gyre_debug_gemm_ablation(bits)
+        try:
+            net(x, t, encoder_hidden_states=ctx)                      # (packs / caches of this plan)
+            _lib.prof_enable(None)
+            outs[bits] = net(x, t, encoder_hidden_states=ctx).sample.float().cpu()
+            launches[bits] = L.gyre_last_launch_count()
+            torch.cuda.synchronize()
+            names[bits] = _lib.prof_collect()
+        finally:
+            _lib.prof_enable([])
+            L.gyre_debug_gemm_ablation(0)
+    assert "k_gemm_sm" in names[0] and names[0]["k_gemm_sm"]["launches"] >= 60 and "k_gemm_sm" not in names[0x20]
+    d = float((outs[0] - outs[0x20]).norm() / outs[0x20].norm())
+    print(f"[property] small-problem kernel on / off at batch {B}: rel-L2 {d:.2e}; launches {launches[0]} vs {launches[0x20]}; "
+          f"k_gemm_sm launches {names[0]['k_gemm_sm']['launches']}")
+    # bit 6 keeps the planner's K slices: what is left differs from the 4-wave path only in WHICH kernel adds the same numbers
+    same = torch.equal(outs[0x40], outs[0x20])
+    print(f"[property]   with the split-K plan kept (bit 6): bit-identical to the 4-wave path: {same}")
+    assert same
+    # the default also runs the long-K few-row problems unsplit: another order of fp32 sums, amplified by a random-weight UNet like any
+    # other rounding change (the GroupNorm fold above: 1.5e-2)
+    assert torch.isfinite(outs[0]).all() and d < 2e-2
+    assert launches[0] < launches[0x20]
