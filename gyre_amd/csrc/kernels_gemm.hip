@@ -1123,6 +1123,11 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
 // 4 = 8w 256x320, 5 = 8w 128x320, 6 = 8w 256x256, 7 = 8w 128x256, 8 = 8w 128x160.
 static thread_local void* g_dbg_ar_ws = nullptr;       // gyre_debug_set_ar_workspace: packed-weight scratch of bare gyre_op_* calls
 static thread_local size_t g_dbg_ar_ws_bytes = 0;
+// smallest grid the A-resident kernel is taken for (GYRE_AR_GRID_MIN: tuning override, read once)
+static long ar_grid_min() {
+    static const long v = getenv("GYRE_AR_GRID_MIN") ? atol(getenv("GYRE_AR_GRID_MIN")) : 192;
+    return v;
+}
 static int pick_cfg(const GemmParams& p, int* splits_out) {
     *splits_out = 1;
     const bool trans = p.out_mode == OUT_BF16_T;
@@ -1149,7 +1154,10 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
     // at 32x32; a plain N = 3 C: 80 -> 62 us).  The C x C projections (5 N tiles per workgroup) are HBM-bound either way and
     // measured 5 - 7 % slower here (33 -> 35 us): they stay on the 8-wave tiles unless tuning bit 22 asks for them.
     if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && !(p.debug & 0x200000) && p.M >= 4096 &&
-        (p.N >= 3 * p.K || (p.debug & 0x400000)) && gemm_ar_supports(p))
+        (p.N >= 3 * p.K || (p.debug & 0x400000)) && gemm_ar_supports(p) &&
+        // ... and only where its grid (256-row blocks x N-range splits of at least four tiles) covers most of the chip: the fused Q|K|V
+        // at batch 2 (M = 8192, 15 N tiles -> 64 workgroups) took 31 us there against 18 us on the 8-wave tile
+        ((long)((p.M + 255) / 256) * gemm_ar_nsplit(p) >= ar_grid_min() || (p.debug & 0x400000)))
         return 30;
     // W-resident kernel (kernels_gemm_wr.hip): the square projections (N = K, or N a multiple of 320 below 3 K) keep a 320-column
     // weight panel in registers and stream their rows through an LDS ring.  OFF unless tuning bit 13 asks for it: measured
