@@ -263,8 +263,11 @@ int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
 int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
- * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic with the
- * per-tile overflow check of the pipelined kernel in every tile (no optimistic first pass).  Returns the previous value. */
+ * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic (the
+ * pipelined kernel's per-tile overflow check in every tile: the default since the end of round 4); 8 = automatic WITH the optimistic
+ * first pass of the pipelined kernel (head dims <= 40: no per-tile check, a workgroup whose row sums leave the finite range repeats its
+ * pass with the check) - 2 % faster per UNet call, exact, but not bit-reproducible when two handles share one GPU concurrently.
+ * Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
 /* Tuning only: with GYRE_ATTN_COUNT_REDO=1 in the environment, the number of attention workgroups that have repeated their pass with
  * the per-tile overflow check so far in this process (the first call creates the counter; -1: counting is off). */

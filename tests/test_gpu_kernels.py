@@ -507,7 +507,7 @@ def test_attention_optimistic_pass_and_its_fallback(D, excess):
     kpre = (k32 * c).to(torch.bfloat16).to(DEV)
     vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
     outs = []
-    for variant in (0, 7):
+    for variant in (8, 7):                          # 8 = optimistic first pass (opt-in), 7 = per-tile check (the default)
         o = torch.full((B, N, C_), float("nan"), dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_attn_variant(variant)
         try:
