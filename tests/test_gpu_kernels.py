@@ -487,12 +487,13 @@ def test_attention_prescaled_peaked_and_drifting_max():
 
 
 @pytest.mark.parametrize("D", [32, 40, 64])
-@pytest.mark.parametrize("excess", [90.0, 300.0])
+@pytest.mark.parametrize("excess", [60.0, 90.0, 300.0])
 def test_attention_optimistic_pass_and_its_fallback(D, excess):
     """The pipelined kernel's first pass centres every row on the maximum of the FIRST key tile and checks no later tile.  A late
-    key whose score lies `excess` (log2 units) above that: 90 - still finite in fp32, the optimistic pass is exact; 300 - exp2
-    overflows, the row sum turns non-finite, and the workgroup repeats the pass with the per-tile check (variant 7 = that pass
-    from the start).  Both must agree with the fp32 reference and with each other.  (D = 64 keeps the checked pass: same kernel twice.)"""
+    key whose score lies `excess` (log2 units) above that: 60 - the row sum stays below the 1e25 acceptance bound, the optimistic
+    pass is exact; 90 - finite but above the bound, 300 - exp2 overflows: the workgroup repeats the pass with the per-tile check
+    (variant 7 = that pass from the start).  All must agree with the fp32 reference and with each other.  (D = 64 keeps the
+    checked pass: same kernel twice.)"""
     L = _lib.lib()
     B, heads, N = 1, 2, 1024
     C_ = heads * D
@@ -507,7 +508,7 @@ def test_attention_optimistic_pass_and_its_fallback(D, excess):
     kpre = (k32 * c).to(torch.bfloat16).to(DEV)
     vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
     outs = []
-    for variant in (8, 7):                          # 8 = optimistic first pass (opt-in), 7 = per-tile check (the default)
+    for variant in (0, 7):                          # 0 = the default: optimistic first pass; 7 = per-tile check from the start
         o = torch.full((B, N, C_), float("nan"), dtype=torch.bfloat16, device=DEV)
         old = L.gyre_debug_force_attn_variant(variant)
         try:

@@ -3,9 +3,9 @@ import math, os, subprocess, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 if len(sys.argv) == 1:
-    for D in (40, 64, 32):
-        for excess in (0.0, 90.0, 300.0):
-            for variant in (8, 7):
+    for D in (40, 64, 32, 80, 16):
+        for excess in (0.0, 60.0, 90.0, 300.0):
+            for variant in (0, 7):
                 for N in (640, 1024):
                     r = subprocess.run([sys.executable, __file__, str(D), str(excess), str(variant), str(N)], capture_output=True, text=True)
                     print(f"D={D} excess={excess} variant={variant} N={N}: rc={r.returncode} {r.stdout.strip()[-200:]} {r.stderr.strip()[-300:] if r.returncode else ''}", flush=True)
