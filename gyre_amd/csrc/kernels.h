@@ -128,6 +128,13 @@ struct GemmParams {
     // first use and sets w_packed, tests pass a scratch buffer through gyre_debug_set_ar_workspace); no_ar = the caller wants a
     // feature that kernel lacks from this launch (column statistics for a GroupNorm)
     const void* w_packed = nullptr; int ar_ok = 0, no_ar = 0;
+    // BLOCKED copy of W for the LDS-DMA tile kernels (tile configs 4 - 8, 12, 20 - 24, 32; round 5): 1-KiB blocks of 8 weight rows x
+    // 64 k, block (n >> 3, k >> 6) at ((n >> 3) * (K / 64) + (k >> 6)) * 512 elements, row-major inside.  A wave's LDS-DMA request
+    // (8 rows x 128 B) then reads ONE contiguous KiB instead of eight lines 2 K bytes apart: tools/ubench/l2_bw.hip measures 82 - 125
+    // GB/s per CU from L2 for requests that stay inside 16 KB and 19 - 60 for requests spread over more 4-KiB pages, which is what
+    // every weight request with K >= 1280 (and every 3x3 conv's: K = 9 Cin) was.  K % 64 == 0, N % 8 == 0; kernels that do not
+    // know the layout ignore the field and read W.  (launch_w_block makes the copy; the model runtime caches one per weight.)
+    const bf16_t* W_blk = nullptr;
     // per-SAMPLE weights (8-wave tile configs 4 - 8, linear mode): rows of sample b = row / rows_per_sample read W + b *
     // w_sample_stride (elements); row blocks never straddle a sample (gemm_per_sample_w_ok).  The GroupNorm folded into a
     // Transformer2D's proj_in (launch_gn_fold); the per-sample bias travels as `rowbias`
@@ -150,6 +157,8 @@ int launch_ln_fold(hipStream_t st, const bf16_t* W, int N, int K, const float* g
 // A-resident kernel (tile config 30): bytes of / conversion into the fragment-ordered weight copy it reads (GemmParams::w_packed)
 size_t gemm_ar_packed_bytes(int N, int K);
 int launch_ar_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
+int launch_w_block(hipStream_t st, const bf16_t* W, int N, int K, bf16_t* out);   // out: N * K elements (GemmParams::W_blk)
+bool gemm_w_block_wanted(const GemmParams& p);      // the planner's kernel for `p` reads a blocked copy and the shape gains from one
 size_t gemm_wr_packed_bytes(int N, int K);          // the W-resident kernel's fragment order (tile config 31)
 int launch_wr_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.

@@ -364,7 +364,7 @@ __device__ __forceinline__ void gemm_epilogue_staged_t(const GemmParams& p, f32x
 // RS: also emit per-row partial statistics of the output tile (GemmParams::rowstat_out)
 // CS: also emit per-column-unit partial statistics of the output tile (GemmParams::colstat_out)
 template <int BM, int BN, int WM, int WN, int MODE, bool UNIFORM_TAP, bool LNF = false, bool RS = false, bool CS = false>
-__global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits) {
+__global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int tiles_n, int splits, int nst) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 16, NI = TN / 16;
     constexpr int AR = BM / 64, BR = (BN + 63) / 64;  // 64-row staging granules per K step (A, B); the last B granule may be partial
@@ -462,7 +462,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int n = n0 + r0 + 64 * i;
-            const bf16_t* src = (kok && n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN)) ? wbase + (size_t)n * p.K + kw : zero;
+            const bf16_t* src = zero;
+            if (kok && n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN))
+                src = p.W_blk ? p.W_blk + ((size_t)(n >> 3) * (p.K >> 6) + (kw >> 6)) * 512 + (n & 7) * 64 + (kw & 63) : wbase + (size_t)n * p.K + kw;
             __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sbase + BM * 128 + i * 8192), 16, 0, 0);
         }
     };
@@ -478,15 +480,10 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int kc0 = split * nk_per;
     const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
-    issue_stage(kc0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kc = kc0; kc < nk; ++kc) {
-        const int cur = (kc - kc0) & 1;
-        if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
-        const uint4* a = (const uint4*)(smem_raw + cur * STAGE_BYTES);
+    // one 64-deep K step out of ring slot `slot`
+    auto k_step = [&](int slot) {
+        const uint4* a = (const uint4*)(smem_raw + slot * STAGE_BYTES);
         const uint4* b = a + BM * 8;
-        if (!(p.debug & 2))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // (explicit 2-deep fragment prefetch pinned with sched_group_barrier was measured 3-6 % slower: with two
@@ -506,8 +503,102 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
             }
         }
+    };
+    bool ring_done = false;
+    if constexpr (MODE == GEMM_LINEAR) {
+        // Round 5: the K loop of the linear problems as an nst-deep LDS ring (nst = 2 ... 4, chosen by the launcher from the LDS a
+        // workgroup may take), nst - 1 stages IN FLIGHT while one is multiplied.  The two-stage loop below requests stage k+1,
+        // multiplies stage k and then waits for everything: one exposed memory latency per 64-deep K step - with the weights of a
+        // 16x16-level projection cold in HBM that was ~1.3 us per step against 0.27 us of MFMA work (M = 4096, N = K = 1280: 20
+        // steps, 32 us for 5.4 us of matrix work).  tools/ubench/l2_bw.hip (profiles/r05_l2_bw.txt) shows what the load path can
+        // do when fed: 125 - 137 GB/s per CU from L2 by LDS-DMA, 30 from the Infinity Cache, 24 - 27 from HBM.
+        //   * requests are inline asm (hipcc would make the next ds_read wait for a builtin LDS-DMA), one running 64-bit source
+        //     pointer per request slot (+128 B per step; rows / weight rows past the end: the zero page, step 0);
+        //   * counted s_waitcnt vmcnt((nst - 2) * requests per wave) + ONE barrier per step; s_waitcnt lgkmcnt(0) in front of the
+        //     barrier: the slot refilled right behind it is the one the previous step read (every fragment read has returned
+        //     before any wave can request the refill - the ring discipline of kernels_attn.hip);
+        //   * past-the-end stages are requested from the zero page so that the in-flight count stays uniform.
+        // Same fragment reads, same K order, same accumulators: bit-identical to the two-stage loop (tuning bit 24 = that loop).
+        if (nst >= 2 && p.K % BK == 0 && p.C1 % BK == 0 && !(p.debug & 0x1000003)) {
+            constexpr int PPW = AR + BR;
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+            auto dma16 = [&](unsigned dst, const char* src) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+            };
+            const int k1 = p.C1 / BK;                                 // first K step of the second source (= all steps for one source)
+            const char* ca[AR]; const char* cw[BR];
+            unsigned ia[AR], iw[BR];
+            auto a_ptr = [&](int i, bool second, int kstep) -> const char* {
+                const int row = a_base[i];
+                return second ? (const char*)(p.A2 + (size_t)row * p.lda2 + kvs * 8) + (size_t)(kstep - k1) * 128
+                              : (const char*)(p.A + (size_t)row * p.lda + kvs * 8) + (size_t)kstep * 128;
+            };
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = a_base[i] >= 0;
+                ca[i] = ok ? a_ptr(i, kc0 >= k1, kc0) : (const char*)zero;
+                ia[i] = ok ? 128u : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) {
+                const int n = n0 + r0 + 64 * i;
+                const bool ok = n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN);
+                if (p.W_blk) {       // blocked copy: the 8 rows x 128 B of a request are one KiB, the next K step the next KiB
+                    cw[i] = ok ? (const char*)(p.W_blk + ((size_t)(n >> 3) * (p.K >> 6) + kc0) * 512 + (n & 7) * 64 + kvs * 8) : (const char*)zero;
+                    iw[i] = ok ? 1024u : 0u;
+                } else {
+                    cw[i] = ok ? (const char*)(wbase + (size_t)n * p.K + kvs * 8) + (size_t)kc0 * 128 : (const char*)zero;
+                    iw[i] = ok ? 128u : 0u;
+                }
+            }
+            int kabs = kc0;                                           // K step the next request fetches
+            auto ring_issue = [&](int slot) {
+                const unsigned dst = lds0 + slot * STAGE_BYTES + wave * 1024;
+                if (kabs < nk) {
+                    if (kabs == k1 && kabs > kc0) {                   // (wave-uniform, at most once) the rows continue in the second source
+#pragma unroll
+                        for (int i = 0; i < AR; ++i) if (a_base[i] >= 0) ca[i] = a_ptr(i, true, kabs);
+                    }
+#pragma unroll
+                    for (int i = 0; i < AR; ++i) { dma16(dst + i * 8192, ca[i]); ca[i] += ia[i]; }
+#pragma unroll
+                    for (int i = 0; i < BR; ++i) { dma16(dst + BM * 128 + i * 8192, cw[i]); cw[i] += iw[i]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i) dma16(dst + i * 8192, (const char*)zero);
+                }
+                ++kabs;
+            };
+            int fill = 0;                                             // slot the next request fills
+            for (int s = 0; s + 1 < nst; ++s) { ring_issue(fill); ++fill; }
+            int slot = 0;
+            for (int kc = kc0; kc < nk; ++kc) {
+                // stage kc has landed for this wave (the nst - 2 younger ones may be in flight), then - barrier - for every wave
+                if (nst == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if (nst == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+                __builtin_amdgcn_s_barrier();
+                ring_issue(fill);                                     // the slot stage kc - 1 was read from
+                fill = fill + 1 == nst ? 0 : fill + 1;
+                k_step(slot);
+                slot = slot + 1 == nst ? 0 : slot + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-page requests past the end: nothing may land after this
+            __syncthreads();
+            ring_done = true;
+        }
+    }
+    if (!ring_done) {
+        issue_stage(kc0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kc = kc0; kc < nk; ++kc) {
+            const int cur = (kc - kc0) & 1;
+            if (kc + 1 < nk && !(p.debug & 1)) issue_stage(kc + 1, cur ^ 1);
+            if (!(p.debug & 2)) k_step(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
     if (!LNF && !RS && !CS && splits > 1) {     // (the folded-LayerNorm / statistics forms are launched unsplit, staged epilogue only)
         // fp32 partial slab of this K slice; bias / residual / rounding happen once in k_splitk_reduce
@@ -1059,9 +1150,23 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int splits) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n * splits;
-    size_t lds = (size_t)2 * (BM + (BN + 63) / 64 * 64) * 128;
+    // ring depth of the linear-mode K loop (k_gemm8): as deep as the LDS of ONE workgroup per CU allows when the grid has no second
+    // workgroup for a CU anyway (or the tile is too big for two), else two stages each for two co-resident workgroups
+    // (tuning bit 24: the two-stage loop everywhere; bit 25: the deep ring also where two 2-stage workgroups would fit)
+    const size_t stage = (size_t)(BM + (BN + 63) / 64 * 64) * 128;
+    int nst = 2;
+    if (p.mode == GEMM_LINEAR && !(p.debug & 0x1000000)) {
+        const int fit1 = (int)std::min<size_t>(4, (size_t)160 * 1024 / stage);
+        const bool two_fit = 4 * stage <= (size_t)160 * 1024;
+        if (grid <= 256 || !two_fit || (p.debug & 0x2000000)) nst = fit1;
+        const int steps = ((p.K + BK - 1) / BK + splits - 1) / splits;
+        if (nst > steps) nst = steps < 2 ? 2 : steps;
+        if (nst < 2) nst = 2;
+    }
+    size_t lds = (size_t)nst * stage;
     if (p.mode == GEMM_LINEAR && p.ln_colsum && p.geglu && gemm_geglu_lnf_lds_bytes(BM, BN, WM, WN) <= 160 * 1024)
         lds = std::max(lds, gemm_geglu_lnf_lds_bytes(BM, BN, WM, WN));
+    const int lds_attr = 160 * 1024;      // (the attribute is set once per kernel and device: the most any launch of it asks for)
     const int kcls = kcls_base + (p.mode == GEMM_CONV3 ? 0 : 4);
     const double n_out = p.geglu ? p.N / 2.0 : (double)p.N;
     const double a_bytes = p.mode == GEMM_CONV3 ? (double)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.Cin * 2.0
@@ -1073,8 +1178,8 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
         auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_>;                                                             \
         static std::atomic<unsigned long long> attr_done{0};                                                                               \
         if (gyre_lds_attr_needed(attr_done))                                                                                            \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, nst);                      \
     } while (0)
     if (p.colstat_out && splits == 1) {
         if constexpr (BN == 320 || BN == 160) {
@@ -1084,8 +1189,8 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
         auto kern = k_gemm8<BM, BN, WM, WN, MODE_, UNI_, false, false, true>;                                       \
         static std::atomic<unsigned long long> attr_done{0};                                                        \
         if (gyre_lds_attr_needed(attr_done))                                                                        \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);                      \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, nst);                      \
     } while (0)
             if (p.mode == GEMM_LINEAR) GYRE_GEMM8_CS(GEMM_LINEAR, true);
             else if (uni) GYRE_GEMM8_CS(GEMM_CONV3, true);
@@ -1098,14 +1203,14 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
         auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, false, true>;
         static std::atomic<unsigned long long> attr_done{0};
         if (gyre_lds_attr_needed(attr_done))
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, nst);
     } else if (p.mode == GEMM_LINEAR && p.ln_colsum) {
         auto kern = k_gemm8<BM, BN, WM, WN, GEMM_LINEAR, true, true>;
         static std::atomic<unsigned long long> attr_done{0};
         if (gyre_lds_attr_needed(attr_done))
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits);
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, nst);
     } else if (p.mode == GEMM_LINEAR) {
         GYRE_GEMM8_GO(GEMM_LINEAR, true);
     } else {
@@ -1391,6 +1496,42 @@ GemmPlan gemm_plan(const GemmParams& p0) {
     return pl;
 }
 
+// W[N][K] -> 1-KiB blocks of 8 rows x 64 k (GemmParams::W_blk); one thread per 16 bytes
+__global__ __launch_bounds__(256) void k_w_block(const bf16_t* __restrict__ W, int N, int K, bf16_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int kv = K >> 3;
+    if (t >= (size_t)N * kv) return;
+    const int n = (int)(t / kv), k = (int)(t - (size_t)n * kv) * 8;
+    const uint4 v = *(const uint4*)(W + (size_t)n * K + k);
+    *(uint4*)(out + ((size_t)(n >> 3) * (K >> 6) + (k >> 6)) * 512 + (n & 7) * 64 + (k & 63)) = v;
+}
+int launch_w_block(hipStream_t st, const bf16_t* W, int N, int K, bf16_t* out) {
+    if (K % 64 || N % 8 || N < 8 || K < 64) GYRE_FAIL(-1, "w_block: K must be a multiple of 64 and N of 8");
+    const size_t total = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(k_w_block, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, out);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
+// tests / tuning: scratch where this thread's bare gyre_op_* calls block their weights on the fly
+static thread_local bf16_t* g_dbg_blk_ws = nullptr;
+static thread_local size_t g_dbg_blk_ws_bytes = 0;
+extern "C" int gyre_debug_set_wblk_workspace(void* ws, size_t bytes) { g_dbg_blk_ws = (bf16_t*)ws; g_dbg_blk_ws_bytes = bytes; return 0; }
+static bool w_block_cfg(int cfg) { return (cfg >= 4 && cfg <= 8) || cfg == 12 || (cfg >= 20 && cfg <= 24) || cfg == 32; }
+bool gemm_w_block_wanted(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    if (!p.force_cfg) p.force_cfg = g_force_cfg;
+    if (p.debug & 0x4000000) return false;                    // tuning bit 26: row-major weights everywhere
+    // a request of 8 weight rows spans 16 K bytes: beyond 16 KB it leaves the fast path of the load unit (K > 1024)
+    if (p.K % 64 || p.N % 8 || p.K <= 1024 || p.batch > 1 || p.w_sample_stride || p.out_mode == OUT_BF16_T) return false;
+    if (!p.A2) { p.C1 = p.mode == GEMM_LINEAR ? p.K : p.Cin; p.A2 = p.A; p.lda2 = p.lda; }
+    if (p.mode == GEMM_CONV3 && (p.Cin % 64 || p.C1 % 64)) return false;      // (the conv K order walks whole 64-channel chunks)
+    if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
+    int splits = 1;
+    const int cfg = p.force_cfg ? (p.force_cfg & 0xff) : plan_cfg(p, &splits);
+    return w_block_cfg(cfg);
+}
+
 int launch_gemm(hipStream_t st, const GemmParams& p0) {
     GemmParams p = p0;
     if (!p.force_cfg) p.force_cfg = g_force_cfg;
@@ -1455,6 +1596,12 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             GYRE_FAIL(-6, "gemm: per-sample weights need an unsplit 8-wave tile config whose row blocks do not straddle samples (gemm_per_sample_w_ok)");
     }
     if (p.mode == GEMM_CONV3 && p.wrap && cfg > 3) GYRE_FAIL(-6, "gemm: circular padding (tiling) exists in the 4-wave tile configs only");
+    if (!p.W_blk && g_dbg_blk_ws && gemm_w_block_wanted(p0) && g_dbg_blk_ws_bytes >= (size_t)p.N * p.K * 2) {   // tests / tuning
+        int rc = launch_w_block(st, p.W, p.N, p.K, g_dbg_blk_ws);
+        if (rc) return rc;
+        p.W_blk = g_dbg_blk_ws;
+    }
+    if (p.W_blk && (!w_block_cfg(cfg) || p.K % 64 || p.N % 8 || p.w_sample_stride || (p.mode == GEMM_CONV3 && (p.Cin % 64 || p.C1 % 64)))) p.W_blk = nullptr;
     if (cfg == 30) {
         if (splits > 1 || !gemm_ar_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the A-resident kernel's domain (K = 320 / 640 linear, bf16 row-major output)");
         const void* wpk = p.w_packed;

@@ -118,9 +118,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
         const int n = min(n0 + 8 * (w + NW * i) + prow, p.N - 1) - n0;
-        vo_w[i] = (unsigned)n * (unsigned)p.K * 2u + kvs * 16u;
+        // (GemmParams::W_blk: 1-KiB blocks of 8 rows x 64 k - the request reads one contiguous KiB)
+        vo_w[i] = p.W_blk ? (unsigned)(n >> 3) * (unsigned)(p.K >> 6) * 1024u + (unsigned)(n & 7) * 128u + kvs * 16u
+                          : (unsigned)n * (unsigned)p.K * 2u + kvs * 16u;
     }
-    const char* w_tile = (const char*)(p.W + (size_t)n0 * p.K);
+    const char* w_tile = p.W_blk ? (const char*)(p.W_blk + (size_t)(n0 >> 3) * (p.K >> 6) * 512) : (const char*)(p.W + (size_t)n0 * p.K);
+    const bool wblk = p.W_blk != nullptr;
     // activations
     unsigned vo_a[AP];                   // linear: byte offset of (row, k-slot) from the tile's first row
     int a_sbp[AP], a_y0[AP], a_x0[AP];   // conv: sample base pixel relative to the tile's first sample, window origin
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
             s.srd = first ? srdA : srdA2;
             s.ab = (first ? cA : cA2) + s.soff;
         }
-        s.wb = s.live_w ? w_tile + (size_t)kw * 2 : (const char*)zero;
+        s.wb = s.live_w ? w_tile + (wblk ? (size_t)(kw >> 6) * 1024 : (size_t)kw * 2) : (const char*)zero;
         return s;
     };
     // DMA piece D (compile-time, 0 .. DTOT-1: activations first) of the step described by s, into LDS stage `buf`

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         const int mr = min(m0 + row, p.M - 1);                        // rows past M re-read row M - 1 (never stored)
         src[i] = (const char*)(p.A + (size_t)mr * p.lda) + chunk * 16;
         src2[i] = (const char*)(p.A2 + (size_t)mr * p.lda2) + chunk * 16 - (size_t)k1 * 128;
-        src[2 + i] = (const char*)(p.W + (size_t)min(n0 + row, p.N - 1) * p.K) + chunk * 16;
+        const int nr = min(n0 + row, p.N - 1);
+        src[2 + i] = p.W_blk ? (const char*)(p.W_blk + (size_t)(nr >> 3) * (p.K >> 6) * 512 + (nr & 7) * 64) + chunk * 16
+                             : (const char*)(p.W + (size_t)nr * p.K) + chunk * 16;
     }
+    const unsigned wstep = p.W_blk ? 1024u : 128u;                    // bytes between consecutive K steps of a weight row group
     auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
         const int kk = kt < nk ? kt : 0;                            // past-the-end: re-read step 0 (never consumed)
         const unsigned dst = lds0 + slot * STAGE + (2 * w) * 1024;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             sm_glds(dst + i * 1024, (second ? src2[i] : src[i]) + (size_t)kk * 128);
-            sm_glds(dst + WOFF + i * 1024, src[2 + i] + (size_t)kk * 128);
+            sm_glds(dst + WOFF + i * 1024, src[2 + i] + (size_t)kk * wstep);
         }
     };
     issue(0, 0);

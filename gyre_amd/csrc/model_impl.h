@@ -126,6 +126,18 @@ struct Store {
         if (en.p) { en.version = weights_version; k = kind; }
         return en.p;
     }
+    // blocked copies of the weights the LDS-DMA tile kernels read (GemmParams::W_blk), keyed like the packed copies above
+    std::unordered_map<const void*, WtEntry> blk_cache;
+    bf16_t* blk_lookup(const void* w, size_t bytes, bool* fresh) {
+        WtEntry& en = blk_cache[w];
+        if (!en.p || en.bytes < bytes) {
+            en.p = (bf16_t*)dmalloc(bytes, false);
+            en.bytes = bytes; en.version = 0;
+        }
+        *fresh = en.p && en.version == weights_version;
+        if (en.p) en.version = weights_version;
+        return en.p;
+    }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
     // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
     bf16_t* wt_lookup(const void* w, size_t bytes, bool* fresh) {
@@ -381,10 +393,21 @@ struct Exec {
         p.w_packed = pk;
         return 0;
     }
+    // blocked weight copy for the LDS-DMA tile kernels (GemmParams::W_blk), made per handle on first use (and after any weight change)
+    int prep_blk(GemmParams& p) {
+        if (dry() || !store || p.W_blk || !gemm_w_block_wanted(p)) return 0;
+        bool fresh = false;
+        bf16_t* b = store->blk_lookup(p.W, (size_t)p.N * p.K * 2, &fresh);
+        if (!b) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the blocked weight copy");
+        if (!fresh) TRY(launch_w_block(st, p.W, p.N, p.K, b));
+        p.W_blk = b;
+        return 0;
+    }
     int run_gemm(GemmParams& p) {
         if (!p.samples) p.samples = batch;
         GemmPlan pl = gemm_plan(p);
         TRY(prep_ar(p));
+        TRY(prep_blk(p));
         Tn ws;
         if (pl.ws_bytes) {
             TRY(alloc_raw(ws, pl.ws_bytes));
@@ -622,6 +645,7 @@ struct Exec {
                     }
                     if (!dry()) {
                         TRY(prep_ar(p));
+                        TRY(prep_blk(p));
                         TRY(launch_gemm(st, p));
                     }
                     free(stats);

@@ -261,6 +261,9 @@ int gyre_debug_set_splitk_workspace(void* ws_dev, size_t bytes);
  * GEMM kernel (tile config 30: K = 320 / 640 linear problems; the model handles keep a packed copy per weight).  With it the
  * planner may choose that kernel for single operators; NULL / 0 = off. */
 int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
+/* Tests / tuning only: scratch space (N * K * 2 bytes) where this thread's gyre_op_* calls make the BLOCKED weight copy the LDS-DMA tile
+ * kernels read for K > 1024 (1-KiB blocks of 8 rows x 64 k; the model handles keep one per weight).  NULL / 0 = off: row-major weights. */
+int gyre_debug_set_wblk_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
  * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic (the

@@ -409,6 +409,75 @@ def test_all_tile_configs_sum_in_the_same_order():
         assert torch.equal(y, outs[1]), f"linear: config {cfg} differs bitwise from config 1"
 
 
+@pytest.mark.parametrize("M,K,N,res", [(777, 640, 1280, 1), (4096, 1280, 1280, 1), (300, 320, 320, 0), (1024, 2560, 640, 1), (2048, 5120, 1280, 0),
+                                       (130, 1280, 960, 0)])
+def test_linear_ring_loop_and_blocked_weights_are_bit_identical(M, K, N, res):
+    """Round 5: the nst-deep LDS ring of the 8-wave kernels' linear K loop (counted vmcnt, 2 - 4 stages by tile and grid size;
+    tuning bit 24 = the two-stage loop it replaces, bit 25 = deep ring also where two workgroups per CU would fit) and the BLOCKED
+    weight copy of the LDS-DMA kernels (gyre_debug_set_wblk_workspace; K > 1024) change the order of nothing: same bits for every
+    tile config, with and without split K."""
+    L = _lib.lib()
+    x = to_dev_bf16(bf16_round(randn(M, K, seed=63)))
+    w = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
+    b = repack_bias(randn(N, seed=65))
+    r = to_dev_bf16(bf16_round(randn(M, N, seed=66))) if res else None
+    wsk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    blk = torch.empty(N * K * 2, dtype=torch.uint8, device=DEV)
+    L.gyre_debug_set_splitk_workspace(vp(wsk), wsk.numel())
+    ref = None
+    try:
+        for cfg in (4, 5, 6, 7, 8, 24, 32, 8 | (2 << 8), 5 | (3 << 8)):
+            if (cfg & 0xff) in (4, 5, 8, 24) and N % 320 and not ((cfg & 0xff) == 8 and N % 160 == 0): continue
+            if (cfg & 0xff) in (6, 7) and N % 256: continue
+            if (cfg & 0xff) == 24 and K < 2048: continue
+            if (cfg & 0xff) == 32 and (N % 64 or cfg >> 8): continue
+            if (cfg >> 8) and K < 2048: continue
+            for bits, blocked in ((0x1000000, 0), (0, 0), (0x2000000, 0), (0, 1)):
+                y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                L.gyre_debug_set_wblk_workspace(vp(blk) if blocked else None, blk.numel() if blocked else 0)
+                oc, ob = L.gyre_debug_force_gemm_cfg(cfg), L.gyre_debug_gemm_ablation(bits)
+                try:
+                    _lib.check(L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), vp(r), 0, vp(y)))
+                finally:
+                    L.gyre_debug_force_gemm_cfg(oc); L.gyre_debug_gemm_ablation(ob)
+                if ref is None:
+                    ref = y
+                    report(f"linear ring M{M} K{K} N{N}", y.float().cpu(), F.linear(x.float().cpu(), bf16_round(randn(N, K, seed=64) / math.sqrt(K)), randn(N, seed=65)) + (r.float().cpu() if res else 0), TOL)
+                assert torch.equal(y, ref), f"config {cfg:#x} bits {bits:#x} blocked {blocked} differs"
+    finally:
+        L.gyre_debug_set_wblk_workspace(None, 0)
+        L.gyre_debug_set_splitk_workspace(None, 0)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 24, 192, 640), (1, 16, 1280, 1280), (2, 8, 640, 1280)])
+def test_conv_blocked_weights_are_bit_identical(B, H, Cin, Cout):
+    """3x3 convs read the blocked weight copy too (every conv has K = 9 Cin > 1024): same bits as from the row-major weights for
+    the 8-wave tiles, the pipelined 32x32x16 tile and their split-K forms."""
+    L = _lib.lib()
+    x = to_dev_bf16(nhwc(bf16_round(randn(B, Cin, H, H, seed=60))))
+    w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
+    b = randn(Cout, seed=62).to(DEV)
+    wsk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    blk = torch.empty(Cout * 9 * Cin * 2, dtype=torch.uint8, device=DEV)
+    L.gyre_debug_set_splitk_workspace(vp(wsk), wsk.numel())
+    ref = None
+    try:
+        for cfg in (4, 5, 8, 24, 8 | (4 << 8), 24 | (2 << 8)):
+            for blocked in (0, 1):
+                y = torch.full((B, H, H, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+                L.gyre_debug_set_wblk_workspace(vp(blk) if blocked else None, blk.numel() if blocked else 0)
+                oc = L.gyre_debug_force_gemm_cfg(cfg)
+                try:
+                    _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, H, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
+                finally:
+                    L.gyre_debug_force_gemm_cfg(oc)
+                if ref is None: ref = y
+                assert torch.equal(y, ref), f"config {cfg:#x} blocked {blocked} differs"
+    finally:
+        L.gyre_debug_set_wblk_workspace(None, 0)
+        L.gyre_debug_set_splitk_workspace(None, 0)
+
+
 def test_groupnorm_statistics_do_not_depend_on_batch_size():
     """The per-sample chunking of the two-pass statistics is a function of HW only."""
     L = _lib.lib()

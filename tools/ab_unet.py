@@ -47,8 +47,8 @@ res = {f: ([], []) for f in flags}
 outs = {}
 for r in range(rounds):
     for f in flags:
-        L.gyre_debug_gemm_ablation(f & 0xffffff)
-        L.gyre_debug_force_attn_variant((f >> 24) & 15)      # bits 24-27: attention variant (8 = automatic without the 8-wave workgroups)
+        L.gyre_debug_gemm_ablation(f & 0xfffffff)
+        L.gyre_debug_force_attn_variant((f >> 28) & 15)      # bits 28-31: attention variant (7 = per-tile check in every tile)
         res[f][0].append(timeit(lambda: net(x, t, encoder_hidden_states=ctx).sample, 5))
         res[f][1].append(timeit(lambda: vae.decode(z).sample, 2))
         if r == 0:

@@ -68,6 +68,55 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, size_t wi
     if (acc == 0x12345677u) sink[0] = acc;
 }
 
+// GEMM-operand pattern: a request = 8 matrix rows x 128 B (row stride `rs` bytes), a wave walks along the row (k steps) and then takes
+// the next 8-row block of its workgroup's 32-row panel ... : what the tile kernels' LDS-DMA requests look like to L2.
+template <int INFL, int R>
+__global__ __launch_bounds__(256) void ks(const char* __restrict__ src, size_t window, unsigned rs, int iters, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t wbase = (size_t)(blockIdx.x & 7) * window;
+    constexpr int LPR = 64 / R, BPR = 1024 / R;                 // lanes and bytes per row of one request
+    const unsigned rows = (unsigned)(window / rs), ksteps = rs / BPR;
+    unsigned row0 = (((blockIdx.x >> 3) * 4 + wave) * R) % rows, k = 0;
+    const char* base = src + wbase + (size_t)(lane / LPR) * rs + (lane % LPR) * 16;
+    char* ring = smem + wave * (INFL * 1024);
+    auto next = [&]() { if (++k == ksteps) { k = 0; row0 += R * 4 * 32; if (row0 >= rows) row0 -= rows; } };
+#pragma unroll
+    for (int i = 0; i < INFL; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void*)(base + (size_t)row0 * rs + k * BPR), (lds_void*)(ring + i * 1024), 16, 0, 0);
+        next();
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL - 1) : "memory");
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + (size_t)row0 * rs + k * BPR), (lds_void*)(ring + i * 1024), 16, 0, 0);
+            next();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (((unsigned*)ring)[lane] == 0x12345677u) sink[0] = 1;
+}
+template <int INFL, int R = 8>
+static double run_strided(const char* src, unsigned rs, int wg_per_cu, unsigned* sink) {
+    const int grid = 256 * wg_per_cu;
+    const size_t window = (2ull << 20) / rs * rs;
+    const int iters = (int)((8ull << 20) / (1024 * (size_t)INFL));
+    const size_t lds = 4 * INFL * 1024;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((ks<INFL, R>), dim3(grid), dim3(256), lds, 0, src, window, rs, iters, sink);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return (double)grid * 4 * ((double)iters + 1) * INFL * 1024 / (best * 1e-3) / 1e9 / 256;
+}
+
 struct Res { double gbs_cu, tbs; };
 template <int PATH, int INFL>
 static Res run(const char* src, size_t window, size_t wg_stride, int mode_xcd, int wg_per_cu, size_t bytes_per_wave, unsigned* sink) {
@@ -122,14 +171,34 @@ int main() {
     printf("# l2_bw: 1 KiB wave requests, INFL in flight per wave, 256-thread workgroups, grid = 256 CUs x WG; max clock %d MHz\n", clk / 1000);
     printf("# per-CU numbers assume all 256 CUs busy (grid is a multiple of 256; blockIdx %% 8 = XCD)\n");
     const size_t per_wave_l2 = 8ull << 20, per_wave_mall = 4ull << 20;
+    const bool only_strided = getenv("ONLY_STRIDED") != nullptr;
+    if (!only_strided) {
     sweep<0>("DMA", "L2", buf, 2ull << 20, stride_l2, 1, per_wave_l2, sink);
     sweep<3>("DMAnt", "L2", buf, 2ull << 20, stride_l2, 1, per_wave_l2, sink);
     sweep<1>("REG", "L2", buf, 2ull << 20, stride_l2, 1, per_wave_l2, sink);
     sweep<2>("REGX", "L2", buf, 2ull << 20, stride_l2, 1, per_wave_l2, sink);
     sweep<0>("DMA", "MALL", buf, 96ull << 20, stride_mall, 0, per_wave_mall, sink);
     sweep<2>("REGX", "MALL", buf, 96ull << 20, stride_mall, 0, per_wave_mall, sink);
+    }
+    printf("# strided: a request = 8 rows x 128 B at row stride rs (the GEMM operand pattern), L2-resident 2 MiB per XCD, DMA path\n");
+    for (unsigned rs : {128u, 640u, 1280u, 2560u, 5120u, 1536u, 4096u, 8192u, 2688u}) {
+        printf("DMA   L2   stride %5u B:", rs);
+        for (int wg : {1, 2}) {
+            printf("  waves/CU=%d: infl2 %6.1f  infl4 %6.1f  infl8 %6.1f GB/s/CU |", 4 * wg, run_strided<2>(buf, rs, wg, sink), run_strided<4>(buf, rs, wg, sink), run_strided<8>(buf, rs, wg, sink));
+        }
+        printf("\n"); fflush(stdout);
+    }
+    printf("# strided, fewer rows per request: R rows x (1024 / R) contiguous bytes\n");
+    for (unsigned rs : {2560u, 5120u, 11520u, 23040u}) {
+        printf("DMA   L2   stride %5u B, 4 waves/CU, infl2 / infl4 / infl8:  R=8 %6.1f %6.1f %6.1f | R=4 %6.1f %6.1f %6.1f | R=2 %6.1f %6.1f %6.1f | R=1 %6.1f %6.1f %6.1f GB/s/CU\n", rs,
+               run_strided<2, 8>(buf, rs, 1, sink), run_strided<4, 8>(buf, rs, 1, sink), run_strided<8, 8>(buf, rs, 1, sink),
+               run_strided<2, 4>(buf, rs, 1, sink), run_strided<4, 4>(buf, rs, 1, sink), run_strided<8, 4>(buf, rs, 1, sink),
+               run_strided<2, 2>(buf, rs, 1, sink), run_strided<4, 2>(buf, rs, 1, sink), run_strided<8, 2>(buf, rs, 1, sink),
+               run_strided<2, 1>(buf, rs, 1, sink), run_strided<4, 1>(buf, rs, 1, sink), run_strided<8, 1>(buf, rs, 1, sink));
+        fflush(stdout);
+    }
     // HBM: every wave streams bytes_per_wave = its slice (6 GiB / waves)
-    for (int pass = 0; pass < 1; ++pass) {
+    for (int pass = 0; pass < (only_strided ? 0 : 1); ++pass) {
         for (int wg : {1, 2, 4}) {
             const size_t per_wave = total / (256 * (size_t)wg) / 4 / 65536 * 65536 - 65536;
             printf("%-5s %-4s waves/CU=%2d :", "DMA", "HBM", 4 * wg);
