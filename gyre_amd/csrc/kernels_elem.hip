@@ -217,6 +217,12 @@ int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W
 // Stage 3 (apply): y = act(a*x+b).
 // ------------------------------------------------------------------------------
 #define GN_MAXV 4  // channel vectors per thread: supports C <= 8*256*4
+// 16-byte non-temporal load (streamed-once data: +11 % from HBM in tools/ubench/l2_bw.hip)
+typedef unsigned gn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+    const gn_u32x4 v = __builtin_nontemporal_load((const gn_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __global__ __launch_bounds__(256) void k_gn_partial(GnParams p, int TX, int PY, int pix_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = (float*)smem_raw;  // [PY][C][2]
@@ -413,27 +419,61 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
     const int p0 = chunk * pix_per_chunk;
     const int p1 = min(p.HW, p0 + pix_per_chunk);
     if (ty >= PY) return;
+    // Round 5: GN_U pixels per trip, every 16-byte load of the trip issued before the first use.  The one-pixel loop had ONE load in
+    // flight per lane: 16 waves per CU x 1 KB = 16 KB in flight, i.e. ~2 TB/s at the ~2 us a loaded HBM / Infinity-Cache round trip
+    // takes (measured 2.3 - 2.5 TB/s on the 64x64 maps where tools/ubench/l2_bw.hip streams 6.1 - 7.0); the loads are non-temporal
+    // (x is read exactly once here), the stores are not (the next conv reads y).
+    constexpr int GN_U = 4;
+    auto one = [&](const uint4& raw, size_t gp, int c) {
+        float f[8];
+        unpack8(raw, f);
+        const float4 a0 = *(const float4*)(ab + c), a1 = *(const float4*)(ab + c + 4);
+        const float4 b0 = *(const float4*)(ab + p.C + c), b1 = *(const float4*)(ab + p.C + c + 4);
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = fmaf(a[j], f[j], b[j]);
+            f[j] = p.silu ? silu_f(y) : y;
+        }
+        *(uint4*)(p.y + gp * p.C + c) = pack8(f);
+    };
+    if (CV <= TX) {                                  // one channel vector per lane (C <= 2048): the common case
+        const int c = tx * 8;
+        if (tx >= CV) return;
+        const bool first = c < p.C1;
+        const bf16_t* base = first ? p.x + c : p.x2 + (c - p.C1);
+        const size_t ld = first ? (size_t)p.C1 : (size_t)C2;
+        for (int pix = p0 + ty; pix < p1; pix += GN_U * PY) {
+            uint4 raw[GN_U];
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) {
+                const int px = pix + u * PY;
+                if (px < p1) raw[u] = nt_load16(base + ((size_t)n * p.HW + px) * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) {
+                const int px = pix + u * PY;
+                if (px < p1) one(raw[u], (size_t)n * p.HW + px, c);
+            }
+        }
+        return;
+    }
     for (int pix = p0 + ty; pix < p1; pix += PY) {
         const size_t gp = (size_t)n * p.HW + pix;
+        uint4 raw[GN_MAXV];
 #pragma unroll
         for (int v = 0; v < GN_MAXV; ++v) {
             const int cv = tx + v * TX;
             if (cv < CV) {
                 const int c = cv * 8;
-                const bf16_t* src = c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
-                float f[8];
-                unpack8(*(const uint4*)src, f);
-                const float4 a0 = *(const float4*)(ab + c), a1 = *(const float4*)(ab + c + 4);
-                const float4 b0 = *(const float4*)(ab + p.C + c), b1 = *(const float4*)(ab + p.C + c + 4);
-                const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = fmaf(a[j], f[j], b[j]);
-                    f[j] = p.silu ? silu_f(y) : y;
-                }
-                *(uint4*)(p.y + gp * p.C + c) = pack8(f);
+                raw[v] = nt_load16(c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1));
             }
+        }
+#pragma unroll
+        for (int v = 0; v < GN_MAXV; ++v) {
+            const int cv = tx + v * TX;
+            if (cv < CV) one(raw[v], gp, cv * 8);
         }
     }
 }
