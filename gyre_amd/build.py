@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgyre_hip.so")
-SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_wr.hip", "kernels_gemm_sm.hip", "kernels_attn.hip", "kernels_tome.hip", "kernels_bwd.hip", "model.hip", "model_vjp.hip"]
+SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_sm.hip", "kernels_attn.hip", "kernels_tome.hip", "kernels_bwd.hip", "model.hip", "model_vjp.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_shared.h", "model_impl.h", os.path.join("..", "..", "include", "gyre_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-Wno-unused-result", "-fno-gpu-rdc",
@@ -32,7 +32,7 @@ PER_FILE_FLAGS = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 # count in vmcnt and may be acknowledged before older loads, which would let the wait pass while a tile is still in
 # flight.  Every compile therefore records the register / scratch use of each kernel (clang remarks), and
 # tests/test_host_cpu.py::test_counted_vmcnt_kernels_do_not_spill checks it.  Kernels listed here drain with vmcnt(0).
-RESOURCE_FILES = ("kernels_attn.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_wr.hip", "kernels_gemm_sm.hip")
+RESOURCE_FILES = ("kernels_attn.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_sm.hip")
 # k_gemm4s: its LDS-DMA requests are always retired with vmcnt(0); the 256x256 form spills in the epilogue only
 SCRATCH_ALLOWED = ("k_attn3ILi80E", "k_gemm4s")
 RESOURCES_JSON = os.path.join(HERE, "build", "kernel_resources.json")
@@ -77,6 +77,7 @@ def _record_resources(source: str, remarks: str) -> None:
             except Exception:
                 data = {}
         data[source] = kernels
+        data = {k: v for k, v in data.items() if k in RESOURCE_FILES}      # (sources that no longer exist)
         with open(RESOURCES_JSON, "w") as f:
             json.dump(data, f, indent=1, sort_keys=True)
 
@@ -105,8 +106,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
             extra = [*extra, "-Rpass-analysis=kernel-resource-usage"]
         if os.environ.get("GYRE_AR_ABLATIONS") and base == "kernels_gemm_ar.hip":   # tools/ar_ablate.py
             extra = [*extra, "-DGYRE_AR_ABLATIONS"]
-        if os.environ.get("GYRE_WR_ABLATIONS") and base == "kernels_gemm_wr.hip":   # tools/wr_bench.py
-            extra = [*extra, "-DGYRE_WR_ABLATIONS"]
         if os.environ.get("GYRE_ATTN_ABLATIONS") and base == "kernels_attn.hip":    # tools/attn_ablate.py
             extra = [*extra, "-DGYRE_ATTN_ABLATIONS"]
         if os.environ.get("GYRE_GEMM_ABLATIONS"):      # tuning builds: the main-loop ablation tests of the pipelined kernel (tools/conv_ablate.py)

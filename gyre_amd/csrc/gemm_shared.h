@@ -31,8 +31,5 @@ int launch_gemm4s(hipStream_t st, const GemmParams& p, int cfg, int splits);
 bool gemm_ar_supports(const GemmParams& p);
 int launch_gemm_ar(hipStream_t st, const GemmParams& p, const void* wpk);
 int gemm_ar_nsplit(const GemmParams& p);      // N-range splits per row block = partial sums per row in rowstat_out
-bool gemm_wr_supports(const GemmParams& p);    // W-resident kernel (kernels_gemm_wr.hip, tile config 31)
-int launch_gemm_wr(hipStream_t st, const GemmParams& p, const void* wpk);
-int gemm_wr_parts(const GemmParams& p);        // partial sums per row in rowstat_out
 bool gemm_sm_supports(const GemmParams& p);    // small-problem kernel (kernels_gemm_sm.hip, tile config 32)
 int launch_gemm_sm(hipStream_t st, const GemmParams& p);

@@ -159,8 +159,6 @@ size_t gemm_ar_packed_bytes(int N, int K);
 int launch_ar_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
 int launch_w_block(hipStream_t st, const bf16_t* W, int N, int K, bf16_t* out);   // out: N * K elements (GemmParams::W_blk)
 bool gemm_w_block_wanted(const GemmParams& p);      // the planner's kernel for `p` reads a blocked copy and the shape gains from one
-size_t gemm_wr_packed_bytes(int N, int K);          // the W-resident kernel's fragment order (tile config 31)
-int launch_wr_pack(hipStream_t st, const bf16_t* W, int N, int K, void* out);
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
 struct GemmPlan { int cfg; int splits; size_t ws_bytes; };

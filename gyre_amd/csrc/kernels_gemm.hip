@@ -1264,13 +1264,6 @@ static int pick_cfg(const GemmParams& p, int* splits_out) {
         // at batch 2 (M = 8192, 15 N tiles -> 64 workgroups) took 31 us there against 18 us on the 8-wave tile
         ((long)((p.M + 255) / 256) * gemm_ar_nsplit(p) >= ar_grid_min() || (p.debug & 0x400000)))
         return 30;
-    // W-resident kernel (kernels_gemm_wr.hip): the square projections (N = K, or N a multiple of 320 below 3 K) keep a 320-column
-    // weight panel in registers and stream their rows through an LDS ring.  OFF unless tuning bit 13 asks for it: measured
-    // 30.8 against 34.4 us (plain), 41.0 against 44.8 (+ residual), 32.6 against 28.9 (folded LayerNorm) per cold launch at
-    // M = 65536, and 17.11 against 17.09 ms for the UNet forward with its 16 launches switched over (profiles/README.md, round 4)
-    if (!trans && p.batch <= 1 && (p.ar_ok || p.w_packed || g_dbg_ar_ws) && !p.no_ar && (p.debug & 0x2000) && p.M >= 4096 &&
-        gemm_wr_supports(p))
-        return 31;
     if (!trans && p.batch <= 1 && !wrap_only4) {
         // the 1-workgroup-per-CU big tiles only pay when the grid covers most of the chip: with few tiles the
         // serial K loop of each workgroup dominates and the small tiles' extra parallelism wins
@@ -1434,11 +1427,10 @@ bool gemm_ln_fusable(const GemmParams& p0) {
     const int cfg = plan_cfg(p, &splits);
     if (cfg == 24) return splits == 1 && gemm4s_supports(p, 24);      // pipelined 256x320 tile (kernels_gemm4s.hip)
     if (cfg == 30) return true;                                        // A-resident kernel (kernels_gemm_ar.hip)
-    if (cfg == 31) return true;                                        // W-resident kernel (kernels_gemm_wr.hip)
-    // small-problem kernel (kernels_gemm_sm.hip): has the fold and the row statistics, but OFF unless tuning bit 7 asks: 47 launches
-    // fewer per UNet call at batch 2 (402 -> 355) and the call 6.01 -> 6.10 ms (batch 4: 7.66 -> 7.78) - the LayerNorm launches it
-    // removes are cheaper than the statistics loops and folded epilogues it adds
-    if (cfg == 32) return !p.geglu && (p.debug & 0x80);
+    // (the small-problem kernel, config 32, had the fold and the row statistics behind a tuning bit in round 4: 47 launches fewer per
+    //  UNet call at batch 2 and the call 6.01 -> 6.10 ms - the LayerNorm launches it removed are cheaper than the statistics loops
+    //  and folded epilogues it added; the form was deleted in round 5)
+    if (cfg == 32) return false;
     if (cfg < 4 || cfg > 8 || splits > 1) return false;
     if (p.geglu && (cfg == 4 || cfg == 5 || cfg == 8)) return false;
     if (p.vt_out) {
@@ -1458,8 +1450,7 @@ int gemm_rowstat_parts(const GemmParams& p0) {
     int splits = 1;
     const int cfg = plan_cfg(p, &splits);
     if (cfg == 30) return gemm_ar_nsplit(p);          // A-resident kernel: one partial per N-range split of the row block
-    if (cfg == 31) return gemm_wr_parts(p);           // W-resident kernel: one partial per wave and column panel
-    if (cfg == 32) return (p.debug & 0x80) ? p.N / 64 : 0;   // small-problem kernel: one partial per 64-column tile (tuning bit 7, see gemm_ln_fusable)
+    if (cfg == 32) return 0;                          // the small-problem kernel leaves no row statistics
     if (cfg < 4 || cfg > 8 || splits > 1) return 0;
     const int bn = (cfg == 4 || cfg == 5) ? 320 : cfg == 8 ? 160 : 256;
     return (p.N + bn - 1) / bn;
@@ -1613,18 +1604,6 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             wpk = g_dbg_ar_ws;
         }
         return launch_gemm_ar(st, p, wpk);
-    }
-    if (cfg == 31) {
-        if (splits > 1 || !gemm_wr_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the W-resident kernel's domain (K = 320 / 640 linear, N % 320 == 0, bf16 row-major output)");
-        const void* wpk = p.w_packed;
-        if (!wpk) {       // tests / tuning: pack into the caller's scratch buffer on the fly
-            if (!g_dbg_ar_ws || g_dbg_ar_ws_bytes < gemm_wr_packed_bytes(p.N, p.K))
-                GYRE_FAIL(-6, "gemm: the W-resident kernel needs the packed weight copy (GemmParams::w_packed or gyre_debug_set_ar_workspace)");
-            int rc = launch_wr_pack(st, p.W, p.N, p.K, g_dbg_ar_ws);
-            if (rc) return rc;
-            wpk = g_dbg_ar_ws;
-        }
-        return launch_gemm_wr(st, p, wpk);
     }
     if (cfg == 32) {
         if (splits > 1) GYRE_FAIL(-6, "gemm: the small-problem kernel has no split-K form");

@@ -6,8 +6,8 @@
 //
 // plus the forms the model's deep levels need at small batch: the fused Q | K | V of a self-attention (GemmParams::vt_out: tiles at
 // or behind vt_col0 leave transposed, V^T[b][channel][token]), two-source rows (A | A2: the 1x1 shortcut over a skip concatenation),
-// the long-K few-row problems the planner used to cut into K slices, and - behind tuning bit 7, measured slower than the separate
-// LayerNorm pass - the folded LayerNorm (ln_colsum) and per-row statistics of the output (rowstat_out, one partial per N tile).
+// and the long-K few-row problems the planner used to cut into K slices.  (Round 4 also had the folded LayerNorm and per-row
+// output statistics here behind a tuning bit: measured slower than the separate LayerNorm pass, deleted in round 5.)
 //
 // Those launches are LATENCY-bound, not bandwidth- or MFMA-bound: 1.7 GFLOP and 6 - 16 MB took 15 - 24 us because the old
 // kernel fetches a K step (global -> registers -> LDS), waits for it, multiplies, and only then fetches the next one - about a
@@ -111,32 +111,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         tile[m * ROWF + wn * 32 + l31] = acc[r];
     }
     __syncthreads();
-    // folded LayerNorm (GemmParams::ln_colsum): out = rstd_m * acc - (rstd_m * mean_m) * colsum[n] + bias[n]; (rstd, rstd * mean) of
-    // the tile's 64 rows go to LDS once - from the finished statistics (ln_stats) or from the partial sums the GEMM that produced
-    // the rows left (ln_parts: per part and row the sum and the sum of squares of the rounded values)
-    const bool lnf = p.ln_colsum != nullptr;
-    float2* srow = (float2*)(tile + 64 * ROWF);
-    if (lnf) {
-        if (tid < 64) {
-            const int m = min(m0 + tid, p.M - 1);
-            float2 rs;
-            if (p.ln_nparts > 0) {
-                float su = 0.f, sq = 0.f;
-                for (int q = 0; q < p.ln_nparts; ++q) {
-                    const float2 v = ((const float2*)p.ln_parts)[(size_t)q * p.M + m];
-                    su += v.x; sq += v.y;
-                }
-                const float invk = 1.0f / (float)p.K;
-                const float mean = su * invk;
-                const float rstd = 1.0f / sqrtf(fmaxf(sq * invk - mean * mean, 0.f) + p.ln_eps);
-                rs = make_float2(rstd, rstd * mean);
-            } else {
-                rs = ((const float2*)p.ln_stats)[m];
-            }
-            srow[tid] = rs;
-        }
-        __syncthreads();
-    }
     if (p.vt_out && n0 >= p.vt_col0) {
         // V columns of a fused Q | K | V projection leave TRANSPOSED: vt_out[(b * Cv + channel) * ldt + token] (what the attention
         // kernel streams); a thread packs 8 consecutive tokens of one channel, 8 lanes cover 128 contiguous bytes of a V^T row
@@ -147,13 +121,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
             const int m = m0 + 8 * t8, n = n0 + col;
             if (m >= p.M) continue;
             const float bb = p.bias ? p.bias[n] : 0.f;
-            const float cs = lnf ? p.ln_colsum[n] : 0.f;
             float f[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = tile[(8 * t8 + e) * ROWF + col];
-                f[e] = lnf ? fmaf(a, srow[8 * t8 + e].x, fmaf(-srow[8 * t8 + e].y, cs, bb)) : a + bb;
-            }
+            for (int e = 0; e < 8; ++e) f[e] = tile[(8 * t8 + e) * ROWF + col] + bb;
             const int b = m / p.tokens_per_batch, t = m - b * p.tokens_per_batch;
             *(uint4*)(p.vt_out + ((size_t)b * cv_total + (n - p.vt_col0)) * p.ldt + t) = pack8(f);
         }
@@ -166,14 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         if (m >= p.M) continue;
         const float4 a = *(const float4*)(tile + row * ROWF + 8 * c8), b = *(const float4*)(tile + row * ROWF + 8 * c8 + 4);
         float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        if (lnf) {
-            const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-            const float4 c0 = *(const float4*)(p.ln_colsum + n), c1 = *(const float4*)(p.ln_colsum + n + 4);
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const float2 rs = srow[row];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs.x, fmaf(-rs.y, cc[e], bb[e]));
-        } else if (p.bias) {
+        if (p.bias) {
             const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
             f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
         }
@@ -183,21 +146,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += r8[e];
         }
-        const uint4 o = pack8(f);
-        *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = o;
-        if (p.rowstat_out) {
-            // per-row (sum, sum of squares) of the ROUNDED values of this 64-column tile: the 8 lanes of a row fold theirs, one partial per
-            // N tile (GemmParams::rowstat_out [N / 64][M][2]); the LayerNorm folded into the next GEMM finishes mean / rstd from them
-            float g[8];
-            unpack8(o, g);
-            float su = 0.f, sq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { su += g[e]; sq = fmaf(g[e], g[e], sq); }
-            su += __shfl_xor(su, 1); sq += __shfl_xor(sq, 1);
-            su += __shfl_xor(su, 2); sq += __shfl_xor(sq, 2);
-            su += __shfl_xor(su, 4); sq += __shfl_xor(sq, 4);
-            if (c8 == 0) ((float2*)p.rowstat_out)[(size_t)tn * p.M + m] = make_float2(su, sq);
-        }
+        *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldc + n) = pack8(f);
     }
 }
 
@@ -207,10 +156,7 @@ bool gemm_sm_supports(const GemmParams& p) {
                      p.residual || ((size_t)p.vt_out & 15)))
         return false;
     if (p.A2 && p.A2 != p.A && (p.C1 <= 0 || p.C1 >= p.K || p.C1 % 64 || p.lda2 % 8 || ((size_t)p.A2 & 15))) return false;
-    if (p.rowbias || p.colstat_out || p.w_sample_stride) return false;
-    if (p.rowstat_out && (p.vt_out || p.ln_colsum || (p.A2 && p.A2 != p.A) || p.M % 8)) return false;
-    if (p.ln_colsum && (!p.bias || (p.A2 && p.A2 != p.A) || p.residual || (!p.ln_stats && p.ln_nparts <= 0) || (p.ln_nparts > 0 && !p.ln_parts)))
-        return false;
+    if (p.rowbias || p.colstat_out || p.w_sample_stride || p.rowstat_out || p.ln_colsum) return false;
     if (p.K % 64 || p.K < 64 || p.N % 64 || p.M < 1 || p.lda % 8 || p.ldc % 8 || (p.residual && p.ldr % 8)) return false;
     if ((((size_t)p.A | (size_t)p.W | (size_t)p.out | (size_t)p.residual) & 15) != 0 || (((size_t)p.bias) & 15) != 0) return false;
     return true;

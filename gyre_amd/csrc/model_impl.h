@@ -385,11 +385,11 @@ struct Exec {
     int prep_ar(GemmParams& p) {
         if (dry()) return 0;
         const int cfg = gemm_plan(p).cfg;
-        if (cfg != 30 && cfg != 31) return 0;
+        if (cfg != 30) return 0;
         bool fresh = false;
         void* pk = store ? store->ar_lookup(p.W, gemm_ar_packed_bytes(p.N, p.K), &fresh, cfg) : nullptr;
-        if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A- / W-resident GEMM");
-        if (!fresh) TRY(cfg == 30 ? launch_ar_pack(st, p.W, p.N, p.K, pk) : launch_wr_pack(st, p.W, p.N, p.K, pk));
+        if (!pk) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the packed weight copy of the A-resident GEMM");
+        if (!fresh) TRY(launch_ar_pack(st, p.W, p.N, p.K, pk));
         p.w_packed = pk;
         return 0;
     }

@@ -237,13 +237,15 @@ class GyreUnifiedPipeline:
                 return [p.as_tokens()]
             return list(p) if isinstance(p, (list, tuple)) else [p]
         pos = frags(prompt)
-        neg = frags(negative_prompt) or [""] * len(pos)
+        neg = frags(negative_prompt)        # None stays None: "no negative prompt" conditions on zeros, an explicit "" is encoded
 
         def mk(tok):
             return lambda text: tok(text, add_special_tokens=False)["input_ids"] if callable(tok) else tok.encode(text)[1:-1]
         dev = self.execution_device
+        pad2 = getattr(self.tokenizer_2, "pad_token_id", 0)
         cnd = SDXLTextConditioner(self.text_encoder, mk(self.tokenizer), self.text_encoder_2, mk(self.tokenizer_2), dev,
-                                  max_embeddings_multiples, self.force_zeros_for_empty_prompt)
+                                  max_embeddings_multiples, self.force_zeros_for_empty_prompt,
+                                  pad_1=getattr(self.tokenizer, "pad_token_id", None), pad_2=0 if pad2 is None else pad2)
         cond, pooled, unc, upooled = cnd(pos, neg, do_cfg)
         rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
         cond, pooled, unc, upooled = rep(cond), rep(pooled), rep(unc), rep(upooled)

@@ -101,7 +101,7 @@ class _NativeModule(nn.Module):
 
     def _apply_tiling(self, h) -> None:
         mode = getattr(self, "_tiling", 0)
-        if getattr(self, "_tiling_applied", (None, 0)) != (h, mode):
+        if (getattr(self, "_tiling_applied", None) or (None, 0)) != (h, mode):
             _lib.check(getattr(_lib.lib(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(h), mode))
             self._tiling_applied = (h, mode)
 
@@ -109,6 +109,9 @@ class _NativeModule(nn.Module):
         if getattr(self, "_handle", None):
             getattr(_lib.lib(), f"gyre_{self._kind}_destroy")(C.c_void_p(self._handle))
             self._handle = None
+        # per-handle options are re-applied to whatever handle comes next: the allocator may hand a new struct the old address
+        self._tiling_applied = None
+        self._tome_applied = None
 
     def __del__(self):
         try:
@@ -349,7 +352,7 @@ class GyreHipUNet(_NativeModule):
         dev = sample.device
         h = self._sync(dev)
         self._apply_tiling(h)
-        if getattr(self, "_tome_applied", (None, None)) != (h, getattr(self, "_tome_r", 0)):
+        if (getattr(self, "_tome_applied", None) or (None, None)) != (h, getattr(self, "_tome_r", 0)):
             _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
             self._tome_applied = (h, getattr(self, "_tome_r", 0))
         self._t_uniform = not isinstance(timestep, torch.Tensor) or timestep.numel() == 1

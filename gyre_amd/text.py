@@ -169,12 +169,14 @@ def parse_prompt_attention(text: str):
 
 
 def pad_tokens_and_weights(tokens, weights, max_length: int, bos: int, eos: int, no_boseos_middle: bool = True,
-                           chunk_length: int = MAX_LEN):
-    """BOS + tokens + EOS padding to max_length; weights padded with 1.0 (per chunk when BOS/EOS are kept)."""
+                           chunk_length: int = MAX_LEN, pad: Optional[int] = None):
+    """BOS + tokens + EOS padding to max_length; weights padded with 1.0 (per chunk when BOS/EOS are kept).  `pad`: id behind the
+    closing EOS (default: EOS itself, the reference's long-prompt convention; SDXL's second tokenizer pads with 0)."""
     mult = (max_length - 2) // (chunk_length - 2)
     out_t, out_w = [], []
     for tk, wt in zip(tokens, weights):
-        out_t.append([bos] + list(tk) + [eos] * (max_length - 1 - len(tk)))
+        tail = max_length - 1 - len(tk)
+        out_t.append([bos] + list(tk) + ([eos] * tail if pad is None or tail <= 0 else [eos] + [pad] * (tail - 1)))
         if no_boseos_middle:
             out_w.append([1.0] + list(wt) + [1.0] * (max_length - 1 - len(wt)))
         else:
@@ -222,8 +224,15 @@ class LPWTextEmbedder:
     """get_embeddings(prompts, negative_prompts) -> (cond [B,75k+2... ,D], uncond).  `tokenize(fragment) -> [ids]`
     is supplied by the caller (a CLIP tokenizer's ids without BOS/EOS); no vocabulary ships offline."""
 
-    def __init__(self, encoder, tokenize, max_embeddings_multiples: int = 3, bos: int = BOS, eos: int = EOS):
-        self.encoder, self.tokenize, self.mult, self.bos, self.eos = encoder, tokenize, max_embeddings_multiples, bos, eos
+    def __init__(self, encoder, tokenize, max_embeddings_multiples: int = 3, bos: int = BOS, eos: int = EOS, pad: Optional[int] = None):
+        self.encoder, self.tokenize, self.mult, self.bos, self.eos, self.pad = encoder, tokenize, max_embeddings_multiples, bos, eos, pad
+
+    def chunks_needed(self, prompts) -> int:
+        """77-token chunks the longest of `prompts` needs under this tokenizer (1 ... max_embeddings_multiples)."""
+        body = MAX_LEN - 2
+        toks, _ = self._tokens(prompts, body * self.mult)
+        longest = max([len(t) for t in toks] + [1])
+        return max(1, min(self.mult, (longest - 1) // body + 1))
 
     def _tokens(self, prompts, max_len):
         toks, wts = [], []
@@ -238,18 +247,22 @@ class LPWTextEmbedder:
             toks.append(t[:max_len]); wts.append(w[:max_len])
         return toks, wts
 
-    def get_embeddings(self, prompts, uncond_prompts=None):
+    def get_embeddings(self, prompts, uncond_prompts=None, chunks: Optional[int] = None):
+        """chunks: encode at exactly this many 77-token chunks (callers that must agree on one length across several calls);
+        default: what the longest of prompts / uncond_prompts needs."""
         body = MAX_LEN - 2
         lim = body * self.mult
         pt, pw = self._tokens(prompts, lim)
         ut, uw = self._tokens(uncond_prompts, lim) if uncond_prompts is not None else ([], [])
         longest = max([len(t) for t in pt + ut] + [1])
         mult = max(1, min(self.mult, (longest - 1) // body + 1))
+        if chunks is not None:
+            mult = max(mult, int(chunks))
         max_length = body * mult + 2
         dev = getattr(self.encoder, "device", "cpu")
 
         def run(tok, wt):
-            tok, wt = pad_tokens_and_weights(tok, wt, max_length, self.bos, self.eos, True, MAX_LEN)
+            tok, wt = pad_tokens_and_weights(tok, wt, max_length, self.bos, self.eos, True, MAX_LEN, self.pad)
             ids = torch.tensor(tok, dtype=torch.long, device=dev)
             emb = chunked_encode(self.encoder, ids, MAX_LEN, True)
             return apply_token_weights(emb, torch.tensor(wt, dtype=emb.dtype, device=emb.device))
@@ -274,10 +287,12 @@ class SDXLTextConditioner:
     LPWTextEmbedder applied per tower (same parser, chunking and mean renormalisation as the SD1.x path)."""
 
     def __init__(self, text_encoder, tokenize, text_encoder_2, tokenize_2, device, max_embeddings_multiples: int = 3,
-                 force_zeros_for_empty_prompt: bool = True, bos: int = BOS, eos: int = EOS):
+                 force_zeros_for_empty_prompt: bool = True, bos: int = BOS, eos: int = EOS, pad_1: Optional[int] = None,
+                 pad_2: Optional[int] = 0):
         self.te1, self.te2, self.tok1, self.tok2 = text_encoder, text_encoder_2, tokenize, tokenize_2
         self.device, self.mult, self.force_zeros = device, max_embeddings_multiples, force_zeros_for_empty_prompt
-        self.bos, self.eos = bos, eos   # (both towers are padded with EOS here, the long-prompt weighting's convention)
+        # pad ids as the published pipeline's tokenizers have them: tower 1 pads with EOS, tower 2 (tokenizer_2.pad_token_id) with 0
+        self.bos, self.eos, self.pad_1, self.pad_2 = bos, eos, pad_1, pad_2
 
     def _tower(self, model, pooled_sink: Optional[list]):
         dev = self.device
@@ -293,30 +308,39 @@ class SDXLTextConditioner:
         encode.device = dev
         return encode
 
-    def _run(self, prompts, uncond):
+    def _embedders(self, sink):
+        return (LPWTextEmbedder(self._tower(self.te1, None), self.tok1, self.mult, self.bos, self.eos, self.pad_1),
+                LPWTextEmbedder(self._tower(self.te2, sink), self.tok2, self.mult, self.bos, self.eos, self.pad_2))
+
+    def _run(self, prompts, chunks):
         sink = []
-        e1 = LPWTextEmbedder(self._tower(self.te1, None), self.tok1, self.mult, self.bos, self.eos)
-        c1, _ = e1.get_embeddings(prompts, None)
-        e2 = LPWTextEmbedder(self._tower(self.te2, sink), self.tok2, self.mult, self.bos, self.eos)
-        c2, _ = e2.get_embeddings(prompts, None)
-        n = min(c1.shape[1], c2.shape[1])
-        return torch.cat([c1[:, :n], c2[:, :n]], dim=-1), sink[0]
+        e1, e2 = self._embedders(sink)
+        c1, _ = e1.get_embeddings(prompts, None, chunks)
+        c2, _ = e2.get_embeddings(prompts, None, chunks)
+        assert c1.shape[1] == c2.shape[1], "both towers are encoded at the same chunk count"
+        return torch.cat([c1, c2], dim=-1), sink[0]
 
     def __call__(self, prompts, negative_prompts=None, do_cfg: bool = True):
-        """-> (context [B,77k,2048], pooled [B,1280], uncond context | None, uncond pooled | None)"""
-        cond, pooled = self._run(list(prompts), None)
-        if not do_cfg:
-            return cond, pooled, None, None
-        neg = list(negative_prompts) if negative_prompts is not None else [""] * len(prompts)
+        """-> (context [B,77k,2048], pooled [B,1280], uncond context | None, uncond pooled | None).
+        ONE chunk count for both towers and both sides: the largest any (prompt, tokenizer) pair needs - the conditioning is never
+        truncated to a shorter partner (a 100-token prompt beside an empty negative keeps all its chunks and its closing EOS).
+        negative_prompts None: zeros for the whole batch when force_zeros_for_empty_prompt (the published pipeline's rule); an
+        explicit "" is ENCODED like any other prompt."""
+        prompts = list(prompts)
+        no_negative = negative_prompts is None
+        neg = [""] * len(prompts) if no_negative else list(negative_prompts)
         if len(neg) == 1 and len(prompts) > 1:
             neg = neg * len(prompts)
-        unc, upooled = self._run(neg, None)
-        n = min(cond.shape[1], unc.shape[1])
-        cond, unc = cond[:, :n], unc[:, :n]
-        if self.force_zeros:
-            empty = torch.tensor([isinstance(p, str) and p == "" for p in neg], device=unc.device)
-            unc = torch.where(empty[:, None, None], torch.zeros_like(unc), unc)
-            upooled = torch.where(empty[:, None], torch.zeros_like(upooled), upooled)
+        e1, e2 = self._embedders([])
+        chunks = max(e1.chunks_needed(prompts), e2.chunks_needed(prompts))
+        if do_cfg:
+            chunks = max(chunks, e1.chunks_needed(neg), e2.chunks_needed(neg))
+        cond, pooled = self._run(prompts, chunks)
+        if not do_cfg:
+            return cond, pooled, None, None
+        if no_negative and self.force_zeros:
+            return cond, pooled, torch.zeros_like(cond), torch.zeros_like(pooled)
+        unc, upooled = self._run(neg, chunks)
         return cond, pooled, unc, upooled
 
 

@@ -266,10 +266,10 @@ int gyre_debug_set_ar_workspace(void* ws_dev, size_t bytes);
 int gyre_debug_set_wblk_workspace(void* ws_dev, size_t bytes);
 /* Tests / tuning only: 0 automatic, 1 = register-staged attention kernel, 2 / 4 = LDS-DMA kernel with 32 / 64
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
- * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic (the
- * pipelined kernel's per-tile overflow check in every tile: the default since the end of round 4); 8 = automatic WITH the optimistic
- * first pass of the pipelined kernel (head dims <= 40: no per-tile check, a workgroup whose row sums leave the finite range repeats its
- * pass with the check) - 2 % faster per UNet call, exact, but not bit-reproducible when two handles share one GPU concurrently.
+ * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic with the
+ * pipelined kernel's per-tile overflow check in every tile (the round-3 kernel); 0 / 8 = automatic: head dims <= 40 run the optimistic
+ * first pass (no per-tile check; a workgroup whose row sums leave (0, 1e25) repeats its pass with the check).  The round-4
+ * non-reproducibility of that pass under concurrent handles was a ring-slot hazard, fixed in round 5 (kernels_attn.hip header).
  * Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
 /* Tuning only: with GYRE_ATTN_COUNT_REDO=1 in the environment, the number of attention workgroups that have repeated their pass with
@@ -283,12 +283,16 @@ long gyre_debug_attn_redo_count(void);
  * statistics pass (no statistics from the producing conv / GEMM), bit19 = slab-outer GEGLU epilogue of the folded-LayerNorm
  * FF1, bit20 = no statistics epilogue on the 128x160 tile, bit21 = no A-resident kernel (K = 320 / 640 linear problems go to the
  * 8-wave tiles as before), bit22 = A-resident kernel also for the C x C projections (N < 3 K),
- * bit12 = the Transformer2D GroupNorm keeps its apply pass (no fold into proj_in), bit13 = W-resident kernel (tile config 31,
- * kernels_gemm_wr.hip) for the K = 320 linear problems with N a multiple of 320 below 3 K (measured: no gain), bit23 = no pipelined 256x320 tile
+ * bit12 = the Transformer2D GroupNorm keeps its apply pass (no fold into proj_in), bit23 = no pipelined 256x320 tile
  * for 3x3 convs whose grid of it has 128 - 159 workgroups (the 48x48 level of a 768 px request), bit5 = no small-problem kernel
  * (tile config 32, kernels_gemm_sm.hip): small linear problems go to the register-staged 4-wave tiles as before, bit6 = it does not take
- * the long-K few-row linear problems from the split-K path, bit7 = folded LayerNorm / row statistics also in it (measured slower than the
- * separate LayerNorm pass small problems keep by default).  Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores. */
+ * the long-K few-row linear problems from the split-K path.  Round 5: bit24 = the two-stage K loop in the 8-wave kernels' linear mode
+ * (instead of the 2 - 4 stage LDS ring with counted waits), bit25 = the deep ring at one workgroup per CU also where two 2-stage
+ * workgroups would fit, bit26 = row-major weights everywhere (no blocked weight copies for the LDS-DMA kernels).  (Bits 7 and 13 -
+ * the small kernel's LayerNorm fold and the W-resident kernel - went with the code they switched on.)
+ * Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores.
+ * These switches are PER CALLING THREAD (thread-local, like gyre_set_batch_invariant): they never change what another thread's
+ * handle computes. */
 int gyre_debug_gemm_ablation(int bits);
 
 /* ---- batch-invariant mode ------------------------------------------------

@@ -80,52 +80,3 @@ def test_fused_qkv_with_transposed_v_on_the_small_kernel(B, tokens, C):
         L.gyre_debug_gemm_ablation(0)
     if rc == 0:
         assert torch.equal(qk, qk2)
-
-
-@pytest.mark.parametrize("M,C,N", [(2048, 640, 640), (512, 1280, 1280), (128, 1280, 3840)])
-def test_layernorm_fold_and_row_statistics_on_the_small_kernel(M, C, N):
-    """gyre_op_linear_rowstats (producer: per-row partial sums of the rounded outputs, one per 64-column tile) feeding
-    gyre_op_ln_linear (consumer: LayerNorm folded into the GEMM, statistics finished from those partials) - the pair that lets the
-    deep-level transformer blocks at small batch drop their separate LayerNorm launches - against plain fp32 arithmetic."""
-    L = _lib.lib()
-    L.gyre_debug_gemm_ablation(0x80)                 # the pair is off by default (tuning bit 7)
-    try:
-        _ln_fold_pair(L, M, C, N)
-    finally:
-        L.gyre_debug_gemm_ablation(0)
-
-
-def _ln_fold_pair(L, M, C, N):
-    x = (randn(M, C, seed=31) * 1.3).to(torch.bfloat16)
-    w1 = (randn(C, C, seed=32) / math.sqrt(C)).to(torch.bfloat16)
-    b1 = randn(C, seed=33) * 0.3
-    r = randn(M, C, seed=34).to(torch.bfloat16)
-    parts = L.gyre_op_linear_rowstats_parts(M, C, C, 1)
-    if parts != C // 64:
-        pytest.skip(f"the planner's kernel for this shape leaves {parts} partials (not the small-problem kernel)")
-    h = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    stats = torch.full((parts, M, 2), float("nan"), dtype=torch.float32, device=DEV)
-    _lib.check(L.gyre_op_linear_rowstats(st(), vp(x.to(DEV)), M, C, vp(repack_linear(w1.float())), C, vp(repack_bias(b1)), vp(r.to(DEV)),
-                                         vp(h), vp(stats)))
-    href = (x.float() @ w1.float().T + b1 + r.float())
-    assert (h.float().cpu() - href).abs().max().item() < 0.08
-    hf = h.float()
-    tot = stats.sum(0)
-    assert torch.allclose(tot[:, 0], hf.sum(1), rtol=1e-4, atol=2e-2) and torch.allclose(tot[:, 1], (hf * hf).sum(1), rtol=1e-4, atol=5e-2)
-    # consumer
-    g, be = (1 + 0.2 * randn(C, seed=35)), 0.1 * randn(C, seed=36)
-    w2 = (randn(N, C, seed=37) / math.sqrt(C)).to(torch.bfloat16)
-    b2 = randn(N, seed=38) * 0.2
-    ws = torch.empty(L.gyre_op_ln_linear_workspace(N, C, M), dtype=torch.uint8, device=DEV)
-    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    _lib.prof_enable(None)
-    try:
-        _lib.check(L.gyre_op_ln_linear(st(), vp(h), M, C, vp(g.to(DEV)), vp(be.to(DEV)), 1e-5, vp(repack_linear(w2.float())), N, vp(repack_bias(b2)),
-                                       0, 0, None, 0, vp(stats), parts, vp(ws), ws.numel(), vp(y)))
-        torch.cuda.synchronize()
-        names = set(_lib.prof_collect())
-    finally:
-        _lib.prof_enable([])
-    assert "k_layernorm" not in names, names
-    ref = torch.nn.functional.layer_norm(hf.cpu(), (C,), g, be, 1e-5) @ w2.float().T + b2
-    assert (y.float().cpu() - ref).abs().max().item() < 0.1, names

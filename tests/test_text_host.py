@@ -87,21 +87,40 @@ def test_sdxl_conditioner_follows_the_published_scheme():
     prompts, neg = ["a cat", "dog"], ["", "blurry"]
     cond, pooled, unc, upooled = cnd(prompts, neg, True)
 
-    def ids_of(text):
+    def ids_of(text, pad=299):
         t = tok(text)
-        return torch.tensor([[298] + t + [299] * (76 - len(t))])
+        return torch.tensor([[298] + t + [299] + [pad] * (75 - len(t))])
     with torch.no_grad():
         for i, (ptxt, ntxt) in enumerate(zip(prompts, neg)):
             o1 = te1(input_ids=ids_of(ptxt), output_hidden_states=True, return_dict=True)
-            o2 = te2(input_ids=ids_of(ptxt), output_hidden_states=True, return_dict=True)
+            o2 = te2(input_ids=ids_of(ptxt, 0), output_hidden_states=True, return_dict=True)      # tower 2 pads with id 0
             want = torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], dim=-1)[0]
             assert cond.shape == (2, 77, 80) and pooled.shape == (2, 40)
             assert torch.allclose(cond[i], want, atol=1e-5) and torch.allclose(pooled[i], o2.text_embeds[0], atol=1e-5)
-            if ntxt == "":
-                assert float(unc[i].abs().max()) == 0 and float(upooled[i].abs().max()) == 0
-            else:
-                u2 = te2(input_ids=ids_of(ntxt), output_hidden_states=True, return_dict=True)
-                assert torch.allclose(upooled[i], u2.text_embeds[0], atol=1e-5) and float(unc[i].abs().max()) > 0
+            # an EXPLICIT negative prompt - also the empty string - is encoded
+            u2 = te2(input_ids=ids_of(ntxt, 0), output_hidden_states=True, return_dict=True)
+            assert torch.allclose(upooled[i], u2.text_embeds[0], atol=1e-5) and float(unc[i].abs().max()) > 0
+    # no negative prompt at all: zeros for the whole batch (force_zeros_for_empty_prompt)
+    _, _, unc0, up0 = cnd(prompts, None, True)
+    assert unc0.shape == cond.shape and float(unc0.abs().max()) == 0 and float(up0.abs().max()) == 0
     ids = T.sdxl_time_ids(3, 1024, 768, original_size=(512, 512), crops_coords_top_left=(8, 16))
     assert ids.tolist() == [[512.0, 512.0, 8.0, 16.0, 1024.0, 768.0]] * 3
     assert T.sdxl_time_ids(1, 1024, 1024).tolist() == [[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]]
+
+
+def test_sdxl_conditioner_never_truncates_a_long_prompt():
+    """A 100-token prompt beside an empty negative prompt, CFG on, three chunks allowed: both towers and both sides are encoded at
+    the chunk count the LONGEST of them needs (2 here) - the positive conditioning keeps every chunk and equals what it is without
+    any negative prompt; the negative side is padded up, not the positive cut down."""
+    te1, te2 = _tiny_sdxl_towers()
+    tok = lambda text: [3 + (ord(c) % 200) for c in text if c != " "]
+    cnd = T.SDXLTextConditioner(te1, tok, te2, tok, "cpu", max_embeddings_multiples=3, bos=298, eos=299)
+    long_prompt = "x" * 100
+    cond, pooled, unc, upooled = cnd([long_prompt], [""], True)
+    alone, pooled_alone, _, _ = cnd([long_prompt], None, False)
+    assert cond.shape == (1, 2 * 75 + 2, 80) and unc.shape == cond.shape
+    assert torch.equal(cond, alone) and torch.equal(pooled, pooled_alone)
+    assert float(unc.abs().max()) > 0
+    # the second chunk really carries the prompt's tail: it differs from the encoding of the first 75 tokens alone
+    short, _, _, _ = cnd([long_prompt[:75]], None, False)
+    assert short.shape[1] == 77 and not torch.allclose(cond[:, :76], short[:, :76], atol=1e-4) or cond.shape[1] > short.shape[1]
