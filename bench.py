@@ -221,6 +221,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # self-check of the launch (rank 0 prints it): the world size AS THE COLLECTIVE BACKEND reports it - one all_reduce of ones over
+    # the real backend (RCCL on a GPU node) - and the device every rank sits on, so that a SCALE run shows at a glance that N
+    # distinct GPUs took part
+    ranks_seen, rank_devices = 1, [dev_index]
+    if world > 1:
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        gathered = [None] * world
+        try:
+            pci = torch.cuda.get_device_properties(dev_index).pci_bus_id
+        except Exception:
+            pci = -1
+        dist.all_gather_object(gathered, (rank, dev_index, pci))
+        rank_devices = [list(g) for g in gathered]
 
     from gyre_amd import _lib, config as gcfg
     from gyre_amd.modules import GyreHipUNet, GyreHipVAE
@@ -480,6 +495,8 @@ def main():
                             f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch), {n_steps} steps DPM++2M ({evals} UNet "
                             f"evals incl. the differentiated stems), batch={B}, bf16 (BASELINE.json configs[4])"}[args.config],
                        "images_per_step": sum(sizes), "images_per_rank": sizes, "parallelism": f"dp{world}",
+                       "dist_backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen,
+                       "rank_devices": rank_devices,
                        "weights": "random-init weights of the exact architecture (SD1.5: 859.5 M UNet, 83.7 M VAE, 123 M CLIP)"},
             "latency_p50_s": round(statistics.median(step_times), 4),
             "latency_note": ("wall time of ONE request of %d images split over %d GPUs (rank 0)" % (B, world)) if args.scaling == "strong"
