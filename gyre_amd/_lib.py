@@ -12,7 +12,7 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first: maps torch's libamdhip64.so.7, which our .so then shares)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgyre_hip.so")
+LIB_PATH = os.environ.get("GYRE_HIP_LIB") or os.path.join(_HERE, "libgyre_hip.so")    # (GYRE_HIP_LIB: tuning / reproducer builds of the same ABI)
 MAX_LEVELS = 8
 
 F32, BF16, F16 = 0, 1, 2

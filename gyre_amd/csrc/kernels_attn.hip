@@ -606,7 +606,12 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
     constexpr int RAW = KBYTES + VR * 128;
     constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
     constexpr int NW = STAGE / 4096;
+#ifdef GYRE_ATTN_R4_RING      // reproducer build (tools/attn_race_repro.sh): the round-4 ring - the refill targets the slot the previous
+                              // step read and nothing waits for that step's fragment reads - under the round-5 code otherwise
+    constexpr bool LDSX = false;
+#else
     constexpr bool LDSX = attn3_spare_slot(D, PD);      // two workgroups per CU still fit with one more slot
+#endif
     constexpr int NS = PD + (LDSX ? 3 : 2);
     constexpr int KG = 64 * KVEC, VG = VR * 8;
     constexpr bool ONES = (D % 16 != 0);
@@ -871,7 +876,9 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
         constexpr bool HASNEXT = decltype(has_next)::value;
         if (HASNEXT) {
             // tile t+1 landed (tiles t+2 .. t+PD may still be in flight); ring discipline: see the kernel's header
+#ifndef GYRE_ATTN_R4_RING
             if constexpr (!LDSX) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             if constexpr (ABL & 6) {}
             else if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NW) : "memory");
@@ -1086,7 +1093,11 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     // ring = 72 KB, TWO workgroups per CU instead of the one its 4 x 24 KB ring allowed (the 32x32 level of SD1.x)
     constexpr int PD = D > 64 ? 1 : 2;
     static_assert(STAGE == attn3_stage_bytes(D), "ring stage size");
+#ifdef GYRE_ATTN_R4_RING
+    const size_t lds = (size_t)(PD + 2) * STAGE;
+#else
     const size_t lds = (size_t)(PD + (attn3_spare_slot(D, PD) ? 3 : 2)) * STAGE;
+#endif
     const bf16_t* zero = attn_zero_page();
     if (!zero) GYRE_FAIL(-5, "attention: cannot allocate the zero page");
     auto kern = k_attn3<D, PD, QI>;

@@ -481,6 +481,11 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
     const int nk = min(nk_all, kc0 + nk_per);
     const int fr = lane & 15, fq = lane >> 4;
     // one 64-deep K step out of ring slot `slot`
+    // (Round 5: issuing all fragment reads of a k32 sub-step - or of the whole step - ahead of its MFMAs, pinned with sched_barrier, was
+    //  measured on the 128x160 tile: -1 us of 23 at one workgroup per CU, but 159 registers instead of 97 - the tile's two workgroups
+    //  per CU are gone (M = 16384: 70 -> 85 us) and the 128x320 tile spills.  With the loads switched off the 20-step loop still
+    //  takes 11 us against 5.3 us of MFMA issue: 14 ds_read_b128 per wave and step = 112 KB per CU and step is 437 cycles of the
+    //  LDS array beside 640 of MFMA - the 32x80 wave tile reads twice the bytes per FLOP the 64x160 one does.  tools/floor_probe.py)
     auto k_step = [&](int slot) {
         const uint4* a = (const uint4*)(smem_raw + slot * STAGE_BYTES);
         const uint4* b = a + BM * 8;
