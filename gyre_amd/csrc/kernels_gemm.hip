@@ -35,6 +35,13 @@
 // Non-transposed epilogue shared by the 4-wave and 8-wave kernels.  Operands were issued swapped, so a
 // lane holds, per 16x16 fragment, output row m = m_base + 16*i + fr and 4 consecutive columns
 // n = n_base + 16*j + 4*fq + {0..3}: bias / time-embedding bias / residual / store are 8- or 16-byte accesses.
+// 16-byte non-temporal load (data read exactly once: residual rows)
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load_u4(const void* p) {
+    const gemm_u32x4 v = __builtin_nontemporal_load((const gemm_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[MI][NI], int m_base, int n_base,
                                               int fr, int fq) {
@@ -135,21 +142,25 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
     float cs_s[CSN], cs_q[CSN];
 #pragma unroll
     for (int c = 0; c < CSN; ++c) { cs_s[c] = 0.f; cs_q[c] = 0.f; }
+    // residual vectors of slab i: requested one slab AHEAD (round 5) - slab 0's in front of the loop, slab i+1's right after slab i's
+    // accumulators have gone to LDS (those registers are free from there on, so the extra 4 * NV registers cost nothing at the
+    // peak: requesting them earlier - tried in round 2 - spilled in the 256x320 kernel).  With one request per slab the epilogue of
+    // the 256x320 tile was four dependent memory round trips per wave, 40 KB in flight per CU: 23 of the 48 us of a cold
+    // M = 65536, K = N = 320 launch with residual (tools/ring_bench.py ablation bit 2).
+    auto res_load = [&](int i, uint4 (&dst)[NV]) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int v = lane + 64 * q;
+            const int row = v / vec_per_row, c8 = v - row * vec_per_row;
+            const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
+            dst[q] = make_uint4(0, 0, 0, 0);
+            if (v < 16 * vec_per_row && mm < p.M && nn < n_out) dst[q] = nt_load_u4(p.residual + (size_t)mm * p.ldr + nn);
+        }
+    };
+    uint4 rres[NV], rnext[NV];
+    if (p.residual) res_load(0, rres);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        // the residual vectors of this slab are requested first, so their latency runs under the LDS round trip
-        // (requesting slab i+1's as well was tried: spills in the 256x320 kernel, slower)
-        uint4 rres[NV];
-        if (p.residual) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const int v = lane + 64 * q;
-                const int row = v / vec_per_row, c8 = v - row * vec_per_row;
-                const int mm = m_base + i * 16 + row, nn = n_out_base + c8 * 8;
-                rres[q] = make_uint4(0, 0, 0, 0);
-                if (v < 16 * vec_per_row && mm < p.M && nn < n_out) rres[q] = *(const uint4*)(p.residual + (size_t)mm * p.ldr + nn);
-            }
-        }
         const int m = m_base + i * 16 + fr;
         const float* rbias = (p.rowbias && m < p.M) ? p.rowbias + (size_t)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
         if (gg) {
@@ -188,6 +199,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 *(float4*)(my + fr * rowf + j * 16 + 4 * fq) = o;
             }
         }
+        if (p.residual && i + 1 < MI) res_load(i + 1, rnext);
         // read the slab back row-wise: 8 consecutive channels (32 B fp32) per lane -> one 16-byte store
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -243,6 +255,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& p, f32x4_
                 rs_row[i * 16 + lane] = make_float2(su, sq);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if (p.residual && i + 1 < MI) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) rres[q] = rnext[q];
         }
     }
     if (CS) {
