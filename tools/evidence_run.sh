@@ -1,10 +1,10 @@
 set -x
-O=$GRAFT_REPO_ROOT/gpurun_out/r04u
+O=$GRAFT_REPO_ROOT/gpurun_out/r05u
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 python bench.py > $O/bench.json 2> $O/bench.err
-bash tools/profile_bench.sh r04 > $O/profile.log 2>&1
+bash tools/profile_bench.sh r05 > $O/profile.log 2>&1
 cd $GRAFT_REPO_ROOT
 MD=$O/unet_layers.md python tools/unet_layers.py > $O/unet_layers.txt 2>&1
 B=2 MD=$O/unet_layers_b2.md python tools/unet_layers.py > $O/unet_layers_b2.txt 2>&1
