@@ -753,6 +753,12 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
 }
 
 // out = bf16( sum_s slab[s] + bias + rowbias + residual ), fixed summation order (deterministic)
+// (Round 5: the same reduction INSIDE the GEMM launch - per-tile arrival counters, agent-scope release by every K slice, the last
+//  arriver adds the slabs row-wise in slice order and finishes the tile: cdna_hip_programming.md guideline 16, counter form - was
+//  built for k_gemm8 and the pipelined 256x320 tile, bit-identical to this kernel (12 repetitions under concurrent traffic per
+//  config), and measured: UNet call 17.50 -> 18.37 ms at batch 16 (338 -> 306 launches), 5.89 -> 6.60 ms at batch 2.  A tile's last
+//  arriver reads splits x 328 KB alone (64 workgroups finish what this kernel spreads over 256 CUs) behind a write-back of
+//  freshly dirtied L2 lines; the guide prices the form as worth it up to "a few tens of KB" per tile.  Removed again.)
 __global__ __launch_bounds__(256) void k_splitk_reduce(GemmParams p, int splits) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 consecutive columns
     const int nq = p.N / 4;
