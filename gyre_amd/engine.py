@@ -334,8 +334,8 @@ class GyreUnifiedPipeline:
             raise NotImplementedError("tiling together with CLIP guidance (the native input-gradient sweep has no circular convolutions)")
         if scheduler_noise_type not in (None, "normal"):
             raise NotImplementedError("only normal sampler noise is implemented (brownian needs torchsde)")
-        if latents is not None:
-            raise NotImplementedError("caller-supplied start latents")
+        # `latents`: accepted and IGNORED, as in the reference - UnifiedPipeline.__call__ declares and documents the keyword
+        # (unified_pipeline.py:1749,1807-1810) but never reads it; start latents always come from the per-image generators
         if self.scheduler is None:
             raise ValueError("no scheduler injected")
         n_prompts = len(prompt.prompts) if hasattr(prompt, "prompts") else (len(prompt) if isinstance(prompt, (list, tuple)) else 1)
