@@ -248,7 +248,10 @@ def test_engine_routes_an_sdxl_unet_through_both_text_towers():
     assert images.shape == (2, 3, 128, 128) and bool(torch.isfinite(images).all()) and nsfw == [False, False]
     cond, unc, added, uadded = eng._embed_sdxl(prompt, negative, 2, 1, True, 3, 128, 128)
     assert cond.shape == (2, 77, 64) and added["text_embeds"].shape == (2, 32) and added["time_ids"].tolist() == [[128.0, 128.0, 0.0, 0.0, 128.0, 128.0]] * 2
-    assert float(unc[0].abs().max()) == 0 and float(uadded["text_embeds"][0].abs().max()) == 0 and float(unc[1].abs().max()) > 0
+    # explicit negative prompts - also the empty string - are ENCODED; no negative prompt at all conditions on zeros (published rule)
+    assert float(unc[0].abs().max()) > 0 and float(unc[1].abs().max()) > 0
+    _, unc_none, _, uadded_none = eng._embed_sdxl(prompt, None, 2, 1, True, 3, 128, 128)
+    assert float(unc_none.abs().max()) == 0 and float(uadded_none["text_embeds"].abs().max()) == 0
     cpu = lambda d: {k: v.float().cpu() for k, v in d.items()}
     ref = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")(
         seeds=seeds, text_embeddings=cond.float().cpu(), uncond_embeddings=unc.float().cpu(), height=128, width=128,

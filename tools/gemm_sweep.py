@@ -38,6 +38,8 @@ if os.environ.get("GYRE_GEMM_DUMP") is None:
     dev = "cuda:0"
     ws = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     L.gyre_debug_set_splitk_workspace(C.c_void_p(ws.data_ptr()), ws.numel())
+    wblk = torch.empty(256 << 20, dtype=torch.uint8, device=dev)      # blocked weight copies, as the model handles keep them (round 5)
+    L.gyre_debug_set_wblk_workspace(C.c_void_p(wblk.data_ptr()), wblk.numel())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device=dev).manual_seed(0)
 
