@@ -26,7 +26,7 @@ into PNG artifacts.  What this class has to honour is therefore exactly what the
   * no-op memory knobs (attention / VAE slicing, xformers): 288 GB of HBM3E, the whole batch stays resident.
 
 Features outside the native hot path raise NotImplementedError (-> gRPC UNIMPLEMENTED, services/exception_to_grpc.py):
-depth / hint images (ControlNet, T2I), textual-inversion token embeddings, brownian sampler noise.  CLIP guidance
+depth / hint images (ControlNet, T2I), textual-inversion token embeddings.  CLIP guidance
 is implemented (gyre_amd/clipguided.py over the native input-gradient sweeps).  The safety checker stays the host module the
 manager loaded; it is RUN exactly as the reference runs it (``_safety_check``), never skipped silently.
 """
@@ -332,8 +332,8 @@ class GyreUnifiedPipeline:
             raise ValueError(f"tiling must be True, False, 'x', 'y' or 'xy', got {tiling!r}")
         if tiling and clip_guidance_scale:
             raise NotImplementedError("tiling together with CLIP guidance (the native input-gradient sweep has no circular convolutions)")
-        if scheduler_noise_type not in (None, "normal"):
-            raise NotImplementedError("only normal sampler noise is implemented (brownian needs torchsde)")
+        if scheduler_noise_type not in (None, "normal", "brownian"):
+            raise ValueError(f"scheduler_noise_type must be 'normal' or 'brownian', got {scheduler_noise_type!r}")
         # `latents`: accepted and IGNORED, as in the reference - UnifiedPipeline.__call__ declares and documents the keyword
         # (unified_pipeline.py:1749,1807-1810) but never reads it; start latents always come from the per-image generators
         if self.scheduler is None:
@@ -406,7 +406,7 @@ class GyreUnifiedPipeline:
                        hires_fix=hires_fix, hires_oos_fraction=hires_oos_fraction,
                        prediction_type=prediction_type or "epsilon", churn=churn, churn_tmin=churn_tmin or 0.0,
                        churn_tmax=churn_tmax if churn_tmax is not None else float("inf"), sigma_min=sigma_min,
-                       sigma_max=sigma_max, **clip_kw)
+                       sigma_max=sigma_max, scheduler_noise_type=scheduler_noise_type or "normal", **clip_kw)
         if sdxl:
             request.update(added_cond=added, uncond_added_cond=uadded)
         if len(self._shard_devices) > 1 and B > 1 and not clip_kw and not lora and not self._tome and not tiling:

@@ -317,7 +317,7 @@ class GyrePipeline:
                  outmask_image: Optional[Tensor] = None, added_cond: Optional[dict] = None,
                  uncond_added_cond: Optional[dict] = None, prediction_type: str = "epsilon",
                  churn: Optional[float] = None, churn_tmin: float = 0.0, churn_tmax: float = float("inf"),
-                 sigma_min: Optional[float] = None, sigma_max: Optional[float] = None,
+                 sigma_min: Optional[float] = None, sigma_max: Optional[float] = None, scheduler_noise_type: str = "normal",
                  clip_guidance_scale: Optional[float] = None, clip_guidance_base: Optional[str] = None,
                  clip_gradient_length: Optional[int] = None, clip_gradient_threshold: Optional[float] = None,
                  clip_gradient_maxloss: Optional[float] = None, vae_cutouts: Optional[int] = None,
@@ -469,7 +469,8 @@ class GyrePipeline:
         sched.set_eps_unets([l.eps_unet for l in leaves])
         sched.set_timesteps(num_inference_steps, strength=strength if image is not None else None,
                             config=S.SchedulerConfig(eta=eta, karras_rho=karras_rho, churn=churn, churn_tmin=churn_tmin,
-                                                     churn_tmax=churn_tmax, sigma_min=sigma_min, sigma_max=sigma_max),
+                                                     churn_tmax=churn_tmax, sigma_min=sigma_min, sigma_max=sigma_max,
+                                                     noise_type=scheduler_noise_type or "normal"),
                             prediction_type=prediction_type)
 
         def _blend(mask, u, orig, nxt):

@@ -47,6 +47,80 @@ def batched_randn(shape: Sequence[int], generators: List[torch.Generator], devic
     return out.to(device)
 
 
+class BrownianTreeNoiseSampler:
+    """`scheduler_noise_type = "brownian"` (reference common_scheduler.py:596-606: one seed per image drawn from that image's
+    generator, then [3P k_diffusion.sampling.BrownianTreeNoiseSampler] over [3P torchsde.BrownianTree]): the noise of a step
+    (sigma -> sigma_next) is the increment of ONE Brownian path per image over [sigma, sigma_next], divided by
+    sqrt(|sigma_next - sigma|) - unit variance per step, but all steps (and all step counts) read the same path, which is
+    what makes SDE samplers converge as the step count grows.
+
+    PARITY UNPINNED: torchsde is not in the reference tree nor in this image, so the values of its tree (its entropy
+    spawning and bridge order) cannot be reproduced; the CONSTRUCTION is the published one - a virtual Brownian tree
+    (Li et al. 2020, "Scalable gradients for stochastic differential equations", the algorithm torchsde's BrownianTree
+    implements): W(t0) = 0, W(t1) ~ N(0, t1 - t0), and W at a query point by repeated bisection with the Brownian bridge
+    W(mid) = (W(a) + W(b)) / 2 + sqrt((b - a) / 4) * z(node), where z(node) is drawn from a counter-based stream keyed
+    by (image seed, tree level, node index) - so any query order gives the same path - down to intervals of
+    (t1 - t0) / 2^DEPTH, inside which the path is interpolated linearly.  Per-image trees: the noise of an image does not
+    depend on what else is in the batch (the property the reference gets from per-image generators)."""
+
+    DEPTH = 20
+
+    def __init__(self, x: Tensor, sigma_min, sigma_max, seed: Sequence[int], transform=lambda v: v):
+        self.transform = transform
+        t0, t1 = float(transform(torch.as_tensor(sigma_min))), float(transform(torch.as_tensor(sigma_max)))
+        self.t0, self.t1 = (t0, t1) if t0 <= t1 else (t1, t0)
+        if x.shape[0] % len(seed) != 0:
+            raise ValueError(f"shape[0] ({x.shape[0]}) needs to be a multiple of len(seed) ({len(seed)})")
+        self.seeds = [int(s) for s in seed] * (x.shape[0] // len(seed))
+        self.shape, self.device, self.dtype = tuple(x.shape[1:]), x.device, x.dtype
+        self._gen = torch.Generator(device="cpu")
+        self._w_cache = {}                                       # (image, node) -> W at that node: steps share their end points
+
+    def _z(self, img: int, level: int, index: int) -> Tensor:
+        # counter-based: splitmix64 of (seed, level, index) -> the seed of a one-shot generator
+        v = (self.seeds[img] + 0x9E3779B97F4A7C15 * (level + 1) + 0xBF58476D1CE4E5B9 * (index + 1)) & 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        v = ((v ^ (v >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        v ^= v >> 31
+        self._gen.manual_seed(v & 0x7FFFFFFFFFFFFFFF)
+        return torch.randn(self.shape, generator=self._gen, dtype=torch.float32)
+
+    def _w(self, img: int, t: float) -> Tensor:
+        """W(t) - W(t0) of image `img` (fp32, host)."""
+        span = self.t1 - self.t0
+        u = min(max((t - self.t0) / span, 0.0), 1.0) if span > 0 else 0.0
+        key = (img, round(u * (1 << 40)))
+        hit = self._w_cache.get(key)
+        if hit is not None:
+            return hit
+        wa = torch.zeros(self.shape, dtype=torch.float32)
+        wb = self._z(img, 0, 0) * span ** 0.5
+        a, b, index = 0.0, 1.0, 0
+        for level in range(1, self.DEPTH + 1):
+            if u == a or u == b:
+                break
+            mid = 0.5 * (a + b)
+            wm = 0.5 * (wa + wb) + self._z(img, level, index) * (0.25 * (b - a) * span) ** 0.5
+            if u < mid:
+                b, wb, index = mid, wm, 2 * index
+            else:
+                a, wa, index = mid, wm, 2 * index + 1
+        w = wa if u == a else wb if u == b else wa + (wb - wa) * ((u - a) / (b - a))
+        if len(self._w_cache) > 4 * len(self.seeds):
+            self._w_cache.clear()
+        self._w_cache[key] = w
+        return w
+
+    def __call__(self, sigma, sigma_next) -> Tensor:
+        ta, tb = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
+        if ta == tb:
+            raise ValueError("BrownianTreeNoiseSampler: empty interval")
+        lo, hi = (ta, tb) if ta < tb else (tb, ta)
+        scale = 1.0 / abs(tb - ta) ** 0.5                        # the sign of the interval cancels as in k-diffusion's sort()
+        out = torch.stack([(self._w(i, hi) - self._w(i, lo)) * scale for i in range(len(self.seeds))])
+        return out.to(self.device, self.dtype)
+
+
 # ------------------------------------------------------------------------------
 # classifier-free guidance wrappers
 # ------------------------------------------------------------------------------
@@ -362,6 +436,7 @@ class SchedulerConfig:
     sigma_min: Optional[float] = None
     sigma_max: Optional[float] = None
     karras_rho: Optional[float] = None
+    noise_type: str = "normal"                                   # "normal" | "brownian" (common_scheduler.py:26,94)
 
 
 class KDiffusionScheduler:
@@ -421,6 +496,9 @@ class KDiffusionScheduler:
             t = torch.linspace(t_max, t_min, num_inference_steps)
             self.sigmas = torch.cat([s.t_to_sigma(t), torch.zeros(1)])
         self.eta = config.eta
+        if config.noise_type not in ("normal", "brownian"):
+            raise ValueError(f"noise_type {config.noise_type!r}")
+        self.noise_type = config.noise_type
         self.churn, self.churn_tmin, self.churn_tmax = config.churn, config.churn_tmin, config.churn_tmax
         self.num_inference_steps = num_inference_steps
         if strength is not None:
@@ -453,7 +531,13 @@ class KDiffusionScheduler:
             kwargs["eta"] = self.eta
         if getattr(self, "churn", None):
             kwargs.update(s_churn=self.churn, s_tmin=self.churn_tmin, s_tmax=self.churn_tmax)
-        kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
+        if getattr(self, "noise_type", "normal") == "brownian":
+            # common_scheduler.py:563-564,597-606: one seed per image from that image's generator; the tree spans the sigmas
+            # of THIS loop (after the img2img start offset)
+            seeds = [int(torch.randint(0, 2 ** 63 - 1, [], generator=g, device=g.device).item()) for g in self.generators]
+            kwargs["noise_sampler"] = BrownianTreeNoiseSampler(latents, sigmas[sigmas > 0].min(), sigmas.max(), seed=seeds)
+        else:
+            kwargs["noise_sampler"] = lambda _, __: batched_randn(latents.shape, self.generators, self.device, self.dtype)
         model = self.unet
         if k_wrap is not None or k_model is not None:
             u_off = self.start_offset / len(self.sigmas)

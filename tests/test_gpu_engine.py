@@ -190,8 +190,15 @@ def test_engine_cancellation_between_unet_calls(tiny_engine):
     eng.progress_bar = None
     images, _ = eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3))
     assert bool(torch.isfinite(images).all())
-    with pytest.raises(NotImplementedError):              # -> gRPC UNIMPLEMENTED (services/generate.py:1162-1173)
-        eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, scheduler_noise_type="brownian"))
+    # scheduler_noise_type = "brownian" (common_scheduler.py:596-606): served (parity unpinned, torchsde absent) - an ancestral
+    # sampler then reads ONE Brownian path per image: reproducible per seed, different from the normal-noise run
+    bkw = lambda: wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3,
+                                 scheduler_noise_type="brownian")
+    brown, _ = eng(**bkw())
+    brown2, _ = eng(**bkw())
+    assert bool(torch.isfinite(brown).all()) and torch.equal(brown, brown2) and not torch.equal(brown, images)
+    with pytest.raises(ValueError):
+        eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, scheduler_noise_type="pink"))
     # `latents`: declared and documented by the reference's __call__ (unified_pipeline.py:1749,1807-1810) but never read - same here
     kw = wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3)
     kw["latents"] = torch.full((1, 4, 16, 16), 7.0)

@@ -583,6 +583,50 @@ def test_churn_semantics_and_pipeline_options(tiny):
     assert torch.equal(churned, pipe(churn=2.0, **kw))
 
 
+def test_brownian_noise_sampler_properties_and_pipeline_option(tiny):
+    """scheduler_noise_type = "brownian" (reference common_scheduler.py:596-606 over k-diffusion's BrownianTreeNoiseSampler).
+    Parity is UNPINNED (torchsde absent); what is checked is what the construction has to guarantee: one path per image -
+    increments add up whatever the query order, unit variance per step, independent steps, per-image seeds (batch
+    composition does not matter), sign convention of a reversed interval - and that the request option reaches the sampler."""
+    x = torch.zeros(2, 4, 32, 32)
+    mk = lambda seeds=(11, 22), xx=x: PS.BrownianTreeNoiseSampler(xx, 0.03, 14.6, seed=list(seeds))
+    ns = mk()
+    a, b, c = 9.0, 4.0, 1.5
+    span = lambda lo, hi: abs(hi - lo) ** 0.5
+    w_ab, w_bc, w_ac = ns(a, b) * span(a, b), ns(b, c) * span(b, c), ns(a, c) * span(a, c)
+    assert torch.allclose(w_ab + w_bc, w_ac, atol=1e-5)                       # one path: increments add up
+    ns2 = mk()
+    assert torch.equal(ns2(b, c) * span(b, c), w_bc) and torch.equal(ns2(a, b) * span(a, b), w_ab)    # query order is irrelevant
+    assert torch.equal(ns(c, b), ns(b, c))                                    # k-diffusion's sort(): the signs cancel
+    assert torch.equal(mk((22,), x[:1])(a, b)[0], ns(a, b)[1])                # per-image trees
+    assert not torch.equal(ns(a, b)[0], ns(a, b)[1])
+    # unit variance, zero mean, independent disjoint steps
+    big = PS.BrownianTreeNoiseSampler(torch.zeros(1, 4, 128, 128), 0.03, 14.6, seed=[5])
+    steps = [big(s0, s1).flatten() for s0, s1 in ((14.6, 10.0), (10.0, 3.0), (3.0, 2.9), (0.5, 0.03))]
+    for z in steps:
+        assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1) < 0.03
+    for i in range(len(steps)):
+        for j in range(i + 1, len(steps)):
+            assert abs(float((steps[i] * steps[j]).mean())) < 0.02
+    # a step far below the leaf width of the tree still has the right variance on average over the path it interpolates
+    with pytest.raises(ValueError):
+        ns(a, a)
+    # the request option
+    ucfg, vcfg, usd, vsd, text, unc = tiny
+    pipe = GyrePipeline(OracleUNet(usd, ucfg), OracleVAE(vsd, vcfg), device="cpu")
+    kw = dict(text_embeddings=text[:1], uncond_embeddings=unc[:1], height=128, width=128, num_inference_steps=4,
+              sampler="euler_a", output_type="latent")
+    normal = pipe(seeds=[1], **kw)
+    brown = pipe(seeds=[1], scheduler_noise_type="brownian", **kw)
+    assert bool(torch.isfinite(brown).all()) and not torch.allclose(brown, normal)
+    assert torch.equal(brown, pipe(seeds=[1], scheduler_noise_type="brownian", **kw))
+    pair = pipe(seeds=[7, 1], scheduler_noise_type="brownian", **dict(kw, text_embeddings=text[:1].repeat(2, 1, 1),
+                                                                      uncond_embeddings=unc[:1].repeat(2, 1, 1)))
+    assert torch.allclose(pair[1], brown[0], rtol=1e-4, atol=1e-3)            # batch composition does not matter (fp32 CPU UNet noise)
+    with pytest.raises(ValueError):
+        pipe(seeds=[1], scheduler_noise_type="pink", **kw)
+
+
 def test_pipeline_grafted_inpaint_tree(tiny):
     """Grafted inpaint (reference unified_pipeline.py:2071-2100 + unet/graft.py:16-56): a masked request with an
     inpaint_unet builds Graft(runway leaf on inpaint_unet, enhanced-inpaint leaf on unet); only the root runs before the
