@@ -354,7 +354,12 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnParams p, size_t total_vec) 
 // k_gn_finalize's arithmetic for its sample (same order -> same bits: nchunks partial sums per group from L2, then a = rstd * gamma,
 // b = beta - mean * a per channel into LDS) and then streams its pixels.  One launch and one dependent round trip per GroupNorm
 // less; the extra reads are 2 KB per thread block against 40 KB of pixels.
-__global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY, int pix_per_chunk) {
+// GN_U = rows a lane requests per trip: 12 (all of a lane's rows at the UNet's map sizes: one memory round trip per launch; VAE-sized
+// tensors in many waves of workgroups: decode of 8 images 31.85 -> 31.0 ms), except where ONE resident wave of workgroups moves tens
+// of MB - then every workgroup reads at the same time and writes at the same time, and trips of 4 (reads of the next trip under the
+// writes of this one) are faster: 64x64x320 at batch 16, 84 MB, 19.6 us against 22.8.
+template <int GN_U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gn_apply_fin(GnParams p, int TX, int PY, int pix_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ab = (float*)smem_raw;                 // [2][C]
     float* red_s = ab + 2 * p.C;                  // [256]
@@ -363,12 +368,61 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
     float* rstd_s = mean_s + 256;                 // [256]
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int cpg = p.C / p.G;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int CV = p.C / 8, C2 = p.C - p.C1;
+    const int p0 = chunk * pix_per_chunk;
+    const int p1 = min(p.HW, p0 + pix_per_chunk);
+    // Round 5: every global request of the kernel that does not depend on the statistics is ISSUED BEFORE the statistics prologue -
+    // the lane's pixels (up to GN_U 16-byte rows: all of them at the UNet's map sizes) and gamma / beta - so the prologue's dependent
+    // chain (partials -> mean / rstd -> a, b: three barriers) runs under the one memory round trip the kernel cannot avoid instead
+    // of in front of it (before: partials, then gamma / beta, then the pixels four at a time = 3 + ceil(pixels / 4) round trips
+    // per launch, 15 - 18 us for maps a 6 TB/s stream would move in 4 - 7).  Loads are non-temporal (x is read exactly once
+    // here), the stores are not (the next conv reads y).  Same arithmetic, same order: bit-identical.
+    constexpr int GN_GB = 4;
+    const bool fast = CV <= TX;                      // one channel vector per lane (C <= 2048): the common case
+    const bool lane_on = ty < PY && tx < CV;
+    const int c_lane = tx * 8;
+    const bool first_src = c_lane < p.C1;
+    const bf16_t* base = first_src ? p.x + c_lane : p.x2 + (c_lane - p.C1);
+    const size_t ld = first_src ? (size_t)p.C1 : (size_t)C2;
+    uint4 raw[GN_U];
+    if (fast && lane_on) {
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const int px = p0 + ty + u * PY;
+            if (px < p1) raw[u] = nt_load16(base + ((size_t)n * p.HW + px) * ld);
+        }
+    }
+    float gm[GN_GB], bt[GN_GB];                      // gamma / beta of channels threadIdx.x + k * 256, k < GN_GB (C <= 1024 in registers)
+#pragma unroll
+    for (int k = 0; k < GN_GB; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < p.C) { gm[k] = p.gamma[c]; bt[k] = p.beta[c]; }
+    }
     {
         const float cnt = (float)p.HW * (float)cpg;
         int parts = 256 / p.G;
         if (parts < 1) parts = 1;
         const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
         float a = 0.f, b = 0.f;
+        // partial sums are fetched FOUR at a time and added in the original order (one load, one wait, one add per partial made
+        // the prologue a chain of 2 - 8 dependent L2 round trips)
+        auto gather = [&](const float2* src, int chunks, int row, int u0, int u1) {     // rows part, part + parts, ...; columns [u0, u1)
+            const int nu = u1 - u0;
+            if (nu <= 0 || part >= chunks) return;
+            const int total = ((chunks - part + parts - 1) / parts) * nu;
+            for (int i0 = 0; i0 < total; i0 += 4) {
+                float2 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j;
+                    if (i < total) t[j] = src[(size_t)(part + (i / nu) * parts) * row + u0 + i % nu];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < total) { a += t[j].x; b += t[j].y; }
+            }
+        };
         if (p.cs_x) {
             // statistics left by the PRODUCERS of x / x2 (GemmParams::colstat_out): per source [B][chunks][C_src / unit][2].
             // Group g = channels [g * cpg, (g + 1) * cpg) of the concatenation: its units below C1 come from x, the others
@@ -376,25 +430,15 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
             const int unit = p.cs_unit, c_lo = g * cpg, c_hi = c_lo + cpg;
             if (part < parts) {
                 const int nu1 = p.C1 / unit;
-                const int u0 = min(c_lo, p.C1) / unit, u1 = min(c_hi, p.C1) / unit;
-                if (u1 > u0)
-                    for (int ch = part; ch < p.cs_x_chunks; ch += parts) {
-                        const float2* src = (const float2*)p.cs_x + ((size_t)n * p.cs_x_chunks + ch) * nu1;
-                        for (int u = u0; u < u1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
-                    }
+                gather((const float2*)p.cs_x + (size_t)n * p.cs_x_chunks * nu1, p.cs_x_chunks, nu1,
+                       min(c_lo, p.C1) / unit, min(c_hi, p.C1) / unit);
                 const int nu2 = (p.C - p.C1) / unit;
-                const int v0 = (max(c_lo, p.C1) - p.C1) / unit, v1 = (max(c_hi, p.C1) - p.C1) / unit;
-                if (v1 > v0)
-                    for (int ch = part; ch < p.cs_x2_chunks; ch += parts) {
-                        const float2* src = (const float2*)p.cs_x2 + ((size_t)n * p.cs_x2_chunks + ch) * nu2;
-                        for (int u = v0; u < v1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
-                    }
+                if (nu2 > 0)
+                    gather((const float2*)p.cs_x2 + (size_t)n * p.cs_x2_chunks * nu2, p.cs_x2_chunks, nu2,
+                           (max(c_lo, p.C1) - p.C1) / unit, (max(c_hi, p.C1) - p.C1) / unit);
             }
         } else if (part < parts)
-            for (int ch = part; ch < p.nchunks; ch += parts) {
-                const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
-                a += src[0]; b += src[1];
-            }
+            gather((const float2*)p.partial + (size_t)n * p.nchunks * p.G, p.nchunks, p.G, g, g + 1);
         red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
         __syncthreads();
         if (threadIdx.x < p.G) {
@@ -406,7 +450,17 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
             rstd_s[g] = rsqrtf(var + p.eps);
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < GN_GB; ++k) {
+            const int c = threadIdx.x + k * 256;
+            if (c < p.C) {
+                const int gg = c / cpg;
+                const float aa = rstd_s[gg] * gm[k];
+                ab[c] = aa;
+                ab[p.C + c] = bt[k] - mean_s[gg] * aa;
+            }
+        }
+        for (int c = threadIdx.x + GN_GB * 256; c < p.C; c += blockDim.x) {
             const int gg = c / cpg;
             const float aa = rstd_s[gg] * p.gamma[c];
             ab[c] = aa;
@@ -414,19 +468,10 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
         }
         __syncthreads();
     }
-    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int CV = p.C / 8, C2 = p.C - p.C1;
-    const int p0 = chunk * pix_per_chunk;
-    const int p1 = min(p.HW, p0 + pix_per_chunk);
     if (ty >= PY) return;
-    // Round 5: GN_U pixels per trip, every 16-byte load of the trip issued before the first use.  The one-pixel loop had ONE load in
-    // flight per lane: 16 waves per CU x 1 KB = 16 KB in flight, i.e. ~2 TB/s at the ~2 us a loaded HBM / Infinity-Cache round trip
-    // takes (measured 2.3 - 2.5 TB/s on the 64x64 maps where tools/ubench/l2_bw.hip streams 6.1 - 7.0); the loads are non-temporal
-    // (x is read exactly once here), the stores are not (the next conv reads y).
-    constexpr int GN_U = 4;
-    auto one = [&](const uint4& raw, size_t gp, int c) {
+    auto one = [&](const uint4& rw, size_t gp, int c) {
         float f[8];
-        unpack8(raw, f);
+        unpack8(rw, f);
         const float4 a0 = *(const float4*)(ab + c), a1 = *(const float4*)(ab + c + 4);
         const float4 b0 = *(const float4*)(ab + p.C + c), b1 = *(const float4*)(ab + p.C + c + 4);
         const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -438,14 +483,14 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
         }
         *(uint4*)(p.y + gp * p.C + c) = pack8(f);
     };
-    if (CV <= TX) {                                  // one channel vector per lane (C <= 2048): the common case
-        const int c = tx * 8;
+    if (fast) {
         if (tx >= CV) return;
-        const bool first = c < p.C1;
-        const bf16_t* base = first ? p.x + c : p.x2 + (c - p.C1);
-        const size_t ld = first ? (size_t)p.C1 : (size_t)C2;
-        for (int pix = p0 + ty; pix < p1; pix += GN_U * PY) {
-            uint4 raw[GN_U];
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {             // the trip requested above
+            const int px = p0 + ty + u * PY;
+            if (px < p1) one(raw[u], (size_t)n * p.HW + px, c_lane);
+        }
+        for (int pix = p0 + ty + GN_U * PY; pix < p1; pix += GN_U * PY) {      // VAE-sized chunks: further trips
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) {
                 const int px = pix + u * PY;
@@ -454,26 +499,26 @@ __global__ __launch_bounds__(256) void k_gn_apply_fin(GnParams p, int TX, int PY
 #pragma unroll
             for (int u = 0; u < GN_U; ++u) {
                 const int px = pix + u * PY;
-                if (px < p1) one(raw[u], (size_t)n * p.HW + px, c);
+                if (px < p1) one(raw[u], (size_t)n * p.HW + px, c_lane);
             }
         }
         return;
     }
     for (int pix = p0 + ty; pix < p1; pix += PY) {
         const size_t gp = (size_t)n * p.HW + pix;
-        uint4 raw[GN_MAXV];
+        uint4 rawv[GN_MAXV];
 #pragma unroll
         for (int v = 0; v < GN_MAXV; ++v) {
             const int cv = tx + v * TX;
             if (cv < CV) {
                 const int c = cv * 8;
-                raw[v] = nt_load16(c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1));
+                rawv[v] = nt_load16(c < p.C1 ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1));
             }
         }
 #pragma unroll
         for (int v = 0; v < GN_MAXV; ++v) {
             const int cv = tx + v * TX;
-            if (cv < CV) one(raw[v], gp, cv * 8);
+            if (cv < CV) one(rawv[v], gp, cv * 8);
         }
     }
 }
@@ -535,7 +580,11 @@ int launch_groupnorm_apply(hipStream_t st, const GnParams& p) {
         int PY = 256 / TX; if (PY < 1) PY = 1;
         const int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
         const size_t lds = ((size_t)2 * p.C + 4 * 256) * sizeof(float);
-        hipLaunchKernelGGL(k_gn_apply_fin, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+        // one resident wave of workgroups (<= 4 per CU) over tens of MB: every workgroup is in the same phase at the same time
+        if ((size_t)p.nchunks * p.B <= 1024 && (size_t)p.B * p.HW * p.C * 2 >= ((size_t)32 << 20))
+            hipLaunchKernelGGL(k_gn_apply_fin<4>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+        else
+            hipLaunchKernelGGL(k_gn_apply_fin<12>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
         GYRE_LAUNCH_CHECK();
         return 0;
     }
@@ -570,18 +619,28 @@ __global__ __launch_bounds__(256) void k_gn_fold(GnParams p, const bf16_t* __res
         if (parts < 1) parts = 1;
         const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
         float a = 0.f, b = 0.f;
-        if (p.cs_x) {
-            const int unit = p.cs_unit, nu = p.C / unit, u0 = g * cpg / unit, u1 = (g + 1) * cpg / unit;
-            if (part < parts)
-                for (int ch = part; ch < p.cs_x_chunks; ch += parts) {
-                    const float2* src = (const float2*)p.cs_x + ((size_t)n * p.cs_x_chunks + ch) * nu;
-                    for (int u = u0; u < u1; ++u) { const float2 t = src[u]; a += t.x; b += t.y; }
+        auto gather = [&](const float2* src, int chunks, int row, int u0, int u1) {     // as in k_gn_apply_fin: four partials in flight
+            const int nu = u1 - u0;
+            if (nu <= 0 || part >= chunks) return;
+            const int total = ((chunks - part + parts - 1) / parts) * nu;
+            for (int i0 = 0; i0 < total; i0 += 4) {
+                float2 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + j;
+                    if (i < total) t[j] = src[(size_t)(part + (i / nu) * parts) * row + u0 + i % nu];
                 }
-        } else if (part < parts)
-            for (int ch = part; ch < p.nchunks; ch += parts) {
-                const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
-                a += src[0]; b += src[1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < total) { a += t[j].x; b += t[j].y; }
             }
+        };
+        if (p.cs_x) {
+            const int unit = p.cs_unit, nu = p.C / unit;
+            if (part < parts)
+                gather((const float2*)p.cs_x + (size_t)n * p.cs_x_chunks * nu, p.cs_x_chunks, nu, g * cpg / unit, (g + 1) * cpg / unit);
+        } else if (part < parts)
+            gather((const float2*)p.partial + (size_t)n * p.nchunks * p.G, p.nchunks, p.G, g, g + 1);
         red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
         __syncthreads();
         if (threadIdx.x < p.G) {
@@ -640,11 +699,18 @@ int launch_gn_fold(hipStream_t st, const GnParams& p, const bf16_t* W, const flo
 // launches (partial / finalize / apply) where the whole tensor is a few MB.
 // ------------------------------------------------------------------------------
 #define GNS_MAXV 24
+#define GNS_MAXC 256
 __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
     __shared__ float red[8];
-    __shared__ float bc[2];
+    __shared__ __attribute__((aligned(16))) float gb[2][GNS_MAXC];   // the group's gamma / beta, requested with the slab (round 5:
+                                                                     // they used to be a dependent round trip behind the statistics)
     const int g = blockIdx.x, n = blockIdx.y;
     const int cpg = p.C / p.G, vpp = cpg / 4;          // 4-channel vectors per pixel
+    const bool gb_lds = cpg <= GNS_MAXC;
+    if (gb_lds && threadIdx.x < cpg) {                 // read after the two block_sum barriers
+        gb[0][threadIdx.x] = p.gamma[g * cpg + threadIdx.x];
+        gb[1][threadIdx.x] = p.beta[g * cpg + threadIdx.x];
+    }
     const int nvec = p.HW * vpp;
     const int C2 = p.C - p.C1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -687,7 +753,9 @@ __global__ __launch_bounds__(256) void k_gn_small(GnParams p) {
         const int idx = threadIdx.x + v * 256;
         if (idx < nvec) {
             const int pix = idx / vpp, c = g * cpg + (idx - pix * vpp) * 4;
-            const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
+            const int cl = c - g * cpg;
+            const float4 ga = gb_lds ? *(const float4*)(&gb[0][cl]) : *(const float4*)(p.gamma + c);
+            const float4 be = gb_lds ? *(const float4*)(&gb[1][cl]) : *(const float4*)(p.beta + c);
             float o[4] = {(f[v][0] - mean) * rstd * ga.x + be.x, (f[v][1] - mean) * rstd * ga.y + be.y,
                           (f[v][2] - mean) * rstd * ga.z + be.z, (f[v][3] - mean) * rstd * ga.w + be.w};
             if (p.silu) {

@@ -25,9 +25,9 @@ with torch.no_grad():
             p.zero_()
 net._invalidate()
 print("weights ready", time.time() - t0)
-x = torch.randn(B, 4, 64, 64, device=dev)
+x = torch.randn(B, 4, 64, 64, device=dev, generator=g)       # seeded: the output hash below compares library builds across processes
 t = torch.full((B,), 500, device=dev)
-ctx = torch.randn(B, 77, 768, device=dev)
+ctx = torch.randn(B, 77, 768, device=dev, generator=g)
 out = net(x, t, encoder_hidden_states=ctx).sample
 torch.cuda.synchronize()
 print("first forward ok", time.time() - t0, "finite:", bool(torch.isfinite(out).all()), "launches", _lib.lib().gyre_last_launch_count())
@@ -37,6 +37,8 @@ for _ in range(iters):
     out = net(x, t, encoder_hidden_states=ctx).sample
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
+import hashlib
+print("output sha1", hashlib.sha1(out.float().cpu().numpy().tobytes()).hexdigest()[:16])      # A/B of two library builds: same bits?
 print(f"UNet forward B={B}: {ms:.2f} ms  -> {B*0.803/ms:.1f} TFLOP/s effective; ws={net._ws.numel()/2**20:.0f} MiB")
 vae = GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).to(dev)
 with torch.no_grad():
