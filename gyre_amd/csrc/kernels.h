@@ -2,8 +2,6 @@
 // and return 0 / negative gyre_status (message via gyre_last_error()).
 #pragma once
 #include "common.h"
-#include <map>
-#include <vector>
 
 // ---- layout / small ops (kernels_elem.hip) ----------------------------------
 int launch_nchw_to_nhwc(hipStream_t st, const void* x, int dtype, int B, int C, int HW, int Cpad, bf16_t* y);
@@ -167,44 +165,6 @@ struct GemmPlan { int cfg; int splits; size_t ws_bytes; };
 GemmPlan gemm_plan(const GemmParams& p);
 int launch_gemm(hipStream_t st, const GemmParams& p);
 
-// ---- weight prefetch into the Infinity Cache (round 5; kernels_gemm.hip) ----------------------------------------------------
-// One UNet evaluation reads 1.7 GB of weights once, in a fixed order, through a 256 MB memory-side cache: every GEMM launch finds
-// its weights COLD in HBM (profiles/README.md "Cold vs warm, separated": in-UNet times sit at the cold figure).  The sequence of
-// weight buffers a call reads is the same from one sampler step to the next, so a handle RECORDS it (launch_gemm reports the
-// buffer it is about to read) and the next call with the same signature replays it one group ahead on a second, low-priority
-// stream: when the main stream enters group g (consecutive launches whose weights total <= group_bytes), a small kernel touches
-// one dword per 128-byte line of group g + 1, ordered behind an event on the main stream so that it never runs further ahead.
-// Only buffers inside ranges the owner registered (the handle's own allocations, alive until destroy) are ever touched: a stale
-// plan can waste bandwidth, it cannot read freed memory.  Results never depend on it.
-struct WeightPrefetcher {
-    struct Span { const void* p; unsigned long long bytes; };
-    struct Plan {
-        uint64_t sig = 0, used = 0;
-        std::vector<Span> spans;                 // one per GEMM launch of the call, bytes = 0: not prefetchable
-        std::vector<int> group_first;            // launch index at which group g starts (+ sentinel)
-        Span* d_table = nullptr; size_t d_cap = 0;
-    };
-    std::vector<Plan> plans;                     // a few signatures (hires fix alternates two sizes)
-    Plan* cur = nullptr;                         // the plan being replayed by this call (null: recording only)
-    std::vector<Span> rec;
-    uint64_t sig = 0, tick = 0;
-    int idx = 0, group = 0;
-    bool active = false;
-    size_t group_bytes = 0;                      // 0: off
-    hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> events;
-    hipEvent_t done = nullptr;
-    const std::map<uintptr_t, size_t>* ranges = nullptr;     // owner's allocations: base -> bytes
-    std::vector<void*> tables_to_free;
-    bool owns(const void* p, size_t bytes) const;
-    int begin(hipStream_t main, uint64_t signature);
-    void on_gemm(hipStream_t main, const void* w, size_t bytes);
-    int end(hipStream_t main);
-    void release();                              // sync + free (handle destroy)
-    ~WeightPrefetcher() { release(); }
-};
-// the prefetcher launch_gemm reports to on this thread (null: none); returns the previous one
-WeightPrefetcher* gemm_set_prefetcher(WeightPrefetcher* pf);
 
 // ---- flash-style attention (kernels_attn.hip) ------------------------------------
 struct AttnParams {

@@ -1575,131 +1575,12 @@ bool gemm_w_block_wanted(const GemmParams& p0) {
     return w_block_cfg(cfg);
 }
 
-// ------------------------------------------------------------------------------
-// Weight prefetch into the Infinity Cache (kernels.h WeightPrefetcher)
-// ------------------------------------------------------------------------------
-// One dword per 128-byte line: the request pulls the whole line through the memory-side cache, 1/32 of it travels on to the CU.
-// All requests of a thread are issued before the single wait (inline asm: the compiler would drop loads nobody reads).
-__global__ __launch_bounds__(256) void k_prefetch_spans(const WeightPrefetcher::Span* __restrict__ t, int n) {
-    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256 * 128;
-    // ONE destination register for every request, live from here to the final wait ("+v": read-write, and used after the wait):
-    // the hardware writes it whenever a request returns, long after the asm statement that issued it - a destination the compiler
-    // believed dead would be handed to the loop counter or an address and overwritten under it (the first version of this kernel
-    // faulted on exactly that).
-    unsigned sink = 0;
-    for (int i = 0; i < n; ++i) {
-        const char* base = (const char*)t[i].p;
-        const size_t nb = t[i].bytes;
-        for (size_t off = lane * 128; off + 4 <= nb; off += stride)
-            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
-    asm volatile("" :: "v"(sink));
-}
-static thread_local WeightPrefetcher* g_prefetcher = nullptr;
-WeightPrefetcher* gemm_set_prefetcher(WeightPrefetcher* pf) { WeightPrefetcher* old = g_prefetcher; g_prefetcher = pf; return old; }
-
-bool WeightPrefetcher::owns(const void* p, size_t bytes) const {
-    if (!ranges || !p || !bytes) return false;
-    auto it = ranges->upper_bound((uintptr_t)p);
-    if (it == ranges->begin()) return false;
-    --it;
-    return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
-}
-int WeightPrefetcher::begin(hipStream_t main, uint64_t signature) {
-    (void)main;
-    active = false; cur = nullptr;
-    if (!group_bytes) return 0;
-    if (!stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);            // lo = numerically greatest = lowest priority
-        GYRE_HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, lo));
-        GYRE_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    }
-    sig = signature; idx = 0; group = 0; rec.clear(); ++tick;
-    for (Plan& pl : plans)
-        if (pl.sig == signature && pl.d_table && !pl.spans.empty()) { cur = &pl; pl.used = tick; break; }
-    if (cur)
-        while (events.size() + 1 < cur->group_first.size()) {
-            hipEvent_t e;
-            GYRE_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            events.push_back(e);
-        }
-    active = true;
-    return 0;
-}
-void WeightPrefetcher::on_gemm(hipStream_t main, const void* w, size_t bytes) {
-    if (!active) return;
-    rec.push_back({owns(w, bytes) ? w : nullptr, owns(w, bytes) ? (unsigned long long)bytes : 0ull});
-    if (cur) {
-        const int ngroups = (int)cur->group_first.size() - 1;
-        if (group < ngroups && idx == cur->group_first[group]) {          // the main stream enters group `group`: fetch the next one
-            if (group + 1 < ngroups) {
-                const int a = cur->group_first[group + 1], b = cur->group_first[group + 2];
-                if (hipEventRecord(events[group], main) == hipSuccess && hipStreamWaitEvent(stream, events[group], 0) == hipSuccess)
-                    hipLaunchKernelGGL(k_prefetch_spans, dim3(64), dim3(256), 0, stream, (const Span*)cur->d_table + a, b - a);
-                (void)hipGetLastError();                                  // best effort: a failed prefetch is not an error of the call
-            }
-            ++group;
-        }
-    }
-    ++idx;
-}
-int WeightPrefetcher::end(hipStream_t main) {
-    if (!active) return 0;
-    active = false;
-    // the caller may free what the handle owns only after its stream is idle: tie the prefetch stream back into it
-    if (cur && group > 0) {
-        GYRE_HIP_CHECK(hipEventRecord(done, stream));
-        GYRE_HIP_CHECK(hipStreamWaitEvent(main, done, 0));
-    }
-    bool same = cur && cur->spans.size() == rec.size();
-    if (same)
-        for (size_t i = 0; i < rec.size(); ++i)
-            if (rec[i].p != cur->spans[i].p || rec[i].bytes != cur->spans[i].bytes) { same = false; break; }
-    if (same || rec.empty()) return 0;
-    // (re)build the plan of this signature: least recently used of at most four
-    Plan* pl = cur;
-    if (!pl) {
-        for (Plan& q : plans) if (q.sig == sig) pl = &q;
-        if (!pl) {
-            if (plans.size() < 4) { plans.emplace_back(); pl = &plans.back(); }
-            else { pl = &plans[0]; for (Plan& q : plans) if (q.used < pl->used) pl = &q; }
-        }
-    }
-    pl->sig = sig; pl->used = tick; pl->spans = rec;
-    pl->group_first.clear();
-    size_t acc = 0;
-    for (size_t i = 0; i < rec.size(); ++i) {
-        if (i == 0 || acc + rec[i].bytes > group_bytes) { pl->group_first.push_back((int)i); acc = 0; }
-        acc += rec[i].bytes;
-    }
-    pl->group_first.push_back((int)rec.size());
-    if (pl->d_cap < rec.size()) {
-        // the old table may still be read by a prefetch kernel in flight: it is freed with the handle
-        if (pl->d_table) tables_to_free.push_back(pl->d_table);
-        pl->d_table = nullptr;
-        void* d = nullptr;
-        GYRE_HIP_CHECK(hipMalloc(&d, rec.size() * sizeof(Span)));
-        pl->d_table = (Span*)d; pl->d_cap = rec.size();
-    } else if (cur && group > 0) {
-        GYRE_HIP_CHECK(hipStreamSynchronize(stream));                     // rewriting a table a kernel may still be reading
-    }
-    GYRE_HIP_CHECK(hipMemcpyAsync(pl->d_table, rec.data(), rec.size() * sizeof(Span), hipMemcpyHostToDevice, main));
-    GYRE_HIP_CHECK(hipStreamSynchronize(main));                           // rec is pageable host memory that the next call clears
-    return 0;
-}
-void WeightPrefetcher::release() {
-    if (stream) (void)hipStreamSynchronize(stream);
-    for (Plan& pl : plans) if (pl.d_table) (void)hipFree(pl.d_table);
-    for (void* t : tables_to_free) (void)hipFree(t);
-    plans.clear(); tables_to_free.clear(); cur = nullptr;
-    for (hipEvent_t e : events) (void)hipEventDestroy(e);
-    events.clear();
-    if (done) { (void)hipEventDestroy(done); done = nullptr; }
-    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
-}
-
+// (Round 5: a weight PREFETCHER was built and removed again - per handle, the sequence of weight buffers a call's GEMM launches read
+//  was recorded and replayed one <= N MB group ahead by a one-dword-per-line kernel on a second low-priority stream, ordered behind
+//  events on the main stream, so that every launch would find its weights in the Infinity Cache instead of cold in HBM.  Results
+//  bit-identical, and SLOWER at every group size (16 / 48 / 128 MB): UNet call 5.70 -> 6.41 - 6.54 ms at batch 2, 16.85 -> 17.36 at
+//  batch 16 (profiles/r05_weight_prefetch_ab.txt): the extra 1.7 GB of requests per call queue in front of the latency-bound loads
+//  of the launches they were meant to help, and an Infinity-Cache hit is not enough faster than HBM to pay that back.)
 int launch_gemm(hipStream_t st, const GemmParams& p0) {
     GemmParams p = p0;
     if (!p.force_cfg) p.force_cfg = g_force_cfg;
@@ -1770,9 +1651,6 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
         p.W_blk = g_dbg_blk_ws;
     }
     if (p.W_blk && (!w_block_cfg(cfg) || p.K % 64 || p.N % 8 || p.w_sample_stride || (p.mode == GEMM_CONV3 && (p.Cin % 64 || p.C1 % 64)))) p.W_blk = nullptr;
-    if (g_prefetcher)
-        g_prefetcher->on_gemm(st, cfg == 30 && p.w_packed ? p.w_packed : p.W_blk ? (const void*)p.W_blk : (const void*)p.W,
-                              p.w_sample_stride ? 0 : (size_t)p.N * p.K * 2);
     if (cfg == 30) {
         if (splits > 1 || !gemm_ar_supports(p)) GYRE_FAIL(-6, "gemm: problem outside the A-resident kernel's domain (K = 320 / 640 linear, bf16 row-major output)");
         const void* wpk = p.w_packed;

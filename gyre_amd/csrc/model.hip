@@ -227,47 +227,13 @@ int gyre_unet_debug_tap(gyre_unet* h, const char* name, float* out_nchw_f32, siz
     h->taps[name] = {out_nchw_f32, out_bytes};
     return 0;
 }
-// One inference call of a UNet handle under its weight prefetcher (kernels.h): on by default with 48 MB groups,
-// GYRE_WEIGHT_PREFETCH_MB=0 turns it off, =N picks another group size.  The signature names everything that changes the
-// sequence of GEMM launches; a sequence that differs anyway is noticed at the end of the call and recorded afresh.
-#define GYRE_WEIGHT_PREFETCH_DEFAULT_MB 0L
-struct PrefetchScope {
-    gyre_unet* h; hipStream_t st; WeightPrefetcher* prev = nullptr; bool on = false;
-    PrefetchScope(gyre_unet* h_, hipStream_t st_, int B, int H, int W, int S, int extra) : h(h_), st(st_) {
-        const char* e = getenv("GYRE_WEIGHT_PREFETCH_MB");       // read per call: tests flip it between two calls of one process
-        const long mb = e ? atol(e) : GYRE_WEIGHT_PREFETCH_DEFAULT_MB;
-        WeightPrefetcher& pf = h->prefetch;
-        pf.group_bytes = mb > 0 ? (size_t)mb << 20 : 0;
-        if (!pf.group_bytes) return;
-        pf.ranges = &h->store.ranges;
-        uint64_t sig = 1469598103934665603ull;
-        for (uint64_t v : {(uint64_t)B, (uint64_t)H, (uint64_t)W, (uint64_t)S, (uint64_t)extra, (uint64_t)h->hint_uniform_t,
-                           (uint64_t)h->hint_cfg_pairs, (uint64_t)h->ex.tome_r, (uint64_t)h->ex.tiling, h->store.weights_version,
-                           (uint64_t)gemm_get_batch_invariant()})
-            sig = (sig ^ v) * 1099511628211ull;
-        if (pf.begin(st, sig) != 0) return;
-        prev = gemm_set_prefetcher(&pf);
-        on = true;
-    }
-    int finish(int rc) {
-        if (on) {
-            gemm_set_prefetcher(prev);
-            on = false;
-            const int rc2 = h->prefetch.end(st);
-            if (!rc) rc = rc2;
-        }
-        return rc;
-    }
-    ~PrefetchScope() { (void)finish(0); }
-};
 int gyre_unet_forward_ex(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                          int H, int W, int S, void* ws, size_t wsb, void* out, int odt, const float* temb_add) {
     if (!h || !x || !t || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     if (!h->finalized) GYRE_FAIL(GYRE_ERR_INCOMPLETE, "gyre_unet_finalize has not succeeded");
     if (xdt < 0 || xdt > 2 || cdt < 0 || cdt > 2 || odt < 0 || odt > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
-    PrefetchScope pf_(h, (hipStream_t)st, B, H, W, S, ctx ? 0 : 8192);
-    return pf_.finish(h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr));
+    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr);
 }
 int gyre_unet_hint_cfg_pairs(gyre_unet* h, int on) {
     if (!h) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
@@ -289,10 +255,9 @@ int gyre_unet_forward_ctrl(gyre_unet* h, void* st, const void* x, int xdt, const
     if (n_down_res < 0 || (n_down_res > 0 && !down_res) || n_adapter_states < 0 || (n_adapter_states > 0 && !adapter_states))
         GYRE_FAIL(GYRE_ERR_INVALID, "bad residual list");
     g_launches = 0;
-    PrefetchScope pf_(h, (hipStream_t)st, B, H, W, S, 1 + n_down_res + 64 * n_adapter_states + (mid_res ? 4096 : 0) + (ctx ? 0 : 8192));
-    return pf_.finish(h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr,
-                             n_down_res ? down_res : nullptr, n_down_res, rdt, mid_res, n_adapter_states ? adapter_states : nullptr,
-                             n_adapter_states));
+    return h->run(false, (hipStream_t)st, x, xdt, t, ctx, cdt, B, H, W, S, ws, wsb, out, odt, temb_add, ctx == nullptr,
+                  n_down_res ? down_res : nullptr, n_down_res, rdt, mid_res, n_adapter_states ? adapter_states : nullptr,
+                  n_adapter_states);
 }
 int gyre_unet_forward(gyre_unet* h, void* st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt, int B,
                       int H, int W, int S, void* ws, size_t wsb, void* out, int odt) {

@@ -155,10 +155,8 @@ struct Store {
         if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
         if (zero) (void)hipMemset(p, 0, bytes);
         allocs.push_back(p);
-        ranges[(uintptr_t)p] = bytes ? bytes : 16;
         return p;
     }
-    std::map<uintptr_t, size_t> ranges;      // every allocation of this store (alive until destroy): what a WeightPrefetcher may touch
     Param* add(const std::string& key, std::vector<int64_t> shape, int kind, void* dev, int o_pad = 0, int i_pad = 0) {
         auto p = std::make_unique<Param>();
         p->key = key; p->shape = std::move(shape); p->kind = kind; p->dev = dev; p->o_pad = o_pad; p->i_pad = i_pad;
@@ -885,7 +883,6 @@ struct UNetVjpState {
 struct gyre_unet {
     gyre_unet_cfg cfg;
     Store store;
-    WeightPrefetcher prefetch;     // declared behind `store`: destroyed (its stream drained) before the weights are freed
     Exec ex;
     UNetVjpState vjp;
     bool finalized = false;
