@@ -79,6 +79,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
             sm_glds(dst + WOFF + i * 1024, src[2 + i] + (size_t)kk * wstep);
         }
     };
+    // Round 5: the epilogue's bias and residual rows are requested HERE, in front of the ring (by hand: a compiler-visible load
+    // would put the compiler's own vmcnt bookkeeping into the counted loop).  They are older than every ring request, so the first
+    // counted wait covers them, and the epilogue no longer ends the launch with one more cold round trip.
+    typedef unsigned sm_u32x4 __attribute__((ext_vector_type(4)));
+    sm_u32x4 e_res[2], e_b0[2], e_b1[2];
+    const bool e_plain = !(p.vt_out && n0 >= p.vt_col0);
+    if (e_plain) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i, row = v >> 3, c8 = v & 7;
+            const int m = min(m0 + row, p.M - 1), n = n0 + 8 * c8;
+            if constexpr (RES)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_res[i]) : "v"(p.residual + (size_t)m * p.ldr + n) : "memory");
+            if (p.bias) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_b0[i]) : "v"(p.bias + n) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(e_b1[i]) : "v"(p.bias + n + 4) : "memory");
+            }
+        }
+    }
     issue(0, 0);
     issue(1, 1);
     issue(2, 2);
@@ -136,13 +155,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         if (m >= p.M) continue;
         const float4 a = *(const float4*)(tile + row * ROWF + 8 * c8), b = *(const float4*)(tile + row * ROWF + 8 * c8 + 4);
         float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        if (p.bias) {
-            const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-            f[0] += b0.x; f[1] += b0.y; f[2] += b0.z; f[3] += b0.w; f[4] += b1.x; f[5] += b1.y; f[6] += b1.z; f[7] += b1.w;
+        if (p.bias) {       // requested in front of the ring (vmcnt(0) above covers them)
+            f[0] += __uint_as_float(e_b0[i].x); f[1] += __uint_as_float(e_b0[i].y); f[2] += __uint_as_float(e_b0[i].z); f[3] += __uint_as_float(e_b0[i].w);
+            f[4] += __uint_as_float(e_b1[i].x); f[5] += __uint_as_float(e_b1[i].y); f[6] += __uint_as_float(e_b1[i].z); f[7] += __uint_as_float(e_b1[i].w);
         }
         if constexpr (RES) {
             float r8[8];
-            unpack8(*(const uint4*)(p.residual + (size_t)m * p.ldr + n), r8);
+            unpack8(make_uint4(e_res[i].x, e_res[i].y, e_res[i].z, e_res[i].w), r8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += r8[e];
         }
