@@ -278,7 +278,9 @@ def main():
         from transformers import CLIPConfig, CLIPModel
         from gyre_amd.clipguided import patch_embedding_as_matmul
         torch.manual_seed(7)
-        clip_model = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(dev))
+        # bf16 like the rest of the pipeline (the reference loads clip_model in the engine's fp16): the guidance follows the dtype the
+        # caller loaded the model in (gyre_amd/clipguided.py cond_fn); fp32 here put ~10 % of the step into rocBLAS fp32 GEMMs
+        clip_model = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(dev).to(torch.bfloat16))
         for p_ in clip_model.parameters():
             p_.requires_grad_(False)
         fe = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711],
@@ -492,7 +494,7 @@ def main():
                 "inpaint768": f"SD1.5 grafted inpaint {size}x{size} (9-ch inpaint UNet + base UNet, hires fix, VAE encode), {n_steps} steps "
                               f"DPM++2M ({evals} UNet evals), batch={B}, bf16 (BASELINE.json configs[2])",
                 "tomeclip": f"SD1.5 txt2img {size}x{size}, ToMe r={args.tome_r} + CLIP guidance (scale {args.clip_scale}, guided base, 2 + 2 "
-                            f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch), {n_steps} steps DPM++2M ({evals} UNet "
+                            f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch, bf16), {n_steps} steps DPM++2M ({evals} UNet "
                             f"evals incl. the differentiated stems), batch={B}, bf16 (BASELINE.json configs[4])"}[args.config],
                        "images_per_step": sum(sizes), "images_per_rank": sizes, "parallelism": f"dp{world}",
                        "dist_backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen,

@@ -297,11 +297,19 @@ class ClipGuidedMode:
             if self.mean.device != image.device or self.mean.dtype != image.dtype:     # once: no per-step host-to-device copy
                 self.mean, self.std = self.mean.to(image.device, image.dtype), self.std.to(image.device, image.dtype)
             image = (image - self.mean) / self.std
+            # the reference hands the CLIP model tensors of the pipeline's own dtype (fp16 end to end on a GPU, :400-404); here the
+            # decoded image is fp32, so it is cast to whatever dtype the caller loaded the CLIP model in (no-op for an fp32 model)
+            clip_dtype = getattr(self.clip_model, "dtype", None)
+            if isinstance(clip_dtype, torch.dtype) and clip_dtype != image.dtype:
+                image = image.to(clip_dtype)
             image_embeddings_clip = _features(self.clip_model.get_image_features(image))
+            text_clip = self.text_embeddings_clip
+            if image_embeddings_clip.dtype != torch.float32:     # reduced-precision CLIP model: the loss itself stays fp32 (2 x B x 512
+                image_embeddings_clip, text_clip = image_embeddings_clip.float(), text_clip.float()     # numbers; arcsin / pow in bf16 is noise)
             if no_cutouts:
-                loss = spherical_dist_loss(image_embeddings_clip, self.text_embeddings_clip).mean()
+                loss = spherical_dist_loss(image_embeddings_clip, text_clip).mean()
             else:
-                text_in = self.text_embeddings_clip.repeat_interleave(num_cutouts, dim=0)
+                text_in = text_clip.repeat_interleave(num_cutouts, dim=0)
                 dists = spherical_dist_loss(image_embeddings_clip, text_in)
                 dists = dists.view([num_cutouts, latents.shape[0], -1])
                 loss = dists.sum(2).mean(0).sum()

@@ -60,6 +60,21 @@ def test_guidance_runs_and_changes_the_image(tiny, sampler, extra):
     assert torch.equal(guided, again)                                    # per-image generators: reproducible
 
 
+def test_guidance_follows_the_dtype_the_clip_model_was_loaded_in(tiny):
+    """The reference feeds its CLIP model tensors of the pipeline's own (fp16) dtype (clipguided.py:400-404); here the decoded image is
+    fp32 and is cast to the model's dtype, the loss stays fp32: a bf16 CLIP model guides like the fp32 one, up to bf16 noise."""
+    pipe, kw, ids = make(tiny)
+    ref = pipe(sampler="euler", clip_guidance_scale=0.5, clip_input_ids=ids, **kw)
+    plain = pipe(sampler="euler", **kw)
+    pipe.clip_model = pipe.clip_model.to(torch.bfloat16)
+    low = pipe(sampler="euler", clip_guidance_scale=0.5, clip_input_ids=ids, **kw)
+    assert bool(torch.isfinite(low).all())
+    d_ref, d_low = (ref - plain).flatten().double(), (low - plain).flatten().double()
+    cos = float(d_ref @ d_low / (d_ref.norm() * d_low.norm()))
+    assert cos > 0.9, cos                                             # the same push, not the same bits
+    assert float((low - ref).abs().max()) < 0.5 * float((ref - plain).abs().max())
+
+
 def test_guidance_without_a_clip_model_is_ignored_with_a_warning(tiny, capsys):
     pipe, kw, ids = make(tiny, clip=False)
     plain = pipe(sampler="euler", **kw)

@@ -1,5 +1,5 @@
 set -x
-O=$GRAFT_REPO_ROOT/gpurun_out/r05u
+O=$GRAFT_REPO_ROOT/gpurun_out/${EVID_TAG:-r05u}
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
