@@ -238,6 +238,30 @@ __global__ __launch_bounds__(256) void k_gn_partial(GnParams p, int TX, int PY, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[v][j] = 0.f; ss[v][j] = 0.f; }
     if (ty < PY) {
+        if (CV <= TX) {
+            // one channel vector per lane (C <= 2048, every UNet / VAE GroupNorm): four pixel rows requested per trip, added in pixel
+            // order - the one-row loop waited for every load before issuing the next (round 5, same sums)
+            if (tx < CV) {
+                const int c = tx * 8;
+                const bool first = c < p.C1;
+                const bf16_t* base = first ? p.x + c : p.x2 + (c - p.C1);
+                const size_t ld = first ? (size_t)p.C1 : (size_t)C2;
+                for (int pix = p0 + ty; pix < p1; pix += 4 * PY) {
+                    uint4 raw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (pix + u * PY < p1) raw[u] = *(const uint4*)(base + ((size_t)n * p.HW + pix + u * PY) * ld);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (pix + u * PY < p1) {
+                            float f[8];
+                            unpack8(raw[u], f);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { s[0][j] += f[j]; ss[0][j] = fmaf(f[j], f[j], ss[0][j]); }
+                        }
+                }
+            }
+        } else
         for (int pix = p0 + ty; pix < p1; pix += PY) {
             size_t gp = (size_t)n * p.HW + pix;
 #pragma unroll
