@@ -526,7 +526,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
     };
     bool ring_done = false;
-    if constexpr (MODE == GEMM_LINEAR) {
+    if constexpr (MODE == GEMM_LINEAR || (UNIFORM_TAP && BM == 128 && BN == 160)) {      // (conv ring: the 128x160 tile only - the 256x320 instance spills with it)
         // Round 5: the K loop of the linear problems as an nst-deep LDS ring (nst = 2 ... 4, chosen by the launcher from the LDS a
         // workgroup may take), nst - 1 stages IN FLIGHT while one is multiplied.  The two-stage loop below requests stage k+1,
         // multiplies stage k and then waits for everything: one exposed memory latency per 64-deep K step - with the weights of a
@@ -540,7 +540,11 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         //     before any wave can request the refill - the ring discipline of kernels_attn.hip);
         //   * past-the-end stages are requested from the zero page so that the in-flight count stays uniform.
         // Same fragment reads, same K order, same accumulators: bit-identical to the two-stage loop (tuning bit 24 = that loop).
-        if (nst >= 2 && p.K % BK == 0 && p.C1 % BK == 0 && !(p.debug & 0x1000003)) {
+        // Late round 5: the same ring for the 3x3 convolutions whose K steps are (64-channel chunk, tap) pairs (UNIFORM_TAP: every UNet /
+        // VAE conv but conv_in): the split-K convs of the 16x16 / 8x8 levels run 256 workgroups of ~23 K steps, one per CU - the
+        // shape the two-stage loop serves worst.  The gather has no running pointer (tap shifts, padding from the zero page), so a
+        // step's sources are recomputed from its (chunk, tap) exactly as issue_stage does; tuning bit 27 = two-stage loop for convs.
+        if (nst >= 2 && p.K % BK == 0 && p.C1 % BK == 0 && !(p.debug & (MODE == GEMM_LINEAR ? 0x1000003 : 0x8000003))) {
             constexpr int PPW = AR + BR;
             const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
             auto dma16 = [&](unsigned dst, const char* src) {
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                 return second ? (const char*)(p.A2 + (size_t)row * p.lda2 + kvs * 8) + (size_t)(kstep - k1) * 128
                               : (const char*)(p.A + (size_t)row * p.lda + kvs * 8) + (size_t)kstep * 128;
             };
+            if constexpr (MODE == GEMM_LINEAR) {
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
                 const bool ok = a_base[i] >= 0;
@@ -572,18 +577,48 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                     iw[i] = ok ? 128u : 0u;
                 }
             }
+            }
             int kabs = kc0;                                           // K step the next request fetches
             auto ring_issue = [&](int slot) {
                 const unsigned dst = lds0 + slot * STAGE_BYTES + wave * 1024;
                 if (kabs < nk) {
-                    if (kabs == k1 && kabs > kc0) {                   // (wave-uniform, at most once) the rows continue in the second source
+                    if constexpr (MODE == GEMM_LINEAR) {
+                        if (kabs == k1 && kabs > kc0) {               // (wave-uniform, at most once) the rows continue in the second source
 #pragma unroll
-                        for (int i = 0; i < AR; ++i) if (a_base[i] >= 0) ca[i] = a_ptr(i, true, kabs);
+                            for (int i = 0; i < AR; ++i) if (a_base[i] >= 0) ca[i] = a_ptr(i, true, kabs);
+                        }
+#pragma unroll
+                        for (int i = 0; i < AR; ++i) { dma16(dst + i * 8192, ca[i]); ca[i] += ia[i]; }
+#pragma unroll
+                        for (int i = 0; i < BR; ++i) { dma16(dst + BM * 128 + i * 8192, cw[i]); cw[i] += iw[i]; }
+                    } else {
+                        // issue_stage's conv gather for K step kabs = (chunk, tap), chunk outer / tap inner
+                        const int chunk = kabs / 9, tap = kabs - chunk * 9;
+                        const int c = chunk * BK + kvs * 8;
+                        const int ky = tap / 3, kx = tap - ky * 3;
+                        const bool first = c < p.C1;
+#pragma unroll
+                        for (int i = 0; i < AR; ++i) {
+                            const bf16_t* src = zero;
+                            int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                            if (a_base[i] >= 0 && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                                if (p.ups) { iy >>= 1; ix >>= 1; }
+                                const size_t pix = (size_t)a_base[i] + (size_t)iy * p.Wi + ix;
+                                src = first ? p.A + pix * p.lda + c : p.A2 + pix * p.lda2 + (c - p.C1);
+                            }
+                            dma16(dst + i * 8192, (const char*)src);
+                        }
+                        const int kw = tap * p.Cin + c;              // this lane's 8 weights inside a [taps][Cin] weight row
+#pragma unroll
+                        for (int i = 0; i < BR; ++i) {
+                            const int n = n0 + r0 + 64 * i;
+                            const bf16_t* src = zero;
+                            if (n < p.N && (BN % 64 == 0 || r0 + 64 * i < BN))
+                                src = p.W_blk ? p.W_blk + ((size_t)(n >> 3) * (p.K >> 6) + (kw >> 6)) * 512 + (n & 7) * 64 + (kw & 63)
+                                              : wbase + (size_t)n * p.K + kw;
+                            dma16(dst + BM * 128 + i * 8192, (const char*)src);
+                        }
                     }
-#pragma unroll
-                    for (int i = 0; i < AR; ++i) { dma16(dst + i * 8192, ca[i]); ca[i] += ia[i]; }
-#pragma unroll
-                    for (int i = 0; i < BR; ++i) { dma16(dst + BM * 128 + i * 8192, cw[i]); cw[i] += iw[i]; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < PPW; ++i) dma16(dst + i * 8192, (const char*)zero);
@@ -1207,7 +1242,8 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
     // (tuning bit 24: the two-stage loop everywhere; bit 25: the deep ring also where two 2-stage workgroups would fit)
     const size_t stage = (size_t)(BM + (BN + 63) / 64 * 64) * 128;
     int nst = 2;
-    if (p.mode == GEMM_LINEAR && !(p.debug & 0x1000000)) {
+    const bool conv_ring = BM == 128 && BN == 160 && p.mode == GEMM_CONV3 && p.Cin % BK == 0 && p.C1 % BK == 0 && p.K % BK == 0 && !(p.debug & 0x8000000);
+    if ((p.mode == GEMM_LINEAR && !(p.debug & 0x1000000)) || conv_ring) {
         const int fit1 = (int)std::min<size_t>(4, (size_t)160 * 1024 / stage);
         const bool two_fit = 4 * stage <= (size_t)160 * 1024;
         if (grid <= 256 || !two_fit || (p.debug & 0x2000000)) nst = fit1;

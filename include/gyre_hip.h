@@ -288,7 +288,8 @@ long gyre_debug_attn_redo_count(void);
  * (tile config 32, kernels_gemm_sm.hip): small linear problems go to the register-staged 4-wave tiles as before, bit6 = it does not take
  * the long-K few-row linear problems from the split-K path.  Round 5: bit24 = the two-stage K loop in the 8-wave kernels' linear mode
  * (instead of the 2 - 4 stage LDS ring with counted waits), bit25 = the deep ring at one workgroup per CU also where two 2-stage
- * workgroups would fit, bit26 = row-major weights everywhere (no blocked weight copies for the LDS-DMA kernels).  (Bits 7 and 13 -
+ * workgroups would fit, bit26 = row-major weights everywhere (no blocked weight copies for the LDS-DMA kernels), bit27 = the two-stage K loop for the
+ * 128x160 tile's 3x3 convolutions (instead of the same ring).  (Bits 7 and 13 -
  * the small kernel's LayerNorm fold and the W-resident kernel - went with the code they switched on.)
  * Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores.
  * These switches are PER CALLING THREAD (thread-local, like gyre_set_batch_invariant): they never change what another thread's

@@ -453,7 +453,8 @@ def test_linear_ring_loop_and_blocked_weights_are_bit_identical(M, K, N, res):
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 24, 192, 640), (1, 16, 1280, 1280), (2, 8, 640, 1280)])
 def test_conv_blocked_weights_are_bit_identical(B, H, Cin, Cout):
     """3x3 convs read the blocked weight copy too (every conv has K = 9 Cin > 1024): same bits as from the row-major weights for
-    the 8-wave tiles, the pipelined 32x32x16 tile and their split-K forms."""
+    the 8-wave tiles, the pipelined 32x32x16 tile and their split-K forms.  Late round 5: the 8-wave kernel's conv K loop runs on
+    the nst-deep LDS ring as well (tuning bit 27 = the two-stage loop it replaces): same bits again, also against the fp32 conv."""
     L = _lib.lib()
     x = to_dev_bf16(nhwc(bf16_round(randn(B, Cin, H, H, seed=60))))
     w = repack_conv(bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)))
@@ -463,17 +464,22 @@ def test_conv_blocked_weights_are_bit_identical(B, H, Cin, Cout):
     L.gyre_debug_set_splitk_workspace(vp(wsk), wsk.numel())
     refs = {}
     try:
-        for cfg in (4, 5, 8, 24, 8 | (2 << 8), 24 | (2 << 8)):
-            for blocked in (0, 1):
+        for cfg in (4, 5, 8, 24, 8 | (2 << 8), 8 | (4 << 8), 5 | (2 << 8), 24 | (2 << 8)):
+            for blocked, bits in ((0, 0), (1, 0), (0, 0x8000000), (1, 0x8000000)):
+                if bits and (cfg & 0xff) == 24: continue          # (the pipelined tile has its own loop)
                 y = torch.full((B, H, H, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
                 L.gyre_debug_set_wblk_workspace(vp(blk) if blocked else None, blk.numel() if blocked else 0)
-                oc = L.gyre_debug_force_gemm_cfg(cfg)
+                oc, ob = L.gyre_debug_force_gemm_cfg(cfg), L.gyre_debug_gemm_ablation(bits)
                 try:
                     _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, H, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
                 finally:
-                    L.gyre_debug_force_gemm_cfg(oc)
-                refs.setdefault(cfg >> 8, y)
-                assert torch.equal(y, refs[cfg >> 8]), f"config {cfg:#x} blocked {blocked} differs"
+                    L.gyre_debug_force_gemm_cfg(oc); L.gyre_debug_gemm_ablation(ob)
+                if (cfg >> 8) not in refs:
+                    refs[cfg >> 8] = y
+                    ref = F.conv2d(bf16_round(randn(B, Cin, H, H, seed=60)), bf16_round(randn(Cout, Cin, 3, 3, seed=61) / math.sqrt(9 * Cin)),
+                                   randn(Cout, seed=62), padding=1)
+                    report(f"conv ring B{B} H{H} {Cin}->{Cout} splits {max(cfg >> 8, 1)}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+                assert torch.equal(y, refs[cfg >> 8]), f"config {cfg:#x} blocked {blocked} bits {bits:#x} differs"
     finally:
         L.gyre_debug_set_wblk_workspace(None, 0)
         L.gyre_debug_set_splitk_workspace(None, 0)
