@@ -14,9 +14,12 @@ int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n);
 int launch_verify_hints(hipStream_t st, const int64_t* t, int B, int check_t, const void* x, size_t bytes_per_half, int check_pairs, int* flag);
 int launch_timestep_embedding(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* out);
 // out[b][n] = sum_k f(x[b][k]) * W[n][k] + bias[n]; x f32 [B][K], W bf16 [N][K], out f32 [B][ldo].  act_in_silu: f = SiLU,
-// and x is OVERWRITTEN with SiLU(x) (its only use on the time-embedding path)
+// and for B > 4 x is OVERWRITTEN with SiLU(x) (its only use on the time-embedding path; B <= 4 applies it on load)
 int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W, const float* bias, int N,
                          int act_in_silu, float* out, int ldo);
+// out[b] = Linear(timestep_embedding(t[b])) - one launch for B <= 4 (emb_scratch [B][dim] floats is used above that)
+int launch_timestep_linear(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* emb_scratch,
+                           const bf16_t* W, const float* bias, int N, float* out, int ldo);
 
 // GroupNorm over NHWC bf16, optional second source for the skip-concat case:
 // channels [0,C1) come from x (pixel stride C1), [C1,C) from x2 (pixel stride C-C1).

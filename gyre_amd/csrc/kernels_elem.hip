@@ -195,9 +195,110 @@ __global__ __launch_bounds__(256) void k_rowvec_linear(const float* __restrict__
             }
     }
 }
+// Round 5, one-image latency: the same dot products for B <= 4 rows (the uniform-timestep call has ONE).  The general kernel
+// above carries 16 row accumulators per column whatever B is - 64 x 6 cross-lane adds per wave for a single row - and the
+// time-embedding chain in front of every UNet call was six dependent launches (embedding, Linear, SiLU, Linear, SiLU, the
+// all-resnets Linear: 91 us of a 5.6 ms batch-2 call, rocprofv3 timeline).  Here the input transform runs on load (INMODE 1:
+// SiLU; INMODE 2: the sinusoidal embedding of t[b] itself, same expressions as k_timestep_embedding), every weight request of
+// the lane (up to 4 k chunks x RV_NPW columns) is in flight before the first multiply, and only ROWS accumulators per column
+// are reduced.  Per column the products are added in the order of the general kernel (k chunks ascending, 8 elements each,
+// then the xor butterfly 32 .. 1): bit-identical outputs (tests/test_gpu_models.py::test_uniform_timestep_fast_path_is_bit_identical
+// compares the B-row tensor form on the general kernel with this one).
+#define RVS_TRIPS 4
+template <int ROWS, int INMODE>
+__global__ __launch_bounds__(256) void k_rowvec_small(const float* __restrict__ x, const int64_t* __restrict__ t, int B, int K,
+                                                      const bf16_t* __restrict__ W, const float* __restrict__ bias, int N,
+                                                      float* __restrict__ out, int ldo, int flip, float shift) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + wave) * RV_NPW;
+    if (n0 >= N) return;
+    float acc[RV_NPW][ROWS];
+#pragma unroll
+    for (int c = 0; c < RV_NPW; ++c)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[c][r] = 0.f;
+    const int half = K / 2;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8 * RVS_TRIPS) {
+        uint4 wv[RVS_TRIPS][RV_NPW];
+#pragma unroll
+        for (int i = 0; i < RVS_TRIPS; ++i) {
+            const int k = k0 + i * 512;
+#pragma unroll
+            for (int c = 0; c < RV_NPW; ++c)
+                if (k < K && n0 + c < N) wv[i][c] = *(const uint4*)(W + (size_t)(n0 + c) * K + k);
+        }
+#pragma unroll
+        for (int i = 0; i < RVS_TRIPS; ++i) {
+            const int k = k0 + i * 512;
+            if (k < K) {
+                float w[RV_NPW][8];
+#pragma unroll
+                for (int c = 0; c < RV_NPW; ++c) {
+                    if (n0 + c < N) unpack8(wv[i][c], w[c]);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[c][j] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    if (r < B) {
+                        float xv[8];
+                        if (INMODE == 2) {
+                            const float tv = (float)t[r];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int jj = k + j;
+                                const int ii = jj < half ? jj : jj - half;
+                                const float freq = expf(-9.210340371976184f * (float)ii / ((float)half - shift));
+                                const float a = tv * freq;
+                                const bool is_cos = flip ? (jj < half) : (jj >= half);
+                                xv[j] = is_cos ? cosf(a) : sinf(a);
+                            }
+                        } else {
+                            const float* xr = x + (size_t)r * K + k;
+                            const float4 x0 = *(const float4*)xr, x1 = *(const float4*)(xr + 4);
+                            xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+                            if (INMODE == 1) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) xv[j] = silu_f(xv[j]);
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < RV_NPW; ++c)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[c][r] = fmaf(xv[j], w[c][j], acc[c][r]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RV_NPW; ++c)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float v = acc[c][r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && r < B && n0 + c < N) out[(size_t)r * ldo + n0 + c] = v + (bias ? bias[n0 + c] : 0.f);
+        }
+}
+template <int INMODE>
+static int launch_rowvec_small(hipStream_t st, const float* x, const int64_t* t, int B, int K, const bf16_t* W, const float* bias,
+                               int N, float* out, int ldo, int flip, float shift) {
+    const dim3 grid((N + 4 * RV_NPW - 1) / (4 * RV_NPW));
+    if (B == 1) hipLaunchKernelGGL((k_rowvec_small<1, INMODE>), grid, dim3(256), 0, st, x, t, B, K, W, bias, N, out, ldo, flip, shift);
+    else if (B == 2) hipLaunchKernelGGL((k_rowvec_small<2, INMODE>), grid, dim3(256), 0, st, x, t, B, K, W, bias, N, out, ldo, flip, shift);
+    else hipLaunchKernelGGL((k_rowvec_small<4, INMODE>), grid, dim3(256), 0, st, x, t, B, K, W, bias, N, out, ldo, flip, shift);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
 int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W, const float* bias, int N,
                          int act_in_silu, float* out, int ldo) {
     if (K % 8) GYRE_FAIL(-1, "rowvec_linear: K must be a multiple of 8");
+    if (B <= 4)                                     // SiLU on load, x left as it is
+        return act_in_silu ? launch_rowvec_small<1>(st, x, nullptr, B, K, W, bias, N, out, ldo, 0, 0.f)
+                           : launch_rowvec_small<0>(st, x, nullptr, B, K, W, bias, N, out, ldo, 0, 0.f);
     if (act_in_silu) {
         const size_t n = (size_t)B * K;
         hipLaunchKernelGGL(k_silu_inplace_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
@@ -206,6 +307,15 @@ int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W
     hipLaunchKernelGGL(k_rowvec_linear, dim3((N + 4 * RV_NPW - 1) / (4 * RV_NPW)), dim3(256), 0, st, x, B, K, W, bias, N, out, ldo);
     GYRE_LAUNCH_CHECK();
     return 0;
+}
+// out[b] = Linear(timestep_embedding(t[b])): the first two launches of the time-embedding chain in one for B <= 4, the two
+// launches otherwise (emb_scratch: [B][dim] floats for that case)
+int launch_timestep_linear(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* emb_scratch,
+                           const bf16_t* W, const float* bias, int N, float* out, int ldo) {
+    if (dim % 16) GYRE_FAIL(-1, "timestep_linear: the embedding width must be a multiple of 16");
+    if (B <= 4) return launch_rowvec_small<2>(st, nullptr, t, B, dim, W, bias, N, out, ldo, flip, shift);
+    if (int rc = launch_timestep_embedding(st, t, B, dim, flip, shift, emb_scratch)) return rc;
+    return launch_rowvec_linear(st, emb_scratch, B, dim, W, bias, N, 0, out, ldo);
 }
 
 // ------------------------------------------------------------------------------

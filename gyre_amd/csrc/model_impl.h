@@ -1131,8 +1131,8 @@ struct gyre_unet {
         if (!dry) {
             TRY(launch_nchw_to_nhwc(st, x, xdt, Bp, c.in_channels, H * W, xin.C, xin.p));
             if (!cached) TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
-            TRY(launch_timestep_embedding(st, t, Bt, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
-            TRY(launch_rowvec_linear(st, (float*)emb.p, Bt, c.block_out_channels[0], te1w, te1b, temb_dim, 0, (float*)t1.p, temb_dim));
+            TRY(launch_timestep_linear(st, t, Bt, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p, te1w, te1b,
+                                       temb_dim, (float*)t1.p, temb_dim));
             TRY(launch_rowvec_linear(st, (float*)t1.p, Bt, temb_dim, te2w, te2b, temb_dim, 1, (float*)t2.p, temb_dim));
             // SDXL-style added conditioning (text_time): emb = time_embedding(t) + aug_emb, aug_emb from the host
             if (temb_add) TRY(launch_add_f32(st, (float*)t2.p, temb_add, (size_t)B * temb_dim));

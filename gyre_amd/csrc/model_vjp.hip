@@ -365,8 +365,8 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
     if (!dry) {
         TRY(launch_nchw_to_nhwc(st, x, xdt, B, c.in_channels, H * W, xin.C, xin.p));
         TRY(launch_ctx_to_bf16(st, ctx, cdt, (size_t)B * S * D, cx.p));
-        TRY(launch_timestep_embedding(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p));
-        TRY(launch_rowvec_linear(st, (float*)emb.p, B, c.block_out_channels[0], u.te1w, u.te1b, u.temb_dim, 0, (float*)t1.p, u.temb_dim));
+        TRY(launch_timestep_linear(st, t, B, c.block_out_channels[0], c.flip_sin_to_cos, c.freq_shift, (float*)emb.p, u.te1w, u.te1b,
+                                   u.temb_dim, (float*)t1.p, u.temb_dim));
         TRY(launch_rowvec_linear(st, (float*)t1.p, B, u.temb_dim, u.te2w, u.te2b, u.temb_dim, 1, (float*)t2.p, u.temb_dim));
         if (temb_add) TRY(launch_add_f32(st, (float*)t2.p, temb_add, (size_t)B * u.temb_dim));
         TRY(launch_rowvec_linear(st, (float*)t2.p, B, u.temb_dim, u.tproj_w, u.tproj_b, u.temb_cols, 1, (float*)tp.p, u.temb_cols));

@@ -208,8 +208,11 @@ def test_context_cache_matches_uncached_and_tracks_changes():
 
 def test_uniform_timestep_fast_path_is_bit_identical():
     """A scalar timestep (what the samplers pass) lets the time-embedding MLP run for one row that every resnet reads
-    (gyre_unet_hint_uniform_timestep): same bits as the per-sample tensor form, at full size and at a ragged batch."""
-    for cfg, B, hw in ((gcfg.tiny_unet(), 3, 16), (gcfg.sd15_unet(), 4, 32)):
+    (gyre_unet_hint_uniform_timestep): same bits as the per-sample tensor form, at full size and at a ragged batch.
+    Round 5: up to four rows take the one-row-specialised kernels of the chain (k_rowvec_small: embedding and SiLU applied on
+    load, three launches instead of six); the B = 6 cases put the general kernels (B rows, separate embedding / SiLU launches)
+    on the tensor side and the specialised ones on the scalar side - same bits."""
+    for cfg, B, hw in ((gcfg.tiny_unet(), 3, 16), (gcfg.sd15_unet(), 4, 32), (gcfg.tiny_unet(), 6, 16), (gcfg.sd15_unet(), 6, 16)):
         net, _ = make_unet(cfg)
         x = randn(B, 4, hw, hw, seed=31).to(DEV)
         ctx = randn(B, 77, cfg.cross_attention_dim, seed=32).to(DEV)
