@@ -165,6 +165,11 @@ bool gemm_w_block_wanted(const GemmParams& p);      // the planner's kernel for 
 // Pure function of the problem shape: tile configuration, K splits and the split-K workspace it needs.
 // The caller allocates `ws_bytes` (or passes none: the launch then falls back to a single split).
 struct GemmPlan { int cfg; int splits; size_t ws_bytes; };
+// 3x3 / stride 1 / zero padding 1 convolution of NHWC bf16 x [B][H][W][C] into O <= 16 channels, written as NCHW of the given
+// runtime dtype (kernels_conv_out.hip): W [O][3][3][C] bf16, bias [O] or null.  conv_out_supports: C % 64 == 0 and the weights fit LDS.
+bool conv_out_supports(int C, int O);
+int launch_conv_out(hipStream_t st, const bf16_t* x, int B, int H, int W, int C, const bf16_t* Wt, const float* bias, int O,
+                    void* out, int out_dtype);
 GemmPlan gemm_plan(const GemmParams& p);
 int launch_gemm(hipStream_t st, const GemmParams& p);
 

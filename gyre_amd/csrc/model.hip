@@ -53,7 +53,7 @@ static const char* kclass_name(int k) {
         "k_gemm<128, 128, 2, 2, 0", "k_gemm<256, 64, 4, 1, 0", "k_gemm<64, 64, 2, 2, 0",
         "k_gemm8<256, 320, 4, 2, 1", "k_gemm8<128, 320, 2, 4, 1", "k_gemm8<256, 256, 4, 2, 1", "k_gemm8<128, 256, 2, 4, 1",
         "k_gemm8<256, 320, 4, 2, 0", "k_gemm8<128, 320, 2, 4, 0", "k_gemm8<256, 256, 4, 2, 0", "k_gemm8<128, 256, 2, 4, 0",
-        "k_gemm8<128, 160, 4, 2, 1", "k_gemm8<256, 128, 4, 2, 1", "(unused 2)", "(unused 3)", "k_gemm8<128, 160, 4, 2, 0",
+        "k_gemm8<128, 160, 4, 2, 1", "k_gemm8<256, 128, 4, 2, 1", "k_conv_out", "(unused 3)", "k_gemm8<128, 160, 4, 2, 0",
         "k_gemm4s<192, 320, 2, 2, 1", "k_gemm4s<192, 320, 2, 2, 0", "k_gemm4s<256, 256, 2, 2, 1", "k_gemm4s<256, 256, 2, 2, 0",
         "k_gemm4s<128, 320, 2, 2, 1", "k_gemm4s<128, 320, 2, 2, 0", "k_gemm4s<128, 256, 2, 2, 1", "k_gemm4s<128, 256, 2, 2, 0", "k_gemm4s<256, 320, 4, 2, 1", "k_gemm4s<256, 320, 4, 2, 0",
         "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other", "k_attn_bwd", "k_gn_bwd+k_ln_bwd",
@@ -450,6 +450,17 @@ int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, con
     p.stride = stride; p.pad = pad; p.ups = ups; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * Ho * Wo; p.samples = B;
     p.bias = bias; p.residual = (const bf16_t*)residual; p.ldr = Cout; p.rows_per_sample = Ho * Wo;
     p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
+    return launch_gemm((hipStream_t)st, p);
+}
+int gyre_op_conv3x3_nchw(void* st, const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const float* bias, void* y,
+                         int y_dtype, int force_tiles) {
+    if (!x || !w || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (!force_tiles && conv_out_supports(Cin, Cout))
+        return launch_conv_out((hipStream_t)st, (const bf16_t*)x, B, H, W, Cin, (const bf16_t*)w, bias, Cout, y, y_dtype);
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = Cin; p.mode = GEMM_CONV3; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Ho = H; p.Wo = W;
+    p.stride = 1; p.pad = 1; p.W = (const bf16_t*)w; p.K = 9 * Cin; p.N = Cout; p.M = B * H * W; p.samples = B;
+    p.bias = bias; p.rows_per_sample = H * W; p.out = y; p.out_mode = OUT_NCHW; p.out_dtype = y_dtype;
     return launch_gemm((hipStream_t)st, p);
 }
 // The same operators leaving the GroupNorm statistics of their output (GemmParams::colstat_out): stats_out

@@ -443,6 +443,9 @@ struct Exec {
     // final 3x3 conv straight to the caller's NCHW buffer
     int conv3_nchw(const Tn& x, const ConvW& w, void* out, int out_dtype) {
         if (dry()) return 0;
+        // the dedicated kernel (kernels_conv_out.hip): zero padding only - a tiling request keeps the tile kernels' circular gather
+        if (!tiling && conv_out_supports(x.C, w.cout))
+            return launch_conv_out(st, x.p, x.B, x.H, x.W, x.C, w.w, w.b, w.cout, out, out_dtype);
         GemmParams p;
         p.A = x.p; p.lda = x.C; p.mode = GEMM_CONV3;
         p.Hi = x.H; p.Wi = x.W; p.Cin = x.C; p.Ho = x.H; p.Wo = x.W; p.stride = 1; p.pad = 1;

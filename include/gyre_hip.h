@@ -369,6 +369,11 @@ int gyre_op_linear_t(void* stream, const void* x, int M, int K, const void* w_bf
  * of the input; stride 1|2; pad 1 (pad 0 + bottom/right zero pad when asym!=0, VAE downsample). */
 int gyre_op_conv3x3(void* stream, const void* x, int B, int Hi, int Wi, int Cin, const void* w_krsc, int Cout,
                     const float* bias, const void* residual, int stride, int ups, int asym, void* y);
+/* The output convolution of the UNet / VAE decoder (3x3, stride 1, zero padding 1, Cout <= 16) written as NCHW y
+ * [B][Cout][H][W] of dtype y_dtype (0 f32, 1 bf16, 2 f16), as the models' last launch does: the dedicated kernel
+ * (kernels_conv_out.hip) where Cin % 64 == 0, the tile kernels otherwise; force_tiles != 0 takes the tile kernels anyway. */
+int gyre_op_conv3x3_nchw(void* stream, const void* x, int B, int H, int W, int Cin, const void* w_krsc, int Cout,
+                         const float* bias, void* y, int y_dtype, int force_tiles);
 /* Repack helpers used by the tests to build the layouts above from PyTorch-layout f32 tensors */
 int gyre_op_repack_conv_weight(void* stream, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cin_pad,
                                void* w_krsc_bf16);

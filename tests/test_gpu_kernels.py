@@ -174,6 +174,41 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups, asym, res):
     report(f"conv3x3 {B}x{H}x{W} {Cin}->{Cout} s{stride} ups{ups} asym{asym}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dt", [
+    (2, 64, 64, 320, 4, torch.float32), (16, 64, 64, 320, 4, torch.bfloat16), (1, 96, 96, 320, 4, torch.float16),
+    (3, 13, 21, 320, 4, torch.float32), (1, 8, 8, 64, 1, torch.float32), (2, 40, 24, 128, 3, torch.float32),
+    (1, 64, 64, 192, 9, torch.float32), (2, 16, 16, 32, 4, torch.float32),
+])
+def test_conv_out_nchw(B, H, W, Cin, Cout, dt):
+    """The models' output convolution (UNet conv_out 320 -> 4, VAE decoder conv_out 128 -> 3; reference call sites
+    unet/core.py:274, unified_pipeline.py:1531) on its dedicated kernel (kernels_conv_out.hip; round 5): against F.conv2d, against
+    the tile kernels it replaces, at image sizes that are no multiple of its 8 x 8 tile, in the three boundary dtypes, and (Cin = 32)
+    the shapes that still take the tile kernels.  Bit-reproducible, and a sample's result does not depend on the batch around it."""
+    L = _lib.lib()
+    x = bf16_round(randn(B, Cin, H, W, seed=26))
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=27) / math.sqrt(9 * Cin))
+    b = randn(Cout, seed=28)
+    ref = F.conv2d(x, w, b, padding=1)
+    xd, wd, bd = to_dev_bf16(nhwc(x)), repack_conv(w), b.to(DEV)
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dt]
+    tol = TOL if dt == torch.float32 else 2 * TOL
+    y = torch.full((B, Cout, H, W), float("nan"), dtype=dt, device=DEV)
+    _lib.check(L.gyre_op_conv3x3_nchw(st(), vp(xd), B, H, W, Cin, vp(wd), Cout, vp(bd), vp(y), code, 0))
+    report(f"conv_out {B}x{H}x{W} {Cin}->{Cout} {dt}", y.float().cpu(), ref, tol)
+    y2 = torch.full_like(y, float("nan"))
+    _lib.check(L.gyre_op_conv3x3_nchw(st(), vp(xd), B, H, W, Cin, vp(wd), Cout, vp(bd), vp(y2), code, 0))
+    assert torch.equal(y, y2)
+    yt = torch.full_like(y, float("nan"))
+    _lib.check(L.gyre_op_conv3x3_nchw(st(), vp(xd), B, H, W, Cin, vp(wd), Cout, vp(bd), vp(yt), code, 1))     # the tile kernels
+    report(f"conv_out vs tile kernels {B}x{H}x{W} {Cin}->{Cout}", y.float().cpu(), yt.float().cpu(), tol)
+    if Cin % 64 == 0:                                # same K order (64-channel chunks, taps inside, two MFMA steps per tap): same bits
+        assert torch.equal(y, yt)
+    if B > 1:                                        # the last sample alone: same bits as inside the batch
+        y1 = torch.full((1, Cout, H, W), float("nan"), dtype=dt, device=DEV)
+        _lib.check(L.gyre_op_conv3x3_nchw(st(), vp(xd[B - 1:].contiguous()), 1, H, W, Cin, vp(wd), Cout, vp(bd), vp(y1), code, 0))
+        assert torch.equal(y1[0], y[B - 1])
+
+
 def test_conv3x3_padded_cin():
     """Cin=4 latents are zero-padded to 8 channels at the NCHW boundary; weights repacked with the same pad."""
     L = _lib.lib()
