@@ -526,7 +526,9 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
         }
     };
     bool ring_done = false;
-    if constexpr (MODE == GEMM_LINEAR || (UNIFORM_TAP && BM == 128 && BN == 160)) {      // (conv ring: the 128x160 tile only - the 256x320 instance spills with it)
+    // (conv ring: the 128x160 tile and the VAE's 256x128 one - three 48 KB stages fit a CU; the 256x320 instance spills with it, the
+    //  256x256 one has no room for a third stage)
+    if constexpr (MODE == GEMM_LINEAR || (UNIFORM_TAP && ((BM == 128 && BN == 160) || (BM == 256 && BN == 128)))) {
         // Round 5: the K loop of the linear problems as an nst-deep LDS ring (nst = 2 ... 4, chosen by the launcher from the LDS a
         // workgroup may take), nst - 1 stages IN FLIGHT while one is multiplied.  The two-stage loop below requests stage k+1,
         // multiplies stage k and then waits for everything: one exposed memory latency per 64-deep K step - with the weights of a
@@ -1242,7 +1244,7 @@ static int launch_cfg8(hipStream_t st, const GemmParams& p, int kcls_base, int s
     // (tuning bit 24: the two-stage loop everywhere; bit 25: the deep ring also where two 2-stage workgroups would fit)
     const size_t stage = (size_t)(BM + (BN + 63) / 64 * 64) * 128;
     int nst = 2;
-    const bool conv_ring = BM == 128 && BN == 160 && p.mode == GEMM_CONV3 && p.Cin % BK == 0 && p.C1 % BK == 0 && p.K % BK == 0 && !(p.debug & 0x8000000);
+    const bool conv_ring = ((BM == 128 && BN == 160) || (BM == 256 && BN == 128)) && p.mode == GEMM_CONV3 && p.Cin % BK == 0 && p.C1 % BK == 0 && p.K % BK == 0 && !(p.debug & 0x8000000);
     if ((p.mode == GEMM_LINEAR && !(p.debug & 0x1000000)) || conv_ring) {
         const int fit1 = (int)std::min<size_t>(4, (size_t)160 * 1024 / stage);
         const bool two_fit = 4 * stage <= (size_t)160 * 1024;
