@@ -312,8 +312,7 @@ int launch_rowvec_linear(hipStream_t st, float* x, int B, int K, const bf16_t* W
 // launches otherwise (emb_scratch: [B][dim] floats for that case)
 int launch_timestep_linear(hipStream_t st, const int64_t* t, int B, int dim, int flip, float shift, float* emb_scratch,
                            const bf16_t* W, const float* bias, int N, float* out, int ldo) {
-    if (dim % 16) GYRE_FAIL(-1, "timestep_linear: the embedding width must be a multiple of 16");
-    if (B <= 4) return launch_rowvec_small<2>(st, nullptr, t, B, dim, W, bias, N, out, ldo, flip, shift);
+    if (B <= 4 && dim % 8 == 0) return launch_rowvec_small<2>(st, nullptr, t, B, dim, W, bias, N, out, ldo, flip, shift);
     if (int rc = launch_timestep_embedding(st, t, B, dim, flip, shift, emb_scratch)) return rc;
     return launch_rowvec_linear(st, emb_scratch, B, dim, W, bias, N, 0, out, ldo);
 }
