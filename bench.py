@@ -369,6 +369,7 @@ def main():
     clocks = ClockSampler() if rank == 0 else None
     if clocks:
         clocks.start()
+    redo0 = _lib.lib().gyre_debug_attn_redo_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
         s0 = time.perf_counter()
@@ -378,6 +379,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     clock_info = clocks.stop() if clocks else None
+    redo1 = _lib.lib().gyre_debug_attn_redo_count()
     prof = _lib.prof_collect()
     _lib.prof_enable([])
     if images is not None:
@@ -430,6 +432,30 @@ def main():
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # ---- the same steps with the attention kernel's per-tile overflow check in EVERY tile (variant 7), after the timed region:
+    # the default pass is optimistic (a workgroup whose row sums leave (0, 2^60) repeats its tile with the checked pass - bit-identical
+    # results either way), so on data whose logits trip the bound the default can cost up to checked + optimistic; this is the
+    # data-INDEPENDENT figure, `attn_redo_count` says how far the timed region was from it (0 = no workgroup repeated anything)
+    checked = None
+    if args.config == "sd15":
+        n_chk = min(2, args.steps)
+        old_variant = _lib.lib().gyre_debug_force_attn_variant(7)
+        try:
+            step(args.steps + 1)                                    # warm-up (nothing to plan: same shapes, same workspace)
+            barrier()
+            c0 = time.perf_counter()
+            for i in range(n_chk):
+                step(args.steps + 2 + i)
+            barrier()
+            c_chk = time.perf_counter() - c0
+        finally:
+            _lib.lib().gyre_debug_force_attn_variant(old_variant)
+        if world > 1:
+            tt = torch.tensor([c_chk], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            c_chk = float(tt.item())
+        checked = (sum(sizes) * n_chk / c_chk, n_chk)
 
     # one extra, fully instrumented step (outside the timed region): the per-class table
     classes = None
@@ -506,6 +532,15 @@ def main():
             "roofline": roof,
         }
         out.update(latency)
+        out["attn_redo_count"] = (redo1 - redo0) if (redo0 >= 0 and redo1 >= 0) else None
+        out["attn_redo_note"] = ("attention workgroups of rank 0's device that repeated their tile with the checked pass during the timed "
+                                 "region (gyre_debug_attn_redo_count; of ~%d k_attn3 workgroups per step)" % (evals * 5 * 4096 if args.config == "sd15" else 0))
+        if checked:
+            out["value_checked_attention"] = round(checked[0], 4)
+            out["value_checked_attention_note"] = (f"images/s of {checked[1]} further step(s) with the per-tile overflow check in every attention tile "
+                                                   f"(gyre_debug_force_attn_variant(7)): the data-independent form; outputs are bit-identical to the default's")
+        if clock_info and clock_info.get("sclk_mhz_median"):
+            out["images_per_s_per_ghz"] = round(value / (clock_info["sclk_mhz_median"] / 1000.0), 3)
         if per_img:
             # CFG-parallel calls share the part of the network in front of the first cross-attention between the two halves of
             # the batch (gyre_unet_hint_cfg_pairs): conv_in, the first resnet, proj_in, Q|K|V, the 64x64 self-attention and its
@@ -535,6 +570,20 @@ def main():
                             "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                             "gbps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBPS, 4)}
             out["kernel_classes"] = table
+            fams = {"k_gemm8 (non-pipelined tile GEMMs / convs)": ("k_gemm8<",), "k_gemm4s (pipelined convs / long-K GEMMs)": ("k_gemm4s<",),
+                    "k_attn": ("k_attn",), "k_gemm_ar": ("k_gemm_ar",), "k_gemm_sm + 4-wave k_gemm": ("k_gemm_sm", "k_gemm<"),
+                    "GroupNorm (k_gn_*)": ("k_gn_",), "split-K reduction": ("k_splitk",), "LayerNorm": ("k_layernorm",)}
+            fam = {}
+            for fname, prefixes in fams.items():
+                sel = [v for k, v in classes.items() if any(k.startswith(p_) for p_ in prefixes)]
+                if sel:
+                    ms_ = sum(v["ms"] for v in sel)
+                    tf = sum(v["flops"] for v in sel) / max(ms_, 1e-9) / 1e9
+                    gb = sum(v["bytes"] for v in sel) / max(ms_, 1e-9) / 1e6
+                    fam[fname] = {"launches": sum(v["launches"] for v in sel), "ms": round(ms_, 2), "share": round(ms_ / tot, 4),
+                                  "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4), "hbm_frac": round(gb / HBM_PEAK_GBPS, 4)}
+            fam["GroupNorm + split-K share"] = round(sum(v["ms"] for k, v in classes.items() if k.startswith(("k_gn_", "k_splitk"))) / tot, 4)
+            out["kernel_families"] = fam
             out["kernel_classes_note"] = (f"HIP-event time per kernel class in one extra fully instrumented step after the timed region "
                                           f"({c_el * 1e3:.0f} ms wall, sum of classes {tot:.0f} ms); tflops / gbps = algorithmic FLOPs / bytes "
                                           f"of the unpadded problems over event-to-event time")

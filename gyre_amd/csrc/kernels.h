@@ -183,7 +183,7 @@ struct AttnParams {
     int B, H, Nq, Nk, D;
     int k_prescaled = 0;        // K already carries log2(e)/sqrt(D) (folded into the to_k weights at repack time)
     int always_check = 0;       // tuning (k_attn3): keep the per-tile overflow check instead of the optimistic first pass
-    unsigned* redo_counter = nullptr;   // tuning: incremented by every workgroup that repeats its pass (GYRE_ATTN_COUNT_REDO)
+    unsigned* redo_counter = nullptr;   // incremented by every workgroup that repeats its pass (per device; gyre_debug_attn_redo_count)
 };
 int launch_attention(hipStream_t st, const AttnParams& p);
 

@@ -967,8 +967,14 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
     // the loop sits at 256 registers + 9 spilled SGPRs and its redo faulted on the GPU in round 4 (address 0, never isolated); ONE
     // copy with a run-time flag around the check, inside a retry loop, was tried in round 5 and spills for every head dim (the
     // whole kernel becomes a loop body: 24 - 112 spilled VGPRs) - so D >= 64 keeps the checked pass it has always had.
-    // The end-of-pass test accepts a row only if its sum is finite, positive and below 1e25: then no p exceeded 2^83 and O (sums of
-    // p * v) is as far from overflow as the checked pass keeps it (p <= 2^60 per re-centred row, times Nk).
+    // The end-of-pass test accepts a row only if its sum is finite, positive and below 2^TAU (round 6; 1e25 ~ 2^83 before): then no p
+    // reached 2^TAU, i.e. no score of the row exceeded its first-tile reference by TAU - exactly the condition under which the checked
+    // pass never takes its re-centring branch after the first tile.  A workgroup whose rows are all accepted has therefore executed
+    // the checked pass's arithmetic instruction for instruction, and a workgroup with one rejected row REPEATS its tile with the
+    // checked pass: the default path is bit-identical to variant 7 (always checked) on EVERY input, the data only decides how many
+    // workgroups pay twice (gyre_debug_attn_redo_count; 0 on the synthetic weights, bench.py prints it).  With the old bound a row
+    // whose excess lay between 2^60 and 2^83 was accepted here and re-centred there: equal to rounding, not to the bit.
+    // (p rounds to bf16 monotonically and 2^TAU is representable, so a score above TAU always leaves a sum >= 2^TAU.)
     constexpr bool OPTIMISTIC = D <= 40;
     if (!OPTIMISTIC || p.always_check) pass(T, T);
     else {
@@ -977,7 +983,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
 #pragma unroll
         for (int qi = 0; qi < QI; ++qi) {
             const float l = row_sum(qi);
-            bad |= (q0 + qi * 16 + fr < p.Nq) && !(l > 0.f && l < 1.0e25f);
+            bad |= (q0 + qi * 16 + fr < p.Nq) && !(l > 0.f && l < 1.152921504606846976e18f);      // 2^TAU, TAU = 60
         }
         const bool wave_bad = __any(bad);
         int* flags = (int*)smem;                        // four words of ring slot 0, used between the two passes only
@@ -1021,23 +1027,23 @@ static const bf16_t* attn_zero_page() {
     std::lock_guard<std::mutex> g(mu);
     auto it = pages.find(dev);
     if (it != pages.end()) return (const bf16_t*)it->second;
-    void* p = nullptr;   // 256 B of zeros followed by 256 B of bf16 ones (0x3f80)
-    if (hipMalloc(&p, 512) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    void* p = nullptr;   // 256 B of zeros followed by 256 B of bf16 ones (0x3f80), then the device's redo counter (one zeroed word)
+    if (hipMalloc(&p, 512 + 16) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess || hipMemset((char*)p + 512, 0, 16) != hipSuccess) return nullptr;
     if (hipMemsetD16((hipDeviceptr_t)((char*)p + 256), 0x3f80, 128) != hipSuccess) return nullptr;
     (void)hipDeviceSynchronize();
     pages[dev] = p;
     return (const bf16_t*)p;
 }
 
-// tuning: device counter of workgroups that repeated their pass with the per-tile check (GYRE_ATTN_COUNT_REDO=1; one per process)
-static unsigned* attn_redo_counter(bool create) {
-    static unsigned* ctr = nullptr;
-    static const bool on = getenv("GYRE_ATTN_COUNT_REDO") != nullptr;
-    if (on && !ctr && create) { if (hipMalloc((void**)&ctr, 4) != hipSuccess) ctr = nullptr; else (void)hipMemset(ctr, 0, 4); }
-    return ctr;
+// Device counter of the workgroups that repeated their pass with the per-tile check (round 6: always on, one word per device behind
+// that device's zero / ones page - the increment only happens on the redo path, so counting costs the optimistic pass nothing;
+// bench.py prints the count of its timed region as `attn_redo_count`)
+static unsigned* attn_redo_counter() {
+    const bf16_t* page = attn_zero_page();
+    return page ? (unsigned*)((char*)page + 512) : nullptr;
 }
 extern "C" long gyre_debug_attn_redo_count() {
-    unsigned* c = attn_redo_counter(true);
+    unsigned* c = attn_redo_counter();
     if (!c) return -1;
     unsigned v = 0;
     if (hipMemcpy(&v, c, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -1110,7 +1116,7 @@ static int launch_attn3_t(hipStream_t st, const AttnParams& p) {
     AttnParams q = p;
     // optimistic first pass by default (variant 7 = always the per-tile check; 8 = a synonym of the default, kept for the tools)
     q.always_check = (g_attn_variant & 255) == 7 ? 1 : 0;
-    q.redo_counter = attn_redo_counter(false);
+    q.redo_counter = (unsigned*)((char*)zero + 512);        // the device's counter sits behind its zero / ones page
 #ifdef GYRE_ATTN_ABLATIONS
     if constexpr (D == 40) {
         const int abl = g_attn_variant >> 8;              // gyre_debug_force_attn_variant(abl << 8)

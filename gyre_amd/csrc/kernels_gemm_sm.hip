@@ -107,8 +107,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
     const int swa = (ra >> 1) & 7, sww = (rw >> 1) & 7;
     f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt landed for this wave (younger requests: stages kt + 1, kt + 2), then for every wave; slot (kt - 1) % NS is free
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        // stage kt landed for this wave (younger requests: stages kt + 1, kt + 2), then for every wave; slot (kt - 1) % NS is free.
+        // lgkmcnt(0) IN FRONT of the barrier (round 6, the ring discipline of k_gemm8 / kernels_attn.hip): the refill issued right
+        // behind this barrier targets slot (kt + 3) % NS == (kt - 1) % NS, the slot step kt - 1 just read, and hipcc may sink the last
+        // MFMAs of that step together with the lgkmcnt wait in front of them BELOW the barrier (the builtin orders memory operations,
+        // not register-only MFMAs or compiler-derived waits) - a wave could then pass the barrier with ds_reads of the slot still
+        // queued while another wave's LDS-DMA for the same slot is on its way.  Every fragment read of this wave has returned here.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(kt + 3, (kt + 3) % NS);
         const char* st = smem + (kt % NS) * STAGE;

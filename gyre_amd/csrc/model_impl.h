@@ -127,16 +127,26 @@ struct Store {
         return en.p;
     }
     // blocked copies of the weights the LDS-DMA tile kernels read (GemmParams::W_blk), keyed like the packed copies above
+    // Memory: one extra copy (N * K * 2 bytes) of every weight the planner routes to an LDS-DMA tile with K > 1024 - nearly all 3x3
+    // convs and FF layers: ~1.6 GB per SD1.5 UNet handle, ~0.15 GB per VAE handle, per device-slot replica.  The copy is
+    // an optimisation only: when it cannot be allocated the launch reads the row-major weights (nullptr here, prep_blk goes on).
     std::unordered_map<const void*, WtEntry> blk_cache;
     bf16_t* blk_lookup(const void* w, size_t bytes, bool* fresh) {
         WtEntry& en = blk_cache[w];
         if (!en.p || en.bytes < bytes) {
+            if (en.p) dfree(en.p);                               // superseded (smaller) buffer: released now, not at Store destruction
             en.p = (bf16_t*)dmalloc(bytes, false);
-            en.bytes = bytes; en.version = 0;
+            en.bytes = en.p ? bytes : 0; en.version = 0;
         }
         *fresh = en.p && en.version == weights_version;
         if (en.p) en.version = weights_version;
         return en.p;
+    }
+    // release one dmalloc'ed buffer early (after the device has finished with it: a superseded cache copy is only replaced between
+    // calls of its handle, but kernels of the previous call may still be queued on the stream)
+    void dfree(void* ptr) {
+        for (size_t i = 0; i < allocs.size(); ++i)
+            if (allocs[i] == ptr) { allocs[i] = allocs.back(); allocs.pop_back(); (void)hipDeviceSynchronize(); (void)hipFree(ptr); return; }
     }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
     // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
@@ -398,7 +408,7 @@ struct Exec {
         if (dry() || !store || p.W_blk || !gemm_w_block_wanted(p)) return 0;
         bool fresh = false;
         bf16_t* b = store->blk_lookup(p.W, (size_t)p.N * p.K * 2, &fresh);
-        if (!b) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the blocked weight copy");
+        if (!b) { (void)hipGetLastError(); return 0; }           // no memory for the copy: the kernels read the row-major weights (W_blk stays null)
         if (!fresh) TRY(launch_w_block(st, p.W, p.N, p.K, b));
         p.W_blk = b;
         return 0;

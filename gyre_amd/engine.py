@@ -335,7 +335,13 @@ class GyreUnifiedPipeline:
         if scheduler_noise_type not in (None, "normal", "brownian"):
             raise ValueError(f"scheduler_noise_type must be 'normal' or 'brownian', got {scheduler_noise_type!r}")
         # `latents`: accepted and IGNORED, as in the reference - UnifiedPipeline.__call__ declares and documents the keyword
-        # (unified_pipeline.py:1749,1807-1810) but never reads it; start latents always come from the per-image generators
+        # (unified_pipeline.py:1749,1807-1810) but never reads it; start latents always come from the per-image generators.
+        # A caller that passes start latents gets an image unrelated to them, so say it once per call (parity kept, silence not)
+        if latents is not None:
+            import warnings
+            warnings.warn("GyreUnifiedPipeline: the `latents` argument is accepted for signature compatibility and ignored (as in the "
+                          "reference, unified_pipeline.py:1749); start latents come from the per-image generators / seeds",
+                          RuntimeWarning, stacklevel=2)
         if self.scheduler is None:
             raise ValueError("no scheduler injected")
         n_prompts = len(prompt.prompts) if hasattr(prompt, "prompts") else (len(prompt) if isinstance(prompt, (list, tuple)) else 1)

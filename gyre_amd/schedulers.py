@@ -112,12 +112,17 @@ class BrownianTreeNoiseSampler:
         return w
 
     def __call__(self, sigma, sigma_next) -> Tensor:
+        """(W(sigma_next) - W(sigma)) / sqrt|sigma_next - sigma|: the SIGNED increment, as k-diffusion returns it (its sort() takes the
+        end points in ascending order for torchsde and multiplies the sign back in), so a reversed interval negates the noise.
+        End points outside the tree's [t0, t1] are clamped to it (k-diffusion builds the tree over the positive sigmas only and
+        asks for noise only in front of a positive sigma_next) and the increment is normalised by the CLAMPED interval, so the
+        result keeps unit variance."""
         ta, tb = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
+        ta, tb = min(max(ta, self.t0), self.t1), min(max(tb, self.t0), self.t1)
         if ta == tb:
             raise ValueError("BrownianTreeNoiseSampler: empty interval")
-        lo, hi = (ta, tb) if ta < tb else (tb, ta)
-        scale = 1.0 / abs(tb - ta) ** 0.5                        # the sign of the interval cancels as in k-diffusion's sort()
-        out = torch.stack([(self._w(i, hi) - self._w(i, lo)) * scale for i in range(len(self.seeds))])
+        scale = 1.0 / abs(tb - ta) ** 0.5
+        out = torch.stack([(self._w(i, tb) - self._w(i, ta)) * scale for i in range(len(self.seeds))])
         return out.to(self.device, self.dtype)
 
 

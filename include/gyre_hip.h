@@ -268,12 +268,14 @@ int gyre_debug_set_wblk_workspace(void* ws_dev, size_t bytes);
  * query rows per wave; with prescaled K: 3 = folded-softmax v2 kernel, 5 = software-pipelined v3 kernel (head dims
  * 16/32/40/64); 6 = automatic without the several-query-blocks-per-workgroup form of short key sequences; 7 = automatic with the
  * pipelined kernel's per-tile overflow check in every tile (the round-3 kernel); 0 / 8 = automatic: head dims <= 40 run the optimistic
- * first pass (no per-tile check; a workgroup whose row sums leave (0, 1e25) repeats its pass with the check).  The round-4
+ * first pass (no per-tile check; a workgroup whose row sums leave (0, 2^60) repeats its pass with the check - since round 6 that
+ * bound equals the checked pass's re-centring threshold, so the default is bit-identical to variant 7 on every input).  The round-4
  * non-reproducibility of that pass under concurrent handles was a ring-slot hazard, fixed in round 5 (kernels_attn.hip header).
  * Returns the previous value. */
 int gyre_debug_force_attn_variant(int v);
-/* Tuning only: with GYRE_ATTN_COUNT_REDO=1 in the environment, the number of attention workgroups that have repeated their pass with
- * the per-tile overflow check so far in this process (the first call creates the counter; -1: counting is off). */
+/* The number of attention workgroups on the CURRENT device that have repeated their pass with the per-tile overflow check so far in
+ * this process (always counted since round 6: the increment sits on the redo path only; one blocking 4-byte read-back per call;
+ * -1: no device / allocation failure).  bench.py reports the count of its timed region as `attn_redo_count`. */
 long gyre_debug_attn_redo_count(void);
 /* Tuning only.  Ablations (results are garbage): bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs,
  * bit2 = no epilogue.  Planner switches for same-box A/B runs (results stay valid): bit8 = default tile order, bit9 = conv

@@ -202,7 +202,8 @@ def test_engine_cancellation_between_unet_calls(tiny_engine):
     # `latents`: declared and documented by the reference's __call__ (unified_pipeline.py:1749,1807-1810) but never read - same here
     kw = wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3)
     kw["latents"] = torch.full((1, 4, 16, 16), 7.0)
-    ignored, _ = eng(**kw)
+    with pytest.warns(RuntimeWarning, match="latents"):            # ... but not silently (round 6)
+        ignored, _ = eng(**kw)
     assert torch.equal(ignored, images)
     # tiling (unified_pipeline.py:1671-1712, :1845): a request option the native conv gather serves; the next request is plain again
     tiled, _ = eng(**wrapper_kwargs(prompt=["a"], generator=generators([1]), width=128, height=128, num_inference_steps=3, tiling=True))

@@ -496,3 +496,50 @@ def test_tiling_circular_convolutions_match_the_reference_patch(mode):
         unet.set_tiling(False); vae.set_tiling(False)
     back = unet(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.cpu()
     assert torch.equal(back, plain)
+
+
+def test_sd_like_attention_logits_through_the_unet_redo_path_gives_the_checked_bits():
+    """Round 6 (verdict item 3): the default self-attention pass is optimistic - rows centred on the first key tile, no per-tile
+    check, a workgroup whose row sums leave (0, 2^60) repeats its tile with the checked pass - and every measurement so far ran on
+    N(0, 1/fan_in) weights whose logits never come near that.  Here the logits are SD-like THROUGH THE UNET PATH: a D = 40 UNet
+    (SD1.5's head dim at the 64x64 level) whose first-level self-attentions get to_k = to_q = 3 x the synthetic weights: off-diagonal
+    scores ~ N(0, 9^2) natural units (row maxima 30 - 45 over 1024 keys), the diagonal |q_i|^2 / sqrt(D) ~ 57 +- 13 with a tail beyond
+    88 - a continuum of excesses over the first tile's maximum, below, inside and above the band the old bound (1e25) accepted and
+    the checked pass re-centred.  Asserts: workgroups did repeat their pass (the redo path ran inside gyre_unet_forward), the output
+    is finite and BIT-equal to the always-checked pass (variant 7), and both sit at the usual distance from the fp32 oracle."""
+    from gyre_amd.config import UNetConfig
+    L = _lib.lib()
+    cfg = UNetConfig(block_out_channels=(160, 160, 320, 320), num_heads=(4, 4, 8, 8), cross_attention_dim=64, sample_size=32)
+    sd = weights.synthetic_state_dict(weights.unet_param_shapes(cfg), 0)
+    for name in list(sd):
+        if name.endswith("attn1.to_q.weight") and (name.startswith("down_blocks.0.") or name.startswith("up_blocks.3.")):
+            sd[name] = sd[name] * 3.0
+            sd[name.replace("to_q", "to_k")] = sd[name].clone()
+    net = GyreHipUNet(cfg)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    x = randn(2, 4, 32, 32, seed=31)
+    t = torch.tensor([700, 700])
+    ctx = randn(2, 77, cfg.cross_attention_dim, seed=32)
+    ref = M.unet_forward(sd, cfg, x, t, ctx)
+    # what the logits of the first such attention look like (oracle tap-free estimate from the weights' construction is not needed:
+    # measure them on the oracle's own hidden states through the public block functions would couple the test to oracle internals;
+    # the redo counter below is the evidence that rows crossed the bound)
+    c0 = L.gyre_debug_attn_redo_count()
+    assert c0 >= 0
+    got = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+    torch.cuda.synchronize()
+    c1 = L.gyre_debug_attn_redo_count()
+    old = L.gyre_debug_force_attn_variant(7)
+    try:
+        chk = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
+        torch.cuda.synchronize()
+    finally:
+        L.gyre_debug_force_attn_variant(old)
+    c2 = L.gyre_debug_attn_redo_count()
+    print(f"[redo] workgroups that repeated their pass: default {c1 - c0}, always-checked {c2 - c1}")
+    assert c1 - c0 > 0, "the SD-like logits were meant to push rows over the acceptance bound"
+    assert c2 == c1, "the always-checked pass never repeats"
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got, chk), "optimistic default differs from the always-checked pass"
+    report("D=40 UNet with SD-like self-attention logits", got.cpu(), ref, 3e-2)

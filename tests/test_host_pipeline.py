@@ -597,7 +597,9 @@ def test_brownian_noise_sampler_properties_and_pipeline_option(tiny):
     assert torch.allclose(w_ab + w_bc, w_ac, atol=1e-5)                       # one path: increments add up
     ns2 = mk()
     assert torch.equal(ns2(b, c) * span(b, c), w_bc) and torch.equal(ns2(a, b) * span(a, b), w_ab)    # query order is irrelevant
-    assert torch.equal(ns(c, b), ns(b, c))                                    # k-diffusion's sort(): the signs cancel
+    assert torch.equal(ns(c, b), -ns(b, c))                                   # k-diffusion's convention: W(next) - W(cur), signed
+    # end points outside the tree are clamped and the increment is normalised by the clamped interval (unit variance kept)
+    assert torch.equal(ns(b, 0.0), ns(b, 0.03)) and torch.equal(ns(20.0, b), ns(14.6, b))
     assert torch.equal(mk((22,), x[:1])(a, b)[0], ns(a, b)[1])                # per-image trees
     assert not torch.equal(ns(a, b)[0], ns(a, b)[1])
     # unit variance, zero mean, independent disjoint steps

@@ -1,7 +1,6 @@
 """How often does the pipelined attention kernel repeat its pass (overflow of the optimistic first pass) in the real sampling
-loop?  One bench-like request (SD1.5 512^2, CFG, N steps) with GYRE_ATTN_COUNT_REDO=1."""
+loop?  One bench-like request (SD1.5 512^2, CFG, N steps) (the counter is always on since round 6)."""
 import os, sys
-os.environ["GYRE_ATTN_COUNT_REDO"] = "1"
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 sys.argv = [sys.argv[0]]

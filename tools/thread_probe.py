@@ -5,7 +5,7 @@ import test_gpu_threads as T
 from gyre_amd import config as gcfg, _lib
 cfg = gcfg.sd15_unet()
 bits = int(os.environ.get("BITS", "0"), 0)
-_lib.lib().gyre_debug_attn_redo_count()          # (creates the counter when GYRE_ATTN_COUNT_REDO is set)
+_lib.lib().gyre_debug_attn_redo_count()          # (the counter is always on since round 6)
 nets = [T._unet(cfg, 0), T._unet(cfg, 1)]
 ins = [[T._inputs(cfg, 2, 64, 10 * k + i) for i in range(2)] for k in range(2)]
 def job(k):
