@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--tome-r", type=int, default=1024, help="tomeclip: keys / values merged per self-attention (clipped to N/2)")
     ap.add_argument("--clip-scale", type=float, default=0.2, help="tomeclip: clip_guidance_scale")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="16-bit storage type of activations / weights (fp32 accumulation in both): bf16 = libgyre_hip.so (default), "
+                         "fp16 = libgyre_hip_f16.so, the reference's own GPU arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class-table", action="store_true", help="skip the extra instrumented step after the timed region")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class INSIDE the timed region (adds event overhead)")
@@ -240,20 +243,22 @@ def main():
     from gyre_amd import _lib, config as gcfg
     from gyre_amd.modules import GyreHipUNet, GyreHipVAE
     from gyre_amd.pipeline import GyrePipeline
+    HDT = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    _lib.set_default_storage(_lib.F16 if args.dtype == "fp16" else _lib.BF16)     # the profiler / redo-counter calls below follow it
     from gyre_amd.sharding import gather_batches, shard_bounds
     from gyre_amd.text import ClipTextEncoder, empty_prompt_ids, synthetic_prompt_ids
 
     ucfg = gcfg.sdxl_unet() if args.config == "sdxl" else gcfg.sd15_unet()
     vcfg = gcfg.sdxl_vae() if args.config == "sdxl" else gcfg.sd15_vae()
-    unet = GyreHipUNet(ucfg).to(torch.bfloat16).to(dev)
+    unet = GyreHipUNet(ucfg).to(HDT).to(dev)
     fill_synthetic_on_device(unet, 0)
-    vae = GyreHipVAE(vcfg).to(torch.bfloat16).to(dev)
+    vae = GyreHipVAE(vcfg).to(HDT).to(dev)
     fill_synthetic_on_device(vae, 1)
     inpaint = None
     if args.config == "inpaint768":
-        inpaint = GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(torch.bfloat16).to(dev)
+        inpaint = GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(HDT).to(dev)
         fill_synthetic_on_device(inpaint, 3)
-    clip = None if args.config == "sdxl" else ClipTextEncoder.synthetic(dev, torch.bfloat16, seed=2)
+    clip = None if args.config == "sdxl" else ClipTextEncoder.synthetic(dev, HDT, seed=2)
     sdxl_cond = None
     if args.config == "sdxl":
         # both SDXL text towers at their real sizes (CLIP ViT-L/14 and OpenCLIP ViT-bigG/14 text models, random init), run on the
@@ -267,7 +272,7 @@ def main():
                                                hidden_act="quick_gelu", **kw_))
             te2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32,
                                                              num_attention_heads=20, hidden_act="gelu", projection_dim=1280, **kw_))
-        te1, te2 = te1.to(torch.bfloat16).eval(), te2.to(torch.bfloat16).eval()
+        te1, te2 = te1.to(HDT).eval(), te2.to(HDT).eval()
         ident = lambda frag: frag                       # prompts arrive pre-tokenised: [(token ids, weight)]
         sdxl_cond = SDXLTextConditioner(te1, ident, te2, ident, dev)
     clip_model = fe = None
@@ -280,7 +285,7 @@ def main():
         torch.manual_seed(7)
         # bf16 like the rest of the pipeline (the reference loads clip_model in the engine's fp16): the guidance follows the dtype the
         # caller loaded the model in (gyre_amd/clipguided.py cond_fn); fp32 here put ~10 % of the step into rocBLAS fp32 GEMMs
-        clip_model = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(dev).to(torch.bfloat16))
+        clip_model = patch_embedding_as_matmul(CLIPModel(CLIPConfig(projection_dim=512)).eval().to(dev).to(HDT))
         for p_ in clip_model.parameters():
             p_.requires_grad_(False)
         fe = SimpleNamespace(image_mean=[0.48145466, 0.4578275, 0.40821073], image_std=[0.26862954, 0.26130258, 0.27577711],
@@ -511,17 +516,17 @@ def main():
             "value": round(value, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": {
                 "sd15": f"SD1.5 txt2img {size}x{size}, {n_steps} steps DPM++2M ({evals} UNet evals, CFG 7.5 parallel), "
-                        f"batch={B} per {'request' if args.scaling == 'strong' else 'GPU'}, bf16 on MI355X (BASELINE.json configs[1])",
+                        f"batch={B} per {'request' if args.scaling == 'strong' else 'GPU'}, {args.dtype} on MI355X (BASELINE.json configs[1])",
                 "sdxl": f"SDXL-base topology txt2img {size}x{size}, {n_steps} steps DPM++2M ({evals} UNet evals, CFG 5), batch={B} per "
-                        f"{'request' if args.scaling == 'strong' else 'GPU'}, bf16, both text towers (random-init CLIP ViT-L + OpenCLIP bigG text models) on the host path (BASELINE.json configs[3]; not in the reference)",
+                        f"{'request' if args.scaling == 'strong' else 'GPU'}, {args.dtype}, both text towers (random-init CLIP ViT-L + OpenCLIP bigG text models) on the host path (BASELINE.json configs[3]; not in the reference)",
                 "inpaint768": f"SD1.5 grafted inpaint {size}x{size} (9-ch inpaint UNet + base UNet, hires fix, VAE encode), {n_steps} steps "
-                              f"DPM++2M ({evals} UNet evals), batch={B}, bf16 (BASELINE.json configs[2])",
+                              f"DPM++2M ({evals} UNet evals), batch={B}, {args.dtype} (BASELINE.json configs[2])",
                 "tomeclip": f"SD1.5 txt2img {size}x{size}, ToMe r={args.tome_r} + CLIP guidance (scale {args.clip_scale}, guided base, 2 + 2 "
                             f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch, bf16), {n_steps} steps DPM++2M ({evals} UNet "
-                            f"evals incl. the differentiated stems), batch={B}, bf16 (BASELINE.json configs[4])"}[args.config],
+                            f"evals incl. the differentiated stems), batch={B}, {args.dtype} (BASELINE.json configs[4])"}[args.config],
                        "images_per_step": sum(sizes), "images_per_rank": sizes, "parallelism": f"dp{world}",
                        "dist_backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen,
                        "rank_devices": rank_devices,

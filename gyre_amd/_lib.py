@@ -12,11 +12,38 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first: maps torch's libamdhip64.so.7, which our .so then shares)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GYRE_HIP_LIB") or os.path.join(_HERE, "libgyre_hip.so")    # (GYRE_HIP_LIB: tuning / reproducer builds of the same ABI)
 MAX_LEVELS = 8
 
 F32, BF16, F16 = 0, 1, 2
 _TORCH_DTYPE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+# One library per 16-bit STORAGE type, same sources and same ABI (csrc/common.h, gyre_storage_dtype()): bf16 (default) and fp16 - the
+# reference's own GPU arithmetic (manager.py:146-151 loads fp16).  A module picks its library by the dtype of its parameters
+# (modules._NativeModule._storage): float16 -> F16, bfloat16 -> BF16, float32 -> the process default, which is BF16 unless
+# GYRE_STORAGE=f16 is set (how the test suite runs every raw-operator test on the fp16 flavour) or set_default_storage() is called.
+# (GYRE_HIP_LIB / GYRE_HIP_LIB_F16: tuning / reproducer builds of the same ABI.)
+LIB_PATHS = {BF16: os.environ.get("GYRE_HIP_LIB") or os.path.join(_HERE, "libgyre_hip.so"),
+             F16: os.environ.get("GYRE_HIP_LIB_F16") or os.path.join(_HERE, "libgyre_hip_f16.so")}
+LIB_PATH = LIB_PATHS[BF16]
+_default_storage = F16 if os.environ.get("GYRE_STORAGE", "").lower() in ("f16", "fp16", "float16", "half") else BF16
+STORAGE_TORCH_DTYPE = {BF16: torch.bfloat16, F16: torch.float16}
+
+
+def default_storage() -> int:
+    return _default_storage
+
+
+def set_default_storage(storage: int) -> int:
+    """Process-wide default storage flavour (BF16 / F16) for float32-parameter modules, lib() without an argument and the
+    profiler helpers.  Returns the previous value."""
+    global _default_storage
+    if storage not in LIB_PATHS:
+        raise ValueError("storage must be _lib.BF16 or _lib.F16")
+    old, _default_storage = _default_storage, storage
+    return old
+
+
+def storage_for(dtype: torch.dtype) -> int:
+    return F16 if dtype == torch.float16 else BF16 if dtype == torch.bfloat16 else _default_storage
 
 
 class GyreError(RuntimeError):
@@ -41,6 +68,7 @@ class VAECfg(C.Structure):
 _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 _SIGS = {
     "gyre_abi_version": (C.c_int, []),
+    "gyre_storage_dtype": (C.c_int, []),
     "gyre_last_error": (C.c_char_p, []),
     "gyre_last_launch_count": (C.c_int64, []),
     "gyre_unet_create": (_i, [C.POINTER(UNetCfg), _i, C.POINTER(_vp)]),
@@ -127,38 +155,53 @@ _SIGS = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
-_lib: Optional[C.CDLL] = None
+_libs: dict = {}
+import threading as _threading
+_tls = _threading.local()          # .last = the library this thread asked for last (check() reads ITS thread-local error string)
 
 
-def lib() -> C.CDLL:
-    """Load (once) and return the native library.  Raises GyreError if it is not built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise GyreError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def lib(storage: Optional[int] = None) -> C.CDLL:
+    """Load (once) and return the native library of the given storage flavour (None = the process default).  Raises GyreError if
+    it is not built."""
+    storage = _default_storage if storage is None else storage
+    l = _libs.get(storage)
+    if l is None:
+        path = LIB_PATHS[storage]
+        if not os.path.exists(path):
+            raise GyreError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             f"(hipcc --offload-arch=gfx950).  There is no non-HIP fallback.")
         try:
-            l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+            # local scope: both flavours export the same symbol names (each is linked -Bsymbolic and binds its own)
+            l = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
         except OSError as e:  # pragma: no cover
-            raise GyreError(f"cannot load {LIB_PATH}: {e}") from e
+            raise GyreError(f"cannot load {path}: {e}") from e
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
         if l.gyre_abi_version() != 1:
             raise GyreError("libgyre_hip ABI version mismatch")
-        _lib = l
-    return _lib
+        if l.gyre_storage_dtype() != storage:
+            raise GyreError(f"{path} stores dtype code {l.gyre_storage_dtype()}, expected {storage}")
+        _libs[storage] = l
+    _tls.last = l
+    return l
+
+
+def all_libs():
+    """Both flavours (loading them): for process-/thread-wide planner switches that must hold whichever library a module uses."""
+    return [lib(BF16), lib(F16)]
 
 
 _EXC = {-1: ValueError, -2: KeyError, -3: GyreError, -4: GyreError, -5: GyreError, -6: NotImplementedError}
 
 
-def check(rc: int) -> None:
+def check(rc: int, L: Optional[C.CDLL] = None) -> None:
     """Map a gyre_status to the Python exception the reference's error plumbing expects
-    (services/exception_to_grpc: NotImplementedError -> UNIMPLEMENTED, ValueError -> generic)."""
+    (services/exception_to_grpc: NotImplementedError -> UNIMPLEMENTED, ValueError -> generic).  L = the library the failing
+    call went to (its thread-local error string; default: the library this thread asked lib() for last)."""
     if rc != 0:
-        msg = lib().gyre_last_error().decode(errors="replace")
+        msg = (L or getattr(_tls, "last", None) or lib()).gyre_last_error().decode(errors="replace")
         raise _EXC.get(rc, GyreError)(f"libgyre_hip: {msg} (status {rc})")
 
 

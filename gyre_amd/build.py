@@ -1,4 +1,5 @@
-"""Build libgyre_hip.so in-tree with hipcc for gfx950 (MI355X).
+"""Build libgyre_hip.so (bf16 storage) and libgyre_hip_f16.so (fp16 storage: the same sources with -DGYRE_STORE_F16, csrc/common.h)
+in-tree with hipcc for gfx950 (MI355X).
 
 The library is plain HIP + a C ABI (include/gyre_hip.h); it does not link against
 torch.  It is loaded with ctypes after `import torch`, so its DT_NEEDED
@@ -15,6 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgyre_hip.so")
+LIB_F16 = os.path.join(HERE, "libgyre_hip_f16.so")
 SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_sm.hip", "kernels_conv_out.hip", "kernels_attn.hip", "kernels_tome.hip", "kernels_bwd.hip", "model.hip", "model_vjp.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_shared.h", "model_impl.h", os.path.join("..", "..", "include", "gyre_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
@@ -77,7 +79,7 @@ def _record_resources(source: str, remarks: str) -> None:
             except Exception:
                 data = {}
         data[source] = kernels
-        data = {k: v for k, v in data.items() if k in RESOURCE_FILES}      # (sources that no longer exist)
+        data = {k: v for k, v in data.items() if k.split("/")[-1] in RESOURCE_FILES}      # (sources that no longer exist)
         with open(RESOURCES_JSON, "w") as f:
             json.dump(data, f, indent=1, sort_keys=True)
 
@@ -86,22 +88,27 @@ import threading as _threading
 _RES_LOCK = _threading.Lock()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, flavours=("bf16", "f16")) -> str:
+    """Compile every translation unit once per storage flavour (objects under build/ and build/f16/) and link the two libraries.
+    Returns the path of the bf16 library (the default one)."""
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
     jobs = []
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append((src, obj))
+    for fl in flavours:
+        objdir = os.path.join(HERE, "build") if fl == "bf16" else os.path.join(HERE, "build", fl)
+        os.makedirs(objdir, exist_ok=True)
+        for s in SOURCES:
+            src = os.path.join(CSRC, s)
+            obj = os.path.join(objdir, s.replace(".hip", ".o"))
+            if force or _stale(obj, [src] + hdrs):
+                jobs.append((src, obj, fl))
 
     def cc(job):
-        src, obj = job
+        src, obj, fl = job
         extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
         base = os.path.basename(src)
+        if fl == "f16":
+            extra = [*extra, "-DGYRE_STORE_F16"]
         if base in RESOURCE_FILES:
             extra = [*extra, "-Rpass-analysis=kernel-resource-usage"]
         if os.environ.get("GYRE_AR_ABLATIONS") and base == "kernels_gemm_ar.hip":   # tools/ar_ablate.py
@@ -115,23 +122,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"hipcc failed for {src} ({fl}):\n{r.stdout}\n{r.stderr}")
         if base in RESOURCE_FILES:
-            _record_resources(base, r.stderr)
+            _record_resources(base if fl == "bf16" else f"{fl}/{base}", r.stderr)
             return ""
         return r.stderr
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:
             for warn in ex.map(cc, jobs):
                 if verbose and warn:
                     print(warn, file=sys.stderr)
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if jobs or force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    for fl in flavours:
+        objdir = os.path.join(HERE, "build") if fl == "bf16" else os.path.join(HERE, "build", fl)
+        lib = LIB if fl == "bf16" else LIB_F16
+        objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+        if any(j[2] == fl for j in jobs) or force or _stale(lib, objs):
+            # -Bsymbolic: a process may map BOTH flavours (same symbol names); each library binds its own definitions
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", lib]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                raise RuntimeError(f"link failed ({fl}):\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

@@ -5,15 +5,48 @@
 #include <stdint.h>
 #include <string>
 
-typedef uint16_t bf16_t;  // raw bf16 bits; all activations are NHWC bf16
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+// ---- storage flavour --------------------------------------------------------------------------------------------------------------
+// The library is built twice from the same sources (gyre_amd/build.py): libgyre_hip.so stores activations and weights as bf16,
+// libgyre_hip_f16.so (-DGYRE_STORE_F16) as IEEE fp16 - the reference's own GPU arithmetic (manager.py:146-151,1199-1200 loads fp16) with
+// three more mantissa bits at the same MFMA rate (v_mfma_f32_*_f16 = v_mfma_f32_*_bf16 on gfx950); accumulation, statistics and
+// every epilogue stay fp32 in both.  Everything type-specific is in this block: the raw 16-bit element type keeps the name bf16_t
+// ("the half-width storage element") throughout the kernels, conversions go through the helpers below, the MFMAs through the
+// GYRE_MFMA_* names.  gyre_storage_dtype() (include/gyre_hip.h) says which flavour a loaded library is.
+typedef uint16_t bf16_t;  // raw bits of the 16-bit storage element (bf16, or fp16 with GYRE_STORE_F16); all activations are NHWC of it
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 #define GYRE_WAVE 64
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef GYRE_STORE_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;      // MFMA operand fragment (8 storage elements)
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+#define GYRE_STORAGE_DTYPE 2                                          /* GYRE_F16 */
+#define GYRE_ONE_BITS 0x3c00                                          /* 1.0 */
+#define GYRE_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define GYRE_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+// softmax probabilities are packed to the storage type: fp16 ends at 65504, so rows are re-centred (and the optimistic attention pass
+// accepted) at 2^14 instead of 2^60
+#define GYRE_ATTN_TAU 14.f
+#define GYRE_ATTN_BOUND 16384.f
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }    // round to nearest even
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return (float)__builtin_bit_cast(bf16x2_t, w)[0]; }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return (float)__builtin_bit_cast(bf16x2_t, w)[1]; }
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#define GYRE_STORAGE_DTYPE 1                                          /* GYRE_BF16 */
+#define GYRE_ONE_BITS 0x3f80
+#define GYRE_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define GYRE_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define GYRE_ATTN_TAU 60.f
+#define GYRE_ATTN_BOUND 1.152921504606846976e18f                      /* 2^60 */
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32, one instruction per pair)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -22,6 +55,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
     f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
@@ -57,15 +91,16 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return fmaf(-0.70710678118654752f * z, q, fmaxf(x, 0.f));
 }
 
-// load one element of a boundary tensor of runtime dtype (0 f32, 1 bf16, 2 f16)
+// load / store one element of a BOUNDARY tensor of runtime dtype (gyre_dtype: 0 f32, 1 bf16, 2 f16) - whatever the storage flavour
+// of the build: bf16 here is always real bf16, f16 always IEEE half
 __device__ __forceinline__ float load_as_f32(const void* p, int dtype, size_t i) {
     if (dtype == 0) return ((const float*)p)[i];
-    if (dtype == 1) return bf16_to_f32(((const bf16_t*)p)[i]);
+    if (dtype == 1) return __uint_as_float(((uint32_t)((const uint16_t*)p)[i]) << 16);
     return __half2float(((const __half*)p)[i]);
 }
 __device__ __forceinline__ void store_from_f32(void* p, int dtype, size_t i, float v) {
     if (dtype == 0) ((float*)p)[i] = v;
-    else if (dtype == 1) ((bf16_t*)p)[i] = f32_to_bf16(v);
+    else if (dtype == 1) ((uint16_t*)p)[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
     else ((__half*)p)[i] = __float2half(v);
 }
 

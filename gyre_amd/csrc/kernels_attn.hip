@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
                 bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(k_lds + krow * KROW + (ks * 4 + fq) * 16));
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
-                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
+                    s[qi][ki] = GYRE_MFMA_16x16x32(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
             }
         }
         // lane now holds, for q = fr: s[qi][ki][r] = key 32*(ki>>1) + 8*fq + 4*(ki&1) + r
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnParams p) {
                     bf16x8_t, *(const uint4*)(v_lds + (di * 16 + fr) * VROW + (ks2 * 32 + fq * 8) * 2));
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
-                    o[qi][di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi], o[qi][di], 0, 0, 0);
+                    o[qi][di] = GYRE_MFMA_16x16x32(vf, pf[qi], o[qi][di], 0, 0, 0);
             }
         }
     }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
     // FOLD: a row is re-centred only when a score exceeds its reference maximum by 2^TAU.  p <= 2^60, row sums
     // <= 2^60 * Nk and the fp32 PV accumulators stay far inside the fp32 range; every row keeps a term >= 1 from
     // the tile that set its reference, so nothing underflows either.
-    constexpr float TAU = 60.f;
+    constexpr float TAU = GYRE_ATTN_TAU;       // 60 (bf16 storage); 14 with fp16 storage, whose P operand ends at 65504 (common.h)
 
     // half_tag: a tail tile whose keys 32..63 all lie past Nk (the second tile of a 77-key context holds 13 keys): the two key
     // fragments and the PV step of that half are skipped instead of masked
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
                     bf16x8_t, *(const uint4*)(k_lds + (ki * 16 + fr) * (D * 2) + (ks * 4 + fq) * 16));
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
-                    s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
+                    s[qi][ki] = GYRE_MFMA_16x16x32(kf, qf[qi][ks], s[qi][ki], 0, 0, 0);
             }
         }
         if (FOLD) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void k_attn2(AttnParams p, 
                 bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vraw);
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi)
-                    o[qi][di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qi], o[qi][di], 0, 0, 0);
+                    o[qi][di] = GYRE_MFMA_16x16x32(vf, pf[qi], o[qi][di], 0, 0, 0);
             }
         }
     };
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
     constexpr int NS = PD + (LDSX ? 3 : 2);
     constexpr int KG = 64 * KVEC, VG = VR * 8;
     constexpr bool ONES = (D % 16 != 0);
-    constexpr float TAU = 60.f;
+    constexpr float TAU = GYRE_ATTN_TAU;       // 60 (bf16 storage); 14 with fp16 storage, whose P operand ends at 65504 (common.h)
     // D = 80 does not fit 256 registers without a few spills.  Scratch stores count in vmcnt and may retire before
     // older loads, so a counted wait is not safe there: drain completely instead (one tile less of DMA lookahead).
     constexpr bool DRAIN = D > 64;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi) {
                     if constexpr (ABL & 8) { if (ks == 0 && CNEG) s[qi][ki] = cneg[qi]; asm volatile("" ::"v"(kf), "v"(qf[qi][ks])); }
-                    else s[qi][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][ks], (CNEG && ks == 0) ? cneg[qi] : s[qi][ki], 0, 0, 0);
+                    else s[qi][ki] = GYRE_MFMA_16x16x32(kf, qf[qi][ks], (CNEG && ks == 0) ? cneg[qi] : s[qi][ki], 0, 0, 0);
                 }
             }
         }
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
 #pragma unroll
                 for (int qi = 0; qi < QI; ++qi) {
                     if constexpr (ABL & 8) asm volatile("" ::"v"(vf), "v"(pf[ks2][qi]));
-                    else o[qi][di] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[ks2][qi], o[qi][di], 0, 0, 0);
+                    else o[qi][di] = GYRE_MFMA_16x16x32(vf, pf[ks2][qi], o[qi][di], 0, 0, 0);
                 }
             }
         }
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256, (QI >= 4 ? 1 : 2)) void k_attn3(AttnParams p, 
 #pragma unroll
         for (int qi = 0; qi < QI; ++qi) {
             const float l = row_sum(qi);
-            bad |= (q0 + qi * 16 + fr < p.Nq) && !(l > 0.f && l < 1.152921504606846976e18f);      // 2^TAU, TAU = 60
+            bad |= (q0 + qi * 16 + fr < p.Nq) && !(l > 0.f && l < GYRE_ATTN_BOUND);      // 2^TAU (common.h)
         }
         const bool wave_bad = __any(bad);
         int* flags = (int*)smem;                        // four words of ring slot 0, used between the two passes only
@@ -1027,9 +1027,9 @@ static const bf16_t* attn_zero_page() {
     std::lock_guard<std::mutex> g(mu);
     auto it = pages.find(dev);
     if (it != pages.end()) return (const bf16_t*)it->second;
-    void* p = nullptr;   // 256 B of zeros followed by 256 B of bf16 ones (0x3f80), then the device's redo counter (one zeroed word)
+    void* p = nullptr;   // 256 B of zeros followed by 256 B of ones in the storage type (GYRE_ONE_BITS), then the device's redo counter (one zeroed word)
     if (hipMalloc(&p, 512 + 16) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess || hipMemset((char*)p + 512, 0, 16) != hipSuccess) return nullptr;
-    if (hipMemsetD16((hipDeviceptr_t)((char*)p + 256), 0x3f80, 128) != hipSuccess) return nullptr;
+    if (hipMemsetD16((hipDeviceptr_t)((char*)p + 256), GYRE_ONE_BITS, 128) != hipSuccess) return nullptr;
     (void)hipDeviceSynchronize();
     pages[dev] = p;
     return (const bf16_t*)p;

@@ -522,10 +522,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
             if constexpr (DS > 0) {
 #pragma unroll
                 for (int i = 0; i < DS; ++i)
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                    s = GYRE_MFMA_32x32x16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
             } else {
                 for (int d0 = 0; d0 < D; d0 += 16)
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D),
+                    s = GYRE_MFMA_32x32x16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D),
                                                                 ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D), s, 0, 0, 0);
             }
             float tmx = NEG;
@@ -560,15 +560,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
         if constexpr (DS > 0) {
 #pragma unroll
             for (int i = 0; i < DS; ++i) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
             }
         } else {
             for (int d0 = 0; d0 < D; d0 += 16) {
                 const bf16x8_t qf = ld_frag(Q, p.ldq, q, p.Nq, d0 + 8 * hi, D);
                 const bf16x8_t dof = ld_frag(DO, p.lddo, q, p.Nq, d0 + 8 * hi, D);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D), qf, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, d0 + 8 * hi, D), dof, dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(ld_frag(K, p.ldk, kb * 32 + col, p.Nk, d0 + 8 * hi, D), qf, s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(ld_frag(V, p.ldv, kb * 32 + col, p.Nk, d0 + 8 * hi, D), dof, dp, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdParams p, int dchunk
 #pragma unroll
             for (int i = 0; i < NDB; ++i) {
                 const int d = dbase + i * 32 + col;
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag_t(KT + (size_t)d * p.ldkt, d < D, kb * 32 + 16 * m + 4 * hi),
+                acc[i] = GYRE_MFMA_32x32x16(ld_frag_t(KT + (size_t)d * p.ldkt, d < D, kb * 32 + 16 * m + 4 * hi),
                                                                  dsf, acc[i], 0, 0, 0);
             }
         }
@@ -636,15 +636,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchun
         if constexpr (DS > 0) {
 #pragma unroll
             for (int i = 0; i < DS; ++i) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
             }
         } else {
             for (int d0 = 0; d0 < D; d0 += 16) {
                 const bf16x8_t kf = ld_frag(K, p.ldk, key, p.Nk, d0 + 8 * hi, D);
                 const bf16x8_t vf = ld_frag(V, p.ldv, key, p.Nk, d0 + 8 * hi, D);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, d0 + 8 * hi, D), kf, s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, d0 + 8 * hi, D), vf, dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(ld_frag(Q, p.ldq, qb * 32 + col, p.Nq, d0 + 8 * hi, D), kf, s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(ld_frag(DO, p.lddo, qb * 32 + col, p.Nq, d0 + 8 * hi, D), vf, dp, 0, 0, 0);
             }
         }
         // lane: key fixed, queries qb*32 + 8g + 4hi + {0..3}; NqPad is a multiple of 32 so the statistics reads stay in range
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdParams p, int dchun
 #pragma unroll
             for (int i = 0; i < NDB; ++i) {
                 const int d = dbase + i * 32 + col;
-                dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, ld_frag_t(DOT + (size_t)d * p.ldqt, d < D, t), dv[i], 0, 0, 0);
-                dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, ld_frag_t(QT + (size_t)d * p.ldqt, d < D, t), dk[i], 0, 0, 0);
+                dv[i] = GYRE_MFMA_32x32x16(pf, ld_frag_t(DOT + (size_t)d * p.ldqt, d < D, t), dv[i], 0, 0, 0);
+                dk[i] = GYRE_MFMA_32x32x16(dsf, ld_frag_t(QT + (size_t)d * p.ldqt, d < D, t), dk[i], 0, 0, 0);
             }
         }
     }
@@ -807,8 +807,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
             f32x16_t s = {}, dp = {};
 #pragma unroll
             for (int i = 0; i < DS; ++i) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qs, rs, rt * 32 + col, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(DOs, rs, rt * 32 + col, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(lds_frag(Qs, rs, rt * 32 + col, i * 16 + 8 * hi, D), kh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(lds_frag(DOs, rs, rt * 32 + col, i * 16 + 8 * hi, D), vh[i], dp, 0, 0, 0);
             }
             // (whole tiles - all but the last of a ragged problem - skip the per-element range tests: wave-uniform branch)
             const bool whole = (qb * ROWS + rt * 32 + 32) <= p.Nq && (k0 + 32) <= p.Nk;
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < NDB; ++i) {
                     const int d = i * 32 + col;
-                    dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, lds_frag_t(DOTs, TS, d, D, t), dv[i], 0, 0, 0);
-                    dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, lds_frag_t(QTs, TS, d, D, t), dk[i], 0, 0, 0);
+                    dv[i] = GYRE_MFMA_32x32x16(pf, lds_frag_t(DOTs, TS, d, D, t), dv[i], 0, 0, 0);
+                    dk[i] = GYRE_MFMA_32x32x16(dsf, lds_frag_t(QTs, TS, d, D, t), dk[i], 0, 0, 0);
                 }
             }
         }
@@ -907,7 +907,7 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
             f32x16_t s = {};
 #pragma unroll
             for (int i = 0; i < DS; ++i)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
             float tmx = NEG;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -950,8 +950,8 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
             f32x16_t s = {}, dp = {};
 #pragma unroll
             for (int i = 0; i < DS; ++i) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vs, rs, rt * 32 + col, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
+                s = GYRE_MFMA_32x32x16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(lds_frag(Vs, rs, rt * 32 + col, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
             }
             if (kb * ROWS + rt * 32 + 32 <= p.Nk) {          // whole key tile: no per-element range test
 #pragma unroll
@@ -969,7 +969,7 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
                 const bf16x8_t dsf = pack_frag(s, m);
 #pragma unroll
                 for (int i = 0; i < NDB; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag_t(KTs, TS, i * 32 + col, D, rt * 32 + 16 * m + 4 * hi), dsf,
+                    acc[i] = GYRE_MFMA_32x32x16(lds_frag_t(KTs, TS, i * 32 + col, D, rt * 32 + 16 * m + 4 * hi), dsf,
                                                                      acc[i], 0, 0, 0);
             }
         }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_conv_out(const bf16_t* __restrict__ x, 
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8_t xf = *(const bf16x8_t*)(xp + ks * 64);
                 const bf16x8_t wf = fr < O ? *(const bf16x8_t*)(wp + ks * 64) : zero8;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+                acc = GYRE_MFMA_16x16x32(wf, xf, acc, 0, 0, 0);
             }
         }
     }

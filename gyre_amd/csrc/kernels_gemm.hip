@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                 bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b[r * 8 + ((ks * 4 + fq) ^ (r & 7))]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = GYRE_MFMA_16x16x32(bf, af[i], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -580,6 +580,14 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
                 }
             }
             }
+            // (Round 6: an L2 PREFETCH beside the ring was built and measured - one dword load per wave and K step whose lanes touch the
+            //  eight 128-byte lines of each of the wave's DMA pieces six steps ahead, counted into the vmcnt waits; bit-identical, and
+            //  SLOWER on every 128x160 shape: M = 4096, N = K = 1280 30.3 -> 35.7 us cold / 29.5 -> 33.1 warm, M = 16384, K = N = 640
+            //  30.9 -> 38.1, K = 2560 75.8 -> 103.9, UNet call 17.20 -> 17.59 ms (profiles/r06_l2_prefetch_ab.txt).  The loop is not
+            //  waiting for first-touch HBM latency: a K step moves 36.9 KB through the CU's vector-memory path, 576 cycles at its
+            //  64 B per clock beside 640 cycles of MFMA - the path is as busy as the matrix pipe, and 40 more line requests per wave
+            //  and step queue in front of the operand requests.  What bounds this tile is operand bytes per FLOP through that path
+            //  (DESIGN 4c), which neither a prefetch nor a split of K inside the workgroup changes.)
             int kabs = kc0;                                           // K step the next request fetches
             auto ring_issue = [&](int slot) {
                 const unsigned dst = lds0 + slot * STAGE_BYTES + wave * 1024;
@@ -1139,8 +1147,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p, int tiles_m, int til
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    else       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    if (TRANS) acc[i][j] = GYRE_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    else       acc[i][j] = GYRE_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
         }
         if (kc + 1 < nk) store_stage(cur ^ 1);

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
             constexpr int c = decltype(c_c)::value;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[U][c], af[U][i], acc[i][c], 0, 0, 0);
+                acc[i][c] = GYRE_MFMA_32x32x16(wf[U][c], af[U][i], acc[i][c], 0, 0, 0);
             if constexpr (R >= 0 && c < NI - 1) {
                 constexpr int r0 = c * RT / (NI - 1), r1 = (c + 1) * RT / (NI - 1);
 #pragma unroll

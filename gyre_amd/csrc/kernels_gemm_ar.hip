@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
             if constexpr (i + PF < NSTREAM && !(ABL & 8)) wf[(i + PF) % RING] = *(const bf16x8_t*)(sb + frag_off(i + PF));
             f32x16_t& acc = b == 0 ? a0 : a1;
             constexpr int fi = (ABL & 8) ? 0 : i % RING;
-            if constexpr (!(ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
+            if constexpr (!(ABL & 2)) acc = GYRE_MFMA_32x32x16(wf[fi], af[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
             else { if constexpr (ks == 0) acc = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }
             if constexpr (NB == 2) {
                 if constexpr (b == 0) {
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_ar(GemmParams p, const char* wp
             constexpr int fi = (ABL & 8) ? 0 : i % RING2;
 #define GYRE_AR_MFMA()                                                                                                          \
             do {                                                                                                                \
-                if constexpr (!(ABL & 2)) cur[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fi], af[ks], ks == 0 ? zero16 : cur[b], 0, 0, 0); \
+                if constexpr (!(ABL & 2)) cur[b] = GYRE_MFMA_32x32x16(wf[fi], af[ks], ks == 0 ? zero16 : cur[b], 0, 0, 0); \
                 else { if constexpr (ks == 0) cur[b] = zero16; asm volatile("" ::"v"(wf[fi]), "v"(af[ks])); }                   \
             } while (0)
             if constexpr (!(ABL & 256)) GYRE_AR_MFMA();

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
         for (int j = 0; j < 4; ++j) {
             const bf16x8_t af = *(const bf16x8_t*)(st + ra * 128 + (((2 * j + hi) ^ swa) * 16));
             const bf16x8_t wf = *(const bf16x8_t*)(st + WOFF + rw * 128 + (((2 * j + hi) ^ sww) * 16));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc, 0, 0, 0);
+            acc = GYRE_MFMA_32x32x16(af, wf, acc, 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // past-the-end requests: nothing may land in LDS after this point

@@ -18,6 +18,7 @@ void gyre_set_error(const std::string& msg) { g_err = msg; }
 int64_t& gyre_launch_counter() { return g_launches; }
 extern "C" const char* gyre_last_error(void) { return g_err.c_str(); }
 extern "C" int gyre_abi_version(void) { return GYRE_ABI_VERSION; }
+extern "C" int gyre_storage_dtype(void) { return GYRE_STORAGE_DTYPE; }      // GYRE_BF16 (libgyre_hip.so) or GYRE_F16 (libgyre_hip_f16.so)
 extern "C" int64_t gyre_last_launch_count(void) { return g_launches; }
 
 // ------------------------------------------------------------------------------------------

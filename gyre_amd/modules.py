@@ -96,18 +96,18 @@ class _NativeModule(nn.Module):
             raise ValueError(f"tiling must be True, False, 'x', 'y' or 'xy', got {tiling!r}")
         self._tiling = mode
         if self._handle is not None:
-            _lib.check(getattr(_lib.lib(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(self._handle), mode))
+            _lib.check(getattr(self._L(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(self._handle), mode))
             self._tiling_applied = (self._handle, mode)
 
     def _apply_tiling(self, h) -> None:
         mode = getattr(self, "_tiling", 0)
         if (getattr(self, "_tiling_applied", None) or (None, 0)) != (h, mode):
-            _lib.check(getattr(_lib.lib(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(h), mode))
+            _lib.check(getattr(self._L(), f"gyre_{self._kind}_set_tiling")(C.c_void_p(h), mode))
             self._tiling_applied = (h, mode)
 
     def _destroy(self):
         if getattr(self, "_handle", None):
-            getattr(_lib.lib(), f"gyre_{self._kind}_destroy")(C.c_void_p(self._handle))
+            getattr(self._L(), f"gyre_{self._kind}_destroy")(C.c_void_p(self._handle))
             self._handle = None
         # per-handle options are re-applied to whatever handle comes next: the allocator may hand a new struct the old address
         self._tiling_applied = None
@@ -119,7 +119,7 @@ class _NativeModule(nn.Module):
         except Exception:
             pass
 
-    _NATIVE_STATE = ("_handle", "_handle_device", "_ws", "_ws_vjp", "_ctx_slots", "_vjp_pending")
+    _NATIVE_STATE = ("_handle", "_handle_device", "_handle_storage", "_ws", "_ws_vjp", "_ctx_slots", "_vjp_pending")
 
     def __deepcopy__(self, memo):
         """A copy gets its OWN native handle (created at first use): the reference clones modules with ``deepcopy`` - per
@@ -141,24 +141,37 @@ class _NativeModule(nn.Module):
     def dtype(self) -> torch.dtype:
         return next(self.parameters()).dtype
 
+    def _storage(self) -> int:
+        """Storage flavour of the native copy: float16 parameters -> the fp16 library (the reference's GPU dtype, manager.py:146-151),
+        bfloat16 -> the bf16 one, float32 -> the process default (_lib.default_storage)."""
+        return _lib.storage_for(self.dtype)
+
+    def _L(self):
+        """The library this module's handle lives in (a handle is destroyed by the library that created it); without a handle, the
+        one its parameters' dtype selects."""
+        st = getattr(self, "_handle_storage", None) if getattr(self, "_handle", None) is not None else None
+        return _lib.lib(self._storage() if st is None else st)
+
     @property
     def device(self) -> torch.device:
         return next(self.parameters()).device
 
     def _sync(self, device: torch.device) -> int:
         """Create the native handle on `device` if needed and (re)upload dirty weights."""
-        L = _lib.lib()
+        L = self._L()
         if device.type != "cuda":
             raise _lib.GyreError(f"{type(self).__name__} runs on the MI355X HIP path only; move it to a GPU "
                                  f"(no CPU fallback)")
-        if self._handle is not None and self._handle_device != device:
-            self._destroy()
+        if self._handle is not None and (self._handle_device != device or getattr(self, "_handle_storage", None) != self._storage()):
+            self._destroy()                      # other device, or .to(dtype) moved the module to the other storage flavour
+            L = self._L()
         with torch.cuda.device(device):
             if self._handle is None:
                 h = C.c_void_p()
                 cfg = self._c_cfg()
                 _lib.check(getattr(L, f"gyre_{self._kind}_create")(C.byref(cfg), device.index or 0, C.byref(h)))
                 self._handle, self._handle_device, self._dirty = h.value, device, True
+                self._handle_storage = self._storage()
             if self._dirty:
                 st = _lib.stream_ptr(device)
                 setw = getattr(L, f"gyre_{self._kind}_set_weight")
@@ -191,7 +204,7 @@ class _NativeModule(nn.Module):
 
     def _workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
         if nbytes == 0:
-            raise _lib.GyreError("libgyre_hip: " + _lib.lib().gyre_last_error().decode())
+            raise _lib.GyreError("libgyre_hip: " + self._L().gyre_last_error().decode())
         if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
@@ -305,7 +318,7 @@ class GyreHipUNet(_NativeModule):
             raise ValueError("tome r must be >= 0")
         self._tome_r = r
         if self._handle is not None:
-            _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(self._handle), r))
+            _lib.check(self._L().gyre_unet_set_tome(C.c_void_p(self._handle), r))
 
     def _aug_embedding(self, added_cond_kwargs, B: int, dev) -> Optional[torch.Tensor]:
         """SDXL text_time conditioning: tiny MLP on the host (PyTorch-ROCm), result handed to the native call."""
@@ -353,7 +366,7 @@ class GyreHipUNet(_NativeModule):
         h = self._sync(dev)
         self._apply_tiling(h)
         if (getattr(self, "_tome_applied", None) or (None, None)) != (h, getattr(self, "_tome_r", 0)):
-            _lib.check(_lib.lib().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
+            _lib.check(self._L().gyre_unet_set_tome(C.c_void_p(h), getattr(self, "_tome_r", 0)))
             self._tome_applied = (h, getattr(self, "_tome_r", 0))
         self._t_uniform = not isinstance(timestep, torch.Tensor) or timestep.numel() == 1
         if isinstance(timestep, torch.Tensor):
@@ -399,7 +412,7 @@ class GyreHipUNet(_NativeModule):
         ctx = encoder_hidden_states.to(dev).contiguous()
         _lib.require_gpu_tensor(x, "latents")
         S = ctx.shape[1]
-        L = _lib.lib()
+        L = self._L()
         with torch.cuda.device(dev):
             # context cache: the denoising loop passes the SAME embeddings tensor on every call (the reference binds
             # it once per request, unet/core.py:242-259); project it through the cross-attention K/V weights once.
@@ -476,7 +489,7 @@ class GyreHipUNet(_NativeModule):
         ctx = encoder_hidden_states.to(dev).contiguous()
         _lib.require_gpu_tensor(x, "latents")
         S = ctx.shape[1]
-        L = _lib.lib()
+        L = self._L()
         with torch.cuda.device(dev):
             need = L.gyre_unet_vjp_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
@@ -502,7 +515,7 @@ class GyreHipUNet(_NativeModule):
         dx = torch.empty_like(sample)
         self._vjp_pending = None
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().gyre_unet_vjp_finish(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(g.data_ptr()),
+            _lib.check(self._L().gyre_unet_vjp_finish(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(g.data_ptr()),
                                                        _lib.dtype_code(g), C.c_void_p(dx.data_ptr()), _lib.dtype_code(dx)))
         return dx
 
@@ -515,7 +528,7 @@ class GyreHipUNet(_NativeModule):
         _lib.require_gpu_tensor(x, "latents")
         _lib.require_gpu_tensor(g, "d_eps")
         S = ctx.shape[1]
-        L = _lib.lib()
+        L = self._L()
         with torch.cuda.device(dev):
             need = L.gyre_unet_vjp_workspace_bytes(C.c_void_p(h), B, H, W, S)
             if need == 0:
@@ -550,7 +563,7 @@ class _UNetInputGrad(torch.autograd.Function):
     def backward(fctx, d_out):
         sample, t, enc = fctx.saved_tensors
         m = fctx.module
-        if getattr(m, "_vjp_pending", None) is fctx.token and _lib.lib().gyre_unet_vjp_pending(C.c_void_p(fctx.h)):
+        if getattr(m, "_vjp_pending", None) is fctx.token and m._L().gyre_unet_vjp_pending(C.c_void_p(fctx.h)):
             return m._vjp_finish(fctx.h, sample, d_out), None, None, None, None, None
         # state dropped by another call on the handle (gyre_unet_vjp_pending == 0): recompute in one shot
         _, dx = m._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
@@ -580,7 +593,7 @@ def set_batch_invariant(canonical_samples: int = 16) -> int:
     """Plan every split-K factor for ``canonical_samples`` batch entries whatever the real batch is (0 = off, the
     default): any split of a request over GPUs / sub-batches is then bit-identical (include/gyre_hip.h
     gyre_set_batch_invariant; reference property tests/batch_independance.py:15-27).  Returns the previous value."""
-    return int(_lib.lib().gyre_set_batch_invariant(int(canonical_samples)))
+    return int([L.gyre_set_batch_invariant(int(canonical_samples)) for L in _lib.all_libs()][0])      # both storage flavours
 
 
 class DiagonalGaussian:
@@ -661,7 +674,7 @@ class GyreHipVAE(_NativeModule):
         x = x.contiguous()
         _lib.require_gpu_tensor(x, "image")
         B, _, H, W = x.shape
-        L = _lib.lib()
+        L = self._L()
         f = 2 ** (len(self.config.block_out_channels) - 1)
         with torch.cuda.device(dev):
             need = L.gyre_vae_workspace_bytes(C.c_void_p(h), B, H, W, 0)
@@ -696,7 +709,7 @@ class GyreHipVAE(_NativeModule):
         z = z.contiguous()
         _lib.require_gpu_tensor(z, "latents")
         B, _, hl, wl = z.shape
-        L = _lib.lib()
+        L = self._L()
         f = 2 ** (len(self.config.block_out_channels) - 1)
         with torch.cuda.device(dev):
             need = (L.gyre_vae_workspace_bytes(C.c_void_p(h), B, hl, wl, 1) if d_img is None else

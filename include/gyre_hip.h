@@ -31,7 +31,8 @@
  *     gyre/manager.py:2107-2139).
  *   - activations cross the boundary in the reference's own layout: NCHW for
  *     latents/images, [B,S,D] for text embeddings; dtype per call (gyre_dtype).
- *     Internally everything is NHWC bf16 with fp32 accumulation.
+ *     Internally everything is NHWC bf16 (libgyre_hip.so) or NHWC fp16 (libgyre_hip_f16.so, gyre_storage_dtype) with fp32
+ *     accumulation.
  *   - `workspace` is caller-allocated device scratch (e.g. from the torch caching
  *     allocator) of at least gyre_*_workspace_bytes(...) bytes, 256-byte aligned.
  */
@@ -94,6 +95,11 @@ typedef struct gyre_vae gyre_vae;
 
 /* ---- library ---------------------------------------------------------- */
 int gyre_abi_version(void);
+/* The 16-bit type this build stores activations and weights in (accumulation and all epilogues are fp32 in both): GYRE_BF16 for
+ * libgyre_hip.so, GYRE_F16 for libgyre_hip_f16.so - the same sources and the same ABI built with -DGYRE_STORE_F16, the reference's own
+ * GPU arithmetic (gyre/manager.py:146-151,1199-1200 loads its pipelines in fp16).  A caller picks the library by the torch_dtype
+ * it loads the model in (gyre_amd/_lib.py lib(storage)); boundary tensors keep their per-call gyre_dtype in both. */
+int gyre_storage_dtype(void);
 const char* gyre_last_error(void);
 /* number of distinct kernel launches issued by this thread's last forward/encode/decode */
 int64_t gyre_last_launch_count(void);
@@ -313,7 +319,8 @@ int gyre_set_batch_invariant(int canonical_samples);
 int gyre_get_batch_invariant(void);
 
 /* ---- single operators (kernel-level parity tests and profiling) --------- */
-/* All tensors bf16 NHWC / row-major unless noted; f32 for norm affine, bias. */
+/* All tensors NHWC / row-major in the library's 16-bit storage type unless noted ("bf16" in the names and comments below reads "fp16"
+ * for libgyre_hip_f16.so: gyre_storage_dtype); f32 for norm affine, bias. */
 int gyre_op_groupnorm(void* stream, const void* x, const void* x2, int C1, int B, int HW, int C, int groups,
                       const float* gamma, const float* beta, float eps, int silu,
                       void* workspace, size_t workspace_bytes, void* y);

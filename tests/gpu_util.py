@@ -7,6 +7,9 @@ import torch
 from gyre_amd import _lib
 
 DEV = "cuda:0"
+# the 16-bit storage dtype of the library flavour under test: bfloat16, or float16 when the suite runs with GYRE_STORAGE=f16
+# (tests/test_gpu_f16_flavour.py re-runs the operator / model parity files that way)
+HDT = _lib.STORAGE_TORCH_DTYPE[_lib.default_storage()]
 
 
 _KEEP = []  # device tensors whose raw pointers were handed to the library; cleared (after a sync) per test
@@ -47,7 +50,8 @@ def report(name, got, ref, tol):
 
 
 def bf16_round(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round to the library's 16-bit storage dtype (HDT: bf16, or fp16 for the fp16 flavour) and back."""
+    return t.to(HDT).to(torch.float32)
 
 
 def randn(*shape, seed=0, scale=1.0):
@@ -60,7 +64,7 @@ def repack_conv(w_oihw: torch.Tensor, cin_pad=None) -> torch.Tensor:
     O, I, KH, KW = w_oihw.shape
     cin_pad = cin_pad or (I + 7) // 8 * 8
     src = w_oihw.float().contiguous().to(DEV)
-    out = torch.zeros(O * KH * KW * cin_pad, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(O * KH * KW * cin_pad, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_repack_conv_weight(st(), vp(src), O, I, KH, KW, cin_pad, vp(out)))
     return out
 
@@ -69,7 +73,7 @@ def repack_linear(w: torch.Tensor, geglu=False) -> torch.Tensor:
     L = _lib.lib()
     O, I = w.shape
     src = w.float().contiguous().to(DEV)
-    out = torch.zeros(O * I, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(O * I, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_repack_linear_weight(st(), vp(src), O, I, int(geglu), vp(out)))
     return out
 

@@ -17,7 +17,7 @@ import torch
 from gyre_amd import _lib, config as gcfg, weights
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE, set_batch_invariant
 from gyre_amd.pipeline import GyrePipeline
-from gpu_util import DEV, randn, report
+from gpu_util import HDT, DEV, randn, report
 from oracle import models_ref as M
 from oracle import pipeline_ref as PR
 
@@ -71,7 +71,7 @@ def test_config3_inpaint_unet_per_level_parity():
 def test_config3_inpaint_unet_properties_full_size():
     """Config-3 UNet call: 4 images x CFG = batch 8, 9 channels, 96x96 latents.  Determinism, sample-permutation
     equivariance (bit-exact) and, under batch-invariant planning, bit-exact batch splits."""
-    net = fill(GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(torch.bfloat16).to(DEV), 5)
+    net = fill(GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(HDT).to(DEV), 5)
     g = torch.Generator(device=DEV).manual_seed(6)
     x = torch.randn(8, 9, 96, 96, device=DEV, generator=g)
     ctx = torch.randn(8, 77, 768, device=DEV, generator=g)
@@ -156,9 +156,9 @@ def test_config3_full_size_grafted_inpaint_768():
     UNet, VAE encode of the (masked) init image, hires fix active (768 > 529 px: natural 64x64 + full 96x96 leaves).
     No oracle at this size: shape, finiteness, bit-determinism and batch independence (reference
     tests/batch_independance.py:15-27) of the whole pipeline."""
-    unet = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
-    inp = fill(GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(torch.bfloat16).to(DEV), 1)
-    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).to(DEV), 2)
+    unet = fill(GyreHipUNet(gcfg.sd15_unet()).to(HDT).to(DEV), 0)
+    inp = fill(GyreHipUNet(gcfg.sd15_unet(in_channels=9)).to(HDT).to(DEV), 1)
+    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(HDT).to(DEV), 2)
     pipe = GyrePipeline(unet, vae, device=DEV, inpaint_unet=inp, grafted_inpaint=True)
     g = torch.Generator().manual_seed(3)
     text, unc = torch.randn(4, 77, 768, generator=g) * 0.3, torch.randn(1, 77, 768, generator=g).expand(4, -1, -1) * 0.3
@@ -193,8 +193,8 @@ def test_config4_sdxl_base_per_level_parity():
     sd = weights.synthetic_state_dict(weights.unet_param_shapes(cfg), 4)
     net = GyreHipUNet(cfg)
     net.load_state_dict(sd)
-    net = net.to(torch.bfloat16).to(DEV)
-    sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}              # the oracle sees the same (rounded) weights
+    net = net.to(HDT).to(DEV)
+    sd = {k: v.to(HDT).float() for k, v in sd.items()}              # the oracle sees the same (rounded) weights
     x, t, ctx = randn(1, 4, 32, 32, seed=41), torch.tensor([500]), randn(1, 77, 2048, seed=42) * 0.5
     ac = {"text_embeds": randn(1, 1280, seed=43), "time_ids": torch.tensor([[1024., 1024, 0, 0, 1024, 1024]])}
     taps_parity(cfg, sd, net, x, t, ctx, "config4 SDXL-base unet 32x32", ac=ac)
@@ -204,7 +204,7 @@ def test_config4_sdxl_base_properties_full_size():
     """SDXL-base at 128x128 latents (1024x1024 px), CFG pair of one image = batch 2 (the per-GPU call of config 4:
     16 images over 8 GPUs): finite, bit-deterministic, permutation-equivariant, and the VAE decodes 128x128 latents."""
     cfg = gcfg.sdxl_unet()
-    net = fill(GyreHipUNet(cfg).to(torch.bfloat16).to(DEV), 7)
+    net = fill(GyreHipUNet(cfg).to(HDT).to(DEV), 7)
     g = torch.Generator(device=DEV).manual_seed(8)
     x = torch.randn(4, 4, 128, 128, device=DEV, generator=g)
     ctx = torch.randn(4, 77, 2048, device=DEV, generator=g) * 0.5
@@ -217,7 +217,7 @@ def test_config4_sdxl_base_properties_full_size():
     perm = torch.tensor([2, 0, 3, 1], device=DEV)
     acp = {k: v[perm].contiguous() for k, v in ac.items()}
     assert torch.equal(net(x[perm].contiguous(), t, encoder_hidden_states=ctx[perm].contiguous(), added_cond_kwargs=acp).sample, out[perm])
-    vae = fill(GyreHipVAE(gcfg.sdxl_vae()).to(torch.bfloat16).to(DEV), 9)
+    vae = fill(GyreHipVAE(gcfg.sdxl_vae()).to(HDT).to(DEV), 9)
     img = vae.decode(x[:1] / 0.13025).sample
     assert img.shape == (1, 3, 1024, 1024) and bool(torch.isfinite(img).all())
 

@@ -10,7 +10,7 @@ from gyre_amd import config as gcfg, weights
 from gyre_amd.executor import DeviceSlotExecutor
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
 from gyre_amd.pipeline import GyrePipeline
-from gpu_util import DEV
+from gpu_util import HDT, DEV
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _pipe(ucfg, vcfg):
     unet, vae = GyreHipUNet(ucfg), GyreHipVAE(vcfg)
     unet.load_state_dict(weights.synthetic_state_dict(weights.unet_param_shapes(ucfg)))
     vae.load_state_dict(weights.synthetic_state_dict(weights.vae_param_shapes(vcfg)))
-    return GyrePipeline(unet.to(torch.bfloat16).to(DEV), vae.to(torch.bfloat16).to(DEV), device=DEV)
+    return GyrePipeline(unet.to(HDT).to(DEV), vae.to(HDT).to(DEV), device=DEV)
 
 
 def test_module_copies_get_their_own_native_handle():

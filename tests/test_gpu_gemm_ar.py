@@ -11,14 +11,14 @@ import torch
 import torch.nn.functional as F
 
 from gyre_amd import _lib
-from gpu_util import DEV, bf16_round, randn, rel_l2, repack_bias, repack_linear, report, st, vp
+from gpu_util import HDT, DEV, bf16_round, randn, rel_l2, repack_bias, repack_linear, report, st, vp
 
 pytestmark = pytest.mark.gpu
 TOL = 4e-3
 
 
 def to_dev_bf16(t):
-    return t.to(torch.bfloat16).contiguous().to(DEV)
+    return t.to(HDT).contiguous().to(DEV)
 
 
 @pytest.fixture()
@@ -62,7 +62,7 @@ def test_linear_matches_reference_and_the_tile_kernels(ar, M, K, N, bias, res):
     outs = []
     for on in (True, False):
         ar(on)
-        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y = torch.full((M, N), float("nan"), dtype=HDT, device=DEV)
         run = lambda: _lib.check(L.gyre_op_linear(st(), vp(xd), M, K, vp(wd), N, vp(bd), vp(rd), 0, vp(y)))
         names = _classes(run)
         assert ("k_gemm_ar" in names) == on, names
@@ -83,7 +83,7 @@ def test_geglu(ar, M, K, F_):
     outs = []
     for on in (True, False):
         ar(on)
-        y = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y = torch.full((M, F_), float("nan"), dtype=HDT, device=DEV)
         names = _classes(lambda: _lib.check(L.gyre_op_linear(st(), vp(xd), M, K, vp(wd), F_, vp(bd), None, 1, vp(y))))
         assert ("k_gemm_ar" in names) == on, names
         outs.append(y)
@@ -116,7 +116,7 @@ def test_folded_layernorm(ar, M, K, N, geglu):
     outs = []
     for on in (True, False):
         ar(on)
-        y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y = torch.full((M, N), float("nan"), dtype=HDT, device=DEV)
         rcs = []
         names = _classes(lambda: rcs.append(L.gyre_op_ln_linear(st(), vp(xd), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(wd), N, vp(bd),
                                                                 geglu, 0, None, 0, None, 0, vp(ws), ws.numel(), vp(y))))
@@ -142,7 +142,7 @@ def test_row_statistics_feed_the_folded_layernorm(ar, M, C, res):
     w1 = bf16_round(randn(C, C, seed=111) / math.sqrt(C))
     b1 = randn(C, seed=112) * 0.3 + 0.2
     r = bf16_round(randn(M, C, seed=113) + 0.5) if res else None
-    y1 = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty(M, C, dtype=HDT, device=DEV)
     stats = torch.full((parts, M, 2), float("nan"), device=DEV)
     names = _classes(lambda: _lib.check(L.gyre_op_linear_rowstats(st(), vp(to_dev_bf16(x)), M, C, vp(repack_linear(w1)), C, vp(b1.to(DEV)),
                                                                   vp(to_dev_bf16(r)) if res else None, vp(y1), vp(stats))))
@@ -156,8 +156,8 @@ def test_row_statistics_feed_the_folded_layernorm(ar, M, C, res):
     w2 = bf16_round(randn(C, C, seed=116) / math.sqrt(C))
     ref2 = F.linear(F.layer_norm(y1f.cpu(), (C,), g, b, 1e-5), w2)
     ws = torch.empty(L.gyre_op_ln_linear_workspace(C, C, M), dtype=torch.uint8, device=DEV)
-    out_p = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
-    out_s = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    out_p = torch.empty(M, C, dtype=HDT, device=DEV)
+    out_s = torch.empty(M, C, dtype=HDT, device=DEV)
     args = (st(), vp(y1), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w2)), C, None, 0, 0, None, 0)
     _lib.check(L.gyre_op_ln_linear(*args, vp(stats), parts, vp(ws), ws.numel(), vp(out_p)))
     _lib.check(L.gyre_op_ln_linear(*args, None, 0, vp(ws), ws.numel(), vp(out_s)))
@@ -176,7 +176,7 @@ def test_rows_are_independent_and_repeatable(ar):
     x = to_dev_bf16(randn(65536, K, seed=5))
     ys = []
     for M in (65536, 65536, 8192, 4096 + 64):
-        y = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y = torch.full((M, N // 2), float("nan"), dtype=HDT, device=DEV)
         _lib.check(L.gyre_op_linear(st(), vp(x), M, K, vp(w), N // 2, vp(b), None, 1, vp(y)))
         ys.append(y)
     assert torch.equal(ys[0], ys[1])
@@ -196,8 +196,8 @@ def test_fused_qkv_with_transposed_v(ar, B, tokens, ln):
     outs = []
     for on in (True, False):
         ar(on)
-        qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
-        vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+        qk = torch.full((M, 2 * C), float("nan"), dtype=HDT, device=DEV)
+        vt = torch.full((B, C, tokens), float("nan"), dtype=HDT, device=DEV)
         rcs = []
         if ln:
             ws = torch.empty(L.gyre_op_ln_linear_workspace(3 * C, C, M), dtype=torch.uint8, device=DEV)

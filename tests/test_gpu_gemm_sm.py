@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from gpu_util import DEV, randn, repack_bias, repack_linear, st, vp
+from gpu_util import HDT, DEV, randn, repack_bias, repack_linear, st, vp
 from gyre_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -18,16 +18,16 @@ pytestmark = pytest.mark.gpu
                                             (63, 128, 192, True, False), (1024, 2560, 640, True, True), (512, 5120, 1280, True, True)])
 def test_small_problem_kernel_matches_the_4_wave_kernel(M, K, N, res, bias):
     L = _lib.lib()
-    x = (randn(M, K, seed=1) * 1.3).to(torch.bfloat16).to(DEV)
+    x = (randn(M, K, seed=1) * 1.3).to(HDT).to(DEV)
     w0, b0 = randn(N, K, seed=2) / math.sqrt(K), randn(N, seed=3) * 0.3
     w, b = repack_linear(w0), (repack_bias(b0) if bias else None)
-    r = randn(M, N, seed=4).to(torch.bfloat16).to(DEV) if res else None
+    r = randn(M, N, seed=4).to(HDT).to(DEV) if res else None
     outs, names = [], []
     for bits in (0x20, 0):
         L.gyre_debug_gemm_ablation(bits)
         try:
             _lib.prof_enable(None)
-            y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            y = torch.full((M, N), float("nan"), dtype=HDT, device=DEV)
             _lib.check(L.gyre_op_linear(st(), vp(x), M, K, vp(w), N, vp(b), vp(r), 0, vp(y)))
             torch.cuda.synchronize()
             names.append(set(_lib.prof_collect()))
@@ -43,7 +43,7 @@ def test_small_problem_kernel_matches_the_4_wave_kernel(M, K, N, res, bias):
         assert (outs[0].float() - outs[1].float()).abs().max().item() < 0.0625
     else:
         assert torch.equal(outs[0], outs[1])
-    ref = x.float() @ w0.to(torch.bfloat16).float().to(DEV).T + (b0.to(DEV) if bias else 0) + (r.float() if res else 0)
+    ref = x.float() @ w0.to(HDT).float().to(DEV).T + (b0.to(DEV) if bias else 0) + (r.float() if res else 0)
     assert (outs[1].float() - ref).abs().max().item() < 0.08
 
 
@@ -53,12 +53,12 @@ def test_fused_qkv_with_transposed_v_on_the_small_kernel(B, tokens, C):
     tiles transposed into V^T[b][channel][token] (gyre_op_qkv); before, such shapes had no fused form at all (two launches)."""
     L = _lib.lib()
     M = B * tokens
-    x = (randn(M, C, seed=21) * 1.1).to(torch.bfloat16)
-    w0 = (randn(3 * C, C, seed=22) / math.sqrt(C)).to(torch.bfloat16)
+    x = (randn(M, C, seed=21) * 1.1).to(HDT)
+    w0 = (randn(3 * C, C, seed=22) / math.sqrt(C)).to(HDT)
     ref = x.float() @ w0.float().T
     xd, wd = x.to(DEV), repack_linear(w0.float())
-    qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qk = torch.full((M, 2 * C), float("nan"), dtype=HDT, device=DEV)
+    vt = torch.full((B, C, tokens), float("nan"), dtype=HDT, device=DEV)
     _lib.prof_enable(None)
     try:
         _lib.check(L.gyre_op_qkv(st(), vp(xd), M, C, vp(wd), tokens, vp(qk), vp(vt), tokens))
@@ -74,7 +74,7 @@ def test_fused_qkv_with_transposed_v_on_the_small_kernel(B, tokens, C):
     # the unfused pair of launches computes the same sums in the same order
     L.gyre_debug_gemm_ablation(0x20)
     try:
-        qk2 = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        qk2 = torch.full((M, 2 * C), float("nan"), dtype=HDT, device=DEV)
         rc = L.gyre_op_linear(st(), vp(xd), M, C, vp(wd), 2 * C, None, None, 0, vp(qk2))
     finally:
         L.gyre_debug_gemm_ablation(0)

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from gyre_amd import _lib
-from gpu_util import DEV, bf16_round, randn, rel_l2, repack_bias, repack_conv, repack_linear, report, st, vp
+from gpu_util import HDT, DEV, bf16_round, randn, rel_l2, repack_bias, repack_conv, repack_linear, report, st, vp
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ TOL_ATTN = 1e-2
 
 
 def to_dev_bf16(t):
-    return t.to(torch.bfloat16).contiguous().to(DEV)
+    return t.to(HDT).contiguous().to(DEV)
 
 
 def nhwc(t):  # NCHW f32 -> NHWC
@@ -32,7 +32,7 @@ def test_nchw_to_nhwc_pad():
     for dt in (torch.float32, torch.bfloat16, torch.float16):
         x = randn(2, 9, 12, 20, seed=1).to(dt)
         xd = x.to(DEV)
-        y = torch.full((2, 12 * 20, 16), 7.0, dtype=torch.bfloat16, device=DEV)
+        y = torch.full((2, 12 * 20, 16), 7.0, dtype=HDT, device=DEV)
         _lib.check(L.gyre_op_nchw_to_nhwc(st(), vp(xd), _lib.dtype_code(xd), 2, 9, 240, 16, vp(y)))
         ref = torch.zeros(2, 240, 16)
         ref[:, :, :9] = bf16_round(x.float()).reshape(2, 9, 240).permute(0, 2, 1)
@@ -58,7 +58,7 @@ def test_groupnorm(B, H, W, C, C1, silu, eps):
         a, b = to_dev_bf16(xn[..., :C1]), to_dev_bf16(xn[..., C1:])
     else:
         a, b = to_dev_bf16(xn), None
-    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, H, W, C, dtype=HDT, device=DEV)
     wsb = L.gyre_op_groupnorm_workspace(B, H * W, C, 32)
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     _lib.check(L.gyre_op_groupnorm(st(), vp(a), vp(b), C1, B, H * W, C, 32, vp(gamma.to(DEV)), vp(beta.to(DEV)), eps,
@@ -90,7 +90,7 @@ def test_layernorm(M, C):
     x = bf16_round(randn(M, C, seed=6) * 2 + 0.3)
     g, b = randn(C, seed=7) * 0.2 + 1, randn(C, seed=8) * 0.2
     ref = F.layer_norm(x, (C,), g, b, 1e-5)
-    y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, C, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_layernorm(st(), vp(to_dev_bf16(x)), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(y)))
     report(f"layernorm {M}x{C}", y.float().cpu(), ref, TOL)
 
@@ -110,7 +110,7 @@ def test_linear(M, K, N, bias, res):
     ref = F.linear(x, w, b)
     if res:
         ref = ref + r
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, N, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w)), N,
                                 vp(b.to(DEV)) if bias else None, vp(to_dev_bf16(r)) if res else None, 0, vp(y)))
     report(f"linear M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
@@ -125,7 +125,7 @@ def test_linear_geglu(M, K, F_):
     h = F.linear(x, w, b)
     val, gate = h.chunk(2, dim=-1)
     ref = val * F.gelu(gate)
-    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, F_, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w, geglu=True)), F_,
                                 vp(repack_bias(b, geglu=True)), None, 1, vp(y)))
     report(f"geglu M{M} K{K} F{F_}", y.float().cpu(), ref, TOL)
@@ -140,7 +140,7 @@ def test_linear_transposed(B, T, K, N, bias):
     w = bf16_round(randn(N, K, seed=17) / math.sqrt(K))
     b = randn(N, seed=18) if bias else None
     ref = F.linear(x, w, b).reshape(B, T, N).permute(0, 2, 1)  # [B][N][T]
-    y = torch.zeros(B, N, ldt, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(B, N, ldt, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_linear_t(st(), vp(to_dev_bf16(x)), B * T, K, vp(repack_linear(w)), N,
                                   vp(b.to(DEV)) if bias else None, T, ldt, vp(y)))
     report(f"linear_t B{B} T{T} K{K} N{N}", y.float().cpu()[:, :, :T], ref, TOL)
@@ -168,7 +168,7 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups, asym, res):
     r = bf16_round(randn(B, Cout, Ho, Wo, seed=22)) if res else None
     if res:
         ref = ref + r
-    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
                                  vp(to_dev_bf16(nhwc(r))) if res else None, stride, ups, asym, vp(y)))
     report(f"conv3x3 {B}x{H}x{W} {Cin}->{Cout} s{stride} ups{ups} asym{asym}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
@@ -218,9 +218,9 @@ def test_conv3x3_padded_cin():
     b = randn(Cout, seed=25)
     ref = F.conv2d(x, w, b, padding=1)
     xd = x.to(DEV)
-    xp = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=DEV)
+    xp = torch.empty(B, H * W, 8, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_nchw_to_nhwc(st(), vp(xd), 0, B, Cin, H * W, 8, vp(xp)))
-    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, H, W, Cout, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_conv3x3(st(), vp(xp), B, H, W, 8, vp(repack_conv(w, 8)), Cout, vp(b.to(DEV)), None, 1, 0, 0, vp(y)))
     report("conv3x3 cin4->pad8", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
 
@@ -247,9 +247,9 @@ def test_attention(B, heads, Nq, Nk, D):
     v = bf16_round(randn(B, Nk, C_, seed=28))
     ref = attn_ref(q, k, v, heads)
     ldvt = (Nk + 7) // 8 * 8
-    vt = torch.full((B, C_, ldvt), float("nan"), dtype=torch.bfloat16, device=DEV)  # pad = NaN on purpose
-    vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
-    o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
+    vt = torch.full((B, C_, ldvt), float("nan"), dtype=HDT, device=DEV)  # pad = NaN on purpose
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(HDT).to(DEV)
+    o = torch.empty(B, Nq, C_, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_attention(st(), vp(to_dev_bf16(q)), C_, vp(to_dev_bf16(k)), C_, vp(vt), ldvt, B, heads, Nq, Nk, D,
                                    vp(o), C_))
     report(f"attention B{B} h{heads} Nq{Nq} Nk{Nk} D{D}", o.float().cpu(), ref, TOL_ATTN)
@@ -266,8 +266,8 @@ def test_attention_peaked_softmax():
     k = bf16_round(k)
     v = bf16_round(randn(B, N, C_, seed=31))
     ref = attn_ref(q, k, v, heads)
-    vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
-    o = torch.empty(B, N, C_, dtype=torch.bfloat16, device=DEV)
+    vt = v.permute(0, 2, 1).to(HDT).contiguous().to(DEV)
+    o = torch.empty(B, N, C_, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_attention(st(), vp(to_dev_bf16(q)), C_, vp(to_dev_bf16(k)), C_, vp(vt), N, B, heads, N, N, D,
                                    vp(o), C_))
     report("attention peaked", o.float().cpu(), ref, 2e-2)
@@ -275,7 +275,7 @@ def test_attention_peaked_softmax():
 
 def test_error_paths():
     L = _lib.lib()
-    x = torch.zeros(64, 12, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(64, 12, dtype=HDT, device=DEV)
     rc = L.gyre_op_linear(st(), vp(x), 64, 12, vp(x), 8, None, None, 0, vp(x))
     assert rc == -1 and b"multiple of 8" in L.gyre_last_error()
     with pytest.raises(ValueError):
@@ -301,7 +301,7 @@ def test_linear_forced_tile_config(cfg, M, K, N, bias, res):
     ref = F.linear(x, w, b)
     if res:
         ref = ref + r
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, N, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w)), N,
@@ -320,7 +320,7 @@ def test_geglu_forced_tile_config(cfg):
     b = randn(2 * F_, seed=46) * 0.5
     val, gate = F.linear(x, w, b).chunk(2, dim=-1)
     ref = val * F.gelu(gate)
-    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, F_, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w, geglu=True)), F_,
@@ -345,7 +345,7 @@ def test_conv_forced_tile_config(cfg, B, H, W, Cin, Cout, stride, ups, asym, res
     r = bf16_round(randn(B, Cout, Ho, Wo, seed=50)) if res else None
     if res:
         ref = ref + r
-    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_conv3x3(st(), vp(to_dev_bf16(nhwc(x))), B, H, W, Cin, vp(repack_conv(w)), Cout, vp(b.to(DEV)),
@@ -367,7 +367,7 @@ def test_conv_split_k(B, H, W, Cin, Cout, res):
     r = bf16_round(randn(B, Cout, H, W, seed=54)) if res else None
     if res:
         ref = ref + r
-    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, H, W, Cout, dtype=HDT, device=DEV)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
     L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
     try:
@@ -395,9 +395,9 @@ def test_attention_variants(variant, B, heads, Nq, Nk, D):
     v = bf16_round(randn(B, Nk, C_, seed=62))
     ref = attn_ref(q, k, v, heads)
     ldvt = (Nk + 7) // 8 * 8
-    vt = torch.zeros((B, C_, ldvt), dtype=torch.bfloat16, device=DEV)  # pad columns must be finite (zero) for v2
-    vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
-    o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros((B, C_, ldvt), dtype=HDT, device=DEV)  # pad columns must be finite (zero) for v2
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(HDT).to(DEV)
+    o = torch.empty(B, Nq, C_, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_attn_variant(variant)
     try:
         _lib.check(L.gyre_op_attention(st(), vp(to_dev_bf16(q)), C_, vp(to_dev_bf16(k)), C_, vp(vt), ldvt, B, heads, Nq, Nk,
@@ -418,7 +418,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     b = randn(Cout, seed=62).to(DEV)
     outs = {}
     for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
-        y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        y = torch.empty(B, H, W, Cout, dtype=HDT, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
             _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, W, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
@@ -433,7 +433,7 @@ def test_all_tile_configs_sum_in_the_same_order():
     wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
     outs = {}
     for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
-        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        y = torch.empty(M, N, dtype=HDT, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
             _lib.check(L.gyre_op_linear(st(), vp(xl), M, K, vp(wl), N, None, None, 0, vp(y)))
@@ -468,7 +468,7 @@ def test_linear_ring_loop_and_blocked_weights_are_bit_identical(M, K, N, res):
             if (cfg & 0xff) == 32 and (N % 64 or cfg >> 8): continue
             if (cfg >> 8) and K < 2048: continue
             for bits, blocked in ((0x1000000, 0), (0, 0), (0x2000000, 0), (0, 1)):
-                y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                y = torch.full((M, N), float("nan"), dtype=HDT, device=DEV)
                 L.gyre_debug_set_wblk_workspace(vp(blk) if blocked else None, blk.numel() if blocked else 0)
                 oc, ob = L.gyre_debug_force_gemm_cfg(cfg), L.gyre_debug_gemm_ablation(bits)
                 try:
@@ -502,7 +502,7 @@ def test_conv_blocked_weights_are_bit_identical(B, H, Cin, Cout):
         for cfg in (4, 5, 8, 24, 8 | (2 << 8), 8 | (4 << 8), 5 | (2 << 8), 24 | (2 << 8)):
             for blocked, bits in ((0, 0), (1, 0), (0, 0x8000000), (1, 0x8000000)):
                 if bits and (cfg & 0xff) == 24: continue          # (the pipelined tile has its own loop)
-                y = torch.full((B, H, H, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+                y = torch.full((B, H, H, Cout), float("nan"), dtype=HDT, device=DEV)
                 L.gyre_debug_set_wblk_workspace(vp(blk) if blocked else None, blk.numel() if blocked else 0)
                 oc, ob = L.gyre_debug_force_gemm_cfg(cfg), L.gyre_debug_gemm_ablation(bits)
                 try:
@@ -525,7 +525,7 @@ def test_groupnorm_statistics_do_not_depend_on_batch_size():
     L = _lib.lib()
     for HW, Cc in ((4096, 320), (1024, 640), (9216, 320), (65536, 128)):
         B = 5
-        x = (torch.randn(B, HW, Cc, device=DEV) * 2 + 0.5).to(torch.bfloat16)
+        x = (torch.randn(B, HW, Cc, device=DEV) * 2 + 0.5).to(HDT)
         gam, bet = torch.randn(Cc, device=DEV), torch.randn(Cc, device=DEV)
 
         def run(xs):
@@ -554,11 +554,11 @@ def test_attention_prescaled_k(variant, B, heads, Nq, Nk, D):
     k32 = randn(B, Nk, C_, seed=71)
     v = bf16_round(randn(B, Nk, C_, seed=72))
     ref = attn_ref(q, k32, v, heads)
-    kpre = (k32 * (1.4426950408889634 / math.sqrt(D))).to(torch.bfloat16).to(DEV)
+    kpre = (k32 * (1.4426950408889634 / math.sqrt(D))).to(HDT).to(DEV)
     ldvt = (Nk + 7) // 8 * 8
-    vt = torch.zeros((B, C_, ldvt), dtype=torch.bfloat16, device=DEV)
-    vt[:, :, :Nk] = v.permute(0, 2, 1).to(torch.bfloat16).to(DEV)
-    o = torch.empty(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros((B, C_, ldvt), dtype=HDT, device=DEV)
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(HDT).to(DEV)
+    o = torch.empty(B, Nq, C_, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_attn_variant(variant)    # 0 planner, 3 folded v2, 5 software-pipelined v3 (where built)
     try:
         _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), ldvt, B, heads, Nq, Nk, D, vp(o), C_, 1))
@@ -584,10 +584,10 @@ def test_attention_prescaled_peaked_and_drifting_max():
     v = bf16_round(randn(B, N, C_, seed=75))
     for name, kk in (("peaked+drift", k32), ("late keys tiny", torch.cat([k32[:, :64], k32[:, 64:] * 0.01], dim=1))):
         ref = attn_ref(q, kk, v, heads)
-        kpre = (kk * c).to(torch.bfloat16).to(DEV)
-        vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
+        kpre = (kk * c).to(HDT).to(DEV)
+        vt = v.permute(0, 2, 1).to(HDT).contiguous().to(DEV)
         for variant in (3, 5):
-            o = torch.empty(B, N, C_, dtype=torch.bfloat16, device=DEV)
+            o = torch.empty(B, N, C_, dtype=HDT, device=DEV)
             old = L.gyre_debug_force_attn_variant(variant)
             try:
                 _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
@@ -617,11 +617,11 @@ def test_attention_optimistic_pass_and_its_fallback(D, excess):
     k32[0, 700, :D] = qn * (excess / c / float(qn @ qn))
     v = bf16_round(randn(B, N, C_, seed=175))
     ref = attn_ref(q, k32, v, heads)
-    kpre = (k32 * c).to(torch.bfloat16).to(DEV)
-    vt = v.permute(0, 2, 1).to(torch.bfloat16).contiguous().to(DEV)
+    kpre = (k32 * c).to(HDT).to(DEV)
+    vt = v.permute(0, 2, 1).to(HDT).contiguous().to(DEV)
     outs = []
     for variant in (0, 7):                          # 0 = the default: optimistic first pass; 7 = per-tile check from the start
-        o = torch.full((B, N, C_), float("nan"), dtype=torch.bfloat16, device=DEV)
+        o = torch.full((B, N, C_), float("nan"), dtype=HDT, device=DEV)
         old = L.gyre_debug_force_attn_variant(variant)
         try:
             _lib.check(L.gyre_op_attention_ex(st(), vp(to_dev_bf16(q)), C_, vp(kpre), C_, vp(vt), N, B, heads, N, N, D, vp(o), C_, 1))
@@ -642,9 +642,9 @@ def test_fused_qkv_projection(cfg, B, tokens, C):
     x = bf16_round(randn(M, C, seed=80))
     w = bf16_round(randn(3 * C, C, seed=81) / math.sqrt(C))
     ref = F.linear(x, w)
-    qk = torch.empty(M, 2 * C, dtype=torch.bfloat16, device=DEV)
+    qk = torch.empty(M, 2 * C, dtype=HDT, device=DEV)
     ldt = tokens
-    vt = torch.full((B, C, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vt = torch.full((B, C, ldt), float("nan"), dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_qkv(st(), vp(to_dev_bf16(x)), M, C, vp(repack_linear(w)), tokens, vp(qk), vp(vt), ldt))
@@ -657,9 +657,9 @@ def test_fused_qkv_projection(cfg, B, tokens, C):
 
 def test_fused_qkv_rejects_unaligned_configs():
     L = _lib.lib()
-    x = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
-    w = torch.zeros(960, 320, dtype=torch.bfloat16, device=DEV)
-    qk = torch.empty(256, 640, dtype=torch.bfloat16, device=DEV); vt = torch.empty(1, 320, 256, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(256, 320, dtype=HDT, device=DEV)
+    w = torch.zeros(960, 320, dtype=HDT, device=DEV)
+    qk = torch.empty(256, 640, dtype=HDT, device=DEV); vt = torch.empty(1, 320, 256, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(1)     # 4-wave config: no transposing epilogue
     try:
         rc = L.gyre_op_qkv(st(), vp(x), 256, 320, vp(w), 256, vp(qk), vp(vt), 256)
@@ -691,12 +691,12 @@ def test_ln_linear(M, K, N, bias):
     gd, bd = g.to(DEV), b.to(DEV)
     bias_d = bias_t.to(DEV) if bias else None
     ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
-    y = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y = torch.full((M, N), float("nan"), dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(xd), M, K, vp(gd), vp(bd), 1e-5, vp(wd), N, vp(bias_d) if bias else None, 0, 0, None, 0,
                                    None, 0, vp(ws), ws.numel(), vp(y)))
     report(f"ln_linear M{M} K{K} N{N}", y.float().cpu(), ref, TOL)
-    n = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
-    y2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    n = torch.empty(M, K, dtype=HDT, device=DEV)
+    y2 = torch.empty(M, N, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_layernorm(st(), vp(xd), M, K, vp(gd), vp(bd), 1e-5, vp(n)))
     _lib.check(L.gyre_op_linear(st(), vp(n), M, K, vp(wd), N, vp(bias_d) if bias else None, None, 0, vp(y2)))
     e_fused, e_two = rel_l2(y.float().cpu(), ref), rel_l2(y2.float().cpu(), ref)
@@ -717,7 +717,7 @@ def test_ln_linear_geglu(M, K, F_):
     val, gate = F.linear(F.layer_norm(x, (K,), g, b, 1e-5), w, bias_t).chunk(2, dim=-1)
     ref = val * F.gelu(gate)
     ws = torch.empty(L.gyre_op_ln_linear_workspace(2 * F_, K, M), dtype=torch.uint8, device=DEV)
-    y = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y = torch.full((M, F_), float("nan"), dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w, geglu=True)), F_,
                                    vp(repack_bias(bias_t, geglu=True)), 1, 0, None, 0, None, 0, vp(ws), ws.numel(), vp(y)))
     report(f"ln_geglu M{M} K{K} F{F_}", y.float().cpu(), ref, TOL)
@@ -732,8 +732,8 @@ def test_ln_fused_qkv(B, tokens, C):
     w = bf16_round(randn(3 * C, C, seed=103) / math.sqrt(C))
     ref = F.linear(F.layer_norm(x, (C,), g, b, 1e-5), w)
     ws = torch.empty(L.gyre_op_ln_linear_workspace(3 * C, C, M), dtype=torch.uint8, device=DEV)
-    qk = torch.full((M, 2 * C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    vt = torch.full((B, C, tokens), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qk = torch.full((M, 2 * C), float("nan"), dtype=HDT, device=DEV)
+    vt = torch.full((B, C, tokens), float("nan"), dtype=HDT, device=DEV)
     rc = L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), 3 * C, None, 0,
                              tokens, vp(vt), tokens, None, 0, vp(ws), ws.numel(), vp(qk))
     if rc == -6:
@@ -752,12 +752,12 @@ def test_ln_linear_large_mean_and_small_shapes():
     w = bf16_round(randn(N, K, seed=108) / math.sqrt(K))
     ref = F.linear(F.layer_norm(x, (K,), g, b, 1e-5), w)
     ws = torch.empty(L.gyre_op_ln_linear_workspace(N, K, M), dtype=torch.uint8, device=DEV)
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, N, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_ln_linear(st(), vp(to_dev_bf16(x)), M, K, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w)), N, None, 0, 0,
                                    None, 0, None, 0, vp(ws), ws.numel(), vp(y)))
     report("ln_linear mean = 8 sigma", y.float().cpu(), ref, 2 * TOL)
-    xs = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV); wsm = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
-    gs = torch.ones(64, device=DEV); ys = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    xs = torch.zeros(64, 64, dtype=HDT, device=DEV); wsm = torch.zeros(64, 64, dtype=HDT, device=DEV)
+    gs = torch.ones(64, device=DEV); ys = torch.empty(64, 64, dtype=HDT, device=DEV)
     assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, None, 0, vp(ws), ws.numel(), vp(ys)) == -6
     assert L.gyre_op_ln_linear(st(), vp(xs), 64, 64, vp(gs), vp(gs), 1e-5, vp(wsm), 64, None, 0, 0, None, 0, None, 0, vp(ws), 16, vp(ys)) == -4
 
@@ -777,7 +777,7 @@ def test_linear_row_statistics_feed_the_folded_layernorm(M, C, res):
     w1 = bf16_round(randn(C, C, seed=111) / math.sqrt(C))
     b1 = randn(C, seed=112) * 0.3 + 0.2
     r = bf16_round(randn(M, C, seed=113) + 0.5) if res else None
-    y1 = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty(M, C, dtype=HDT, device=DEV)
     stats = torch.full((parts, M, 2), float("nan"), device=DEV)
     _lib.check(L.gyre_op_linear_rowstats(st(), vp(to_dev_bf16(x)), M, C, vp(repack_linear(w1)), C, vp(b1.to(DEV)),
                                          vp(to_dev_bf16(r)) if res else None, vp(y1), vp(stats)))
@@ -792,8 +792,8 @@ def test_linear_row_statistics_feed_the_folded_layernorm(M, C, res):
     w2 = bf16_round(randn(C, C, seed=116) / math.sqrt(C))
     ref2 = F.linear(F.layer_norm(y1f.cpu(), (C,), g, b, 1e-5), w2)
     ws = torch.empty(L.gyre_op_ln_linear_workspace(C, C, M), dtype=torch.uint8, device=DEV)
-    out_p = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
-    out_s = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    out_p = torch.empty(M, C, dtype=HDT, device=DEV)
+    out_s = torch.empty(M, C, dtype=HDT, device=DEV)
     args = (st(), vp(y1), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w2)), C, None, 0, 0, None, 0)
     _lib.check(L.gyre_op_ln_linear(*args, vp(stats), parts, vp(ws), ws.numel(), vp(out_p)))
     _lib.check(L.gyre_op_ln_linear(*args, None, 0, vp(ws), ws.numel(), vp(out_s)))
@@ -807,8 +807,8 @@ def test_linear_row_statistics_feed_the_folded_layernorm(M, C, res):
         b3 = randn(2 * F_, seed=118) * 0.5
         val, gate = F.linear(F.layer_norm(y1f.cpu(), (C,), g, b, 1e-5), w3, b3).chunk(2, dim=-1)
         ws3 = torch.empty(L.gyre_op_ln_linear_workspace(2 * F_, C, M), dtype=torch.uint8, device=DEV)
-        gp = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
-        gs = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+        gp = torch.empty(M, F_, dtype=HDT, device=DEV)
+        gs = torch.empty(M, F_, dtype=HDT, device=DEV)
         gargs = (st(), vp(y1), M, C, vp(g.to(DEV)), vp(b.to(DEV)), 1e-5, vp(repack_linear(w3, geglu=True)), F_,
                  vp(repack_bias(b3, geglu=True)), 1, 0, None, 0)
         _lib.check(L.gyre_op_ln_linear(*gargs, vp(stats), parts, vp(ws3), ws3.numel(), vp(gp)))
@@ -835,7 +835,7 @@ def test_linear_4s_tile_config(cfg, M, K, N, bias, res):
     ref = F.linear(x, w, b)
     if res:
         ref = ref + r
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, N, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w)), N,
@@ -854,7 +854,7 @@ def test_geglu_4s_tile_config(cfg):
     b = randn(2 * F_, seed=46) * 0.5
     val, gate = F.linear(x, w, b).chunk(2, dim=-1)
     ref = val * F.gelu(gate)
-    y = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, F_, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     try:
         _lib.check(L.gyre_op_linear(st(), vp(to_dev_bf16(x)), M, K, vp(repack_linear(w, geglu=True)), F_,
@@ -882,7 +882,7 @@ def test_conv_4s_tile_config(zfill, cfg, B, H, W, Cin, Cout, stride, ups, asym, 
     r = bf16_round(randn(B, Cout, Ho, Wo, seed=50)) if res else None
     if res:
         ref = ref + r
-    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(cfg)
     olda = _ablation(0x200 if zfill else 0)
     try:
@@ -903,7 +903,7 @@ def test_conv_4s_split_k(cfg, splits):
     b = randn(Cout, seed=53)
     r = bf16_round(randn(B, Cout, H, W, seed=54))
     ref = F.conv2d(x, w, b, padding=1) + r
-    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, H, W, Cout, dtype=HDT, device=DEV)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
     L.gyre_debug_set_splitk_workspace(vp(ws), ws.numel())
     old = L.gyre_debug_force_gemm_cfg(cfg | (splits << 8))
@@ -928,7 +928,7 @@ def test_4s_tile_configs_sum_in_the_same_order_as_the_others():
     b = randn(Cout, seed=62).to(DEV)
     outs = {}
     for cfg in (1, 4, 20, 21, 22, 23, 24):
-        y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        y = torch.empty(B, H, W, Cout, dtype=HDT, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
             _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, W, Cin, vp(w), Cout, vp(b), None, 1, 0, 0, vp(y)))
@@ -942,7 +942,7 @@ def test_4s_tile_configs_sum_in_the_same_order_as_the_others():
     wl = repack_linear(bf16_round(randn(N, K, seed=64) / math.sqrt(K)))
     outs = {}
     for cfg in (1, 4, 20, 21, 22, 23, 24):
-        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        y = torch.empty(M, N, dtype=HDT, device=DEV)
         old = L.gyre_debug_force_gemm_cfg(cfg)
         try:
             _lib.check(L.gyre_op_linear(st(), vp(xl), M, K, vp(wl), N, None, None, 0, vp(y)))
@@ -957,7 +957,7 @@ def test_4s_rejects_unsupported_shapes():
     L = _lib.lib()
     x = to_dev_bf16(bf16_round(randn(256, 200, seed=1)))
     w = repack_linear(bf16_round(randn(320, 200, seed=2)))
-    y = torch.empty(256, 320, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(256, 320, dtype=HDT, device=DEV)
     old = L.gyre_debug_force_gemm_cfg(20)
     try:
         assert L.gyre_op_linear(st(), vp(x), 256, 200, vp(w), 320, None, None, 0, vp(y)) == -6   # K not in 64-channel steps
@@ -973,8 +973,8 @@ def _tome_run(k, v, r):
     ldvt = (N - reff + 7) // 8 * 8
     kd, vd = to_dev_bf16(k), to_dev_bf16(v)
     ws = torch.empty(L.gyre_op_tome_workspace(B, N, Cc), dtype=torch.uint8, device=DEV)
-    k_out = torch.empty(B, N - reff, Cc, dtype=torch.bfloat16, device=DEV)
-    vt_out = torch.full((B, Cc, ldvt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    k_out = torch.empty(B, N - reff, Cc, dtype=HDT, device=DEV)
+    vt_out = torch.full((B, Cc, ldvt), float("nan"), dtype=HDT, device=DEV)
     order = torch.empty(B, N // 2, dtype=torch.int32, device=DEV)
     nidx = torch.empty(B, N // 2, dtype=torch.int32, device=DEV)
     _lib.check(L.gyre_op_tome_merge(st(), vp(kd), Cc, vp(vd), Cc, B, N, Cc, r, vp(ws), ws.numel(), vp(k_out), vp(vt_out), ldvt,
@@ -1024,11 +1024,11 @@ def test_tome_merge_matches_oracle(B, N, C, r):
 
 def test_tome_rejects_bad_arguments():
     L = _lib.lib()
-    x = torch.zeros(1, 64, 36, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(1, 64, 36, dtype=HDT, device=DEV)
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
-    out = torch.empty(1, 64, 36, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(1, 64, 36, dtype=HDT, device=DEV)
     assert L.gyre_op_tome_merge(st(), vp(x), 36, vp(x), 36, 1, 64, 36, 8, vp(ws), ws.numel(), vp(out), vp(out), 64, None, None) == -1   # C % 8
-    x = torch.zeros(1, 64, 64, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(1, 64, 64, dtype=HDT, device=DEV)
     assert L.gyre_op_tome_merge(st(), vp(x), 64, vp(x), 64, 1, 64, 64, 8, vp(ws), 16, vp(out), vp(out), 64, None, None) == -4         # workspace
 
 
@@ -1076,7 +1076,7 @@ def test_conv_emits_groupnorm_statistics(B, H, W, Cin, Cout, stride, ups, res, w
     r = bf16_round(randn(B, Cout, Ho, Wo, seed=64)) if res else None
     if res:
         ref = ref + r
-    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=HDT, device=DEV)
     stats = torch.full((B * Ho * Wo // 16, Cout // unit, 2), float("nan"), dtype=torch.float32, device=DEV)
     need = L.gyre_op_gemm_splitk_bytes(1, B * Ho * Wo, Cout, 9 * Cin, B)
     ws = torch.empty(max(need, 16) + 256, dtype=torch.uint8, device=DEV)
@@ -1121,7 +1121,7 @@ def test_linear_emits_groupnorm_statistics(B, HW, C, res):
     b = randn(C, seed=73)
     r = bf16_round(randn(M, C, seed=74) * 2 + 0.5) if res else None
     ref = F.linear(x, w, b) + (r if res else 0)
-    y = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(M, C, dtype=HDT, device=DEV)
     stats = torch.full((M // 16, C // unit, 2), float("nan"), dtype=torch.float32, device=DEV)
     rows = Ct.c_int(0)
     rc = L.gyre_op_linear_colstats(st(), vp(to_dev_bf16(x)), M, C, vp(to_dev_bf16(w)), C, vp(b.to(DEV)),
@@ -1154,7 +1154,7 @@ def test_groupnorm_from_producer_statistics(B, H, W, C1, C2, silu):
     cs_a = _colstats_ref(xn[..., :C1].reshape(-1, C1), B, rows_a, unit).float().to(DEV).contiguous()
     cs_b = _colstats_ref(xn[..., C1:].reshape(-1, C2), B, rows_b, unit).float().to(DEV).contiguous() if C2 else None
     ws = torch.empty(L.gyre_op_groupnorm_workspace(B, HW, C, 32) + 256, dtype=torch.uint8, device=DEV)
-    y = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    y = torch.empty(B, H, W, C, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_groupnorm_colstats(st(), vp(a), vp(b), C1, B, HW, C, 32, vp(gamma.to(DEV)), vp(beta.to(DEV)), 1e-5, silu,
                                             vp(cs_a), HW // rows_a, vp(cs_b), HW // rows_b if C2 else 0, unit, vp(ws), ws.numel(), vp(y)))
     report(f"groupnorm from producer statistics {B}x{H}x{W} {C1}+{C2}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
@@ -1175,7 +1175,7 @@ def test_unet_with_and_without_producer_statistics_full_size():
     cfg = gcfg.sd15_unet()
     net = GyreHipUNet(cfg)
     net.load_state_dict(weights.synthetic_state_dict(weights.unet_param_shapes(cfg)))
-    net = net.to(torch.bfloat16).to(DEV)
+    net = net.to(HDT).to(DEV)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 4, 64, 64, generator=g).to(DEV)
     ctx = torch.randn(2, 77, 768, generator=g).to(DEV)
@@ -1202,9 +1202,9 @@ def test_colstats_entry_points_reject_bad_integers():
     """rows_per_sample = 0 used to reach an integer division (SIGFPE); now every size is checked up front."""
     import ctypes as C
     L = _lib.lib()
-    x = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
-    w = torch.zeros(320, 320, dtype=torch.bfloat16, device=DEV)
-    y = torch.zeros(256, 320, dtype=torch.bfloat16, device=DEV)
+    x = torch.zeros(256, 320, dtype=HDT, device=DEV)
+    w = torch.zeros(320, 320, dtype=HDT, device=DEV)
+    y = torch.zeros(256, 320, dtype=HDT, device=DEV)
     stats = torch.zeros(4096, dtype=torch.float32, device=DEV)
     rows = C.c_int(0)
     for rps, unit in ((0, 10), (256, 0), (100, 10), (256, 7)):

@@ -10,7 +10,7 @@ import torch
 from gyre_amd import _lib, config as gcfg
 from gyre_amd import weights
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
-from gpu_util import DEV, randn, rel_l2, report
+from gpu_util import HDT, DEV, randn, rel_l2, report
 from oracle import models_ref as M
 
 pytestmark = pytest.mark.gpu
@@ -388,7 +388,7 @@ def test_sd15_unet_tome_full_size_properties():
     attention is reported by tools/, not asserted here."""
     import gpu_util
     cfg = gcfg.sd15_unet()
-    net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
+    net = GyreHipUNet(cfg).to(HDT).to(DEV)
     g = torch.Generator(device=DEV).manual_seed(0)
     with torch.no_grad():
         for k, p in net.named_parameters():

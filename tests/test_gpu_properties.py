@@ -9,7 +9,7 @@ import torch
 
 from gyre_amd import _lib, config as gcfg
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
-from gpu_util import DEV, randn, repack_conv, repack_linear, st, vp
+from gpu_util import HDT, DEV, randn, repack_conv, repack_linear, st, vp
 
 pytestmark = pytest.mark.gpu
 
@@ -34,13 +34,13 @@ def test_conv_linearity_full_size():
     L = _lib.lib()
     B, H, W, Ci, Co = 16, 64, 64, 320, 320
     g = torch.Generator(device=DEV).manual_seed(0)
-    x = torch.randn(B, H, W, Ci, device=DEV, generator=g).to(torch.bfloat16)
-    y = torch.randn(B, H, W, Ci, device=DEV, generator=g).to(torch.bfloat16)
-    z = (2.0 * x.float() - 0.5 * y.float()).to(torch.bfloat16)   # exactly representable scaling, one rounding
+    x = torch.randn(B, H, W, Ci, device=DEV, generator=g).to(HDT)
+    y = torch.randn(B, H, W, Ci, device=DEV, generator=g).to(HDT)
+    z = (2.0 * x.float() - 0.5 * y.float()).to(HDT)   # exactly representable scaling, one rounding
     w = repack_conv(randn(Co, Ci, 3, 3, seed=1) / math.sqrt(9 * Ci))
     outs = []
     for inp in (x, y, z):
-        o = torch.empty(B, H, W, Co, dtype=torch.bfloat16, device=DEV)
+        o = torch.empty(B, H, W, Co, dtype=HDT, device=DEV)
         _lib.check(L.gyre_op_conv3x3(st(), vp(inp), B, H, W, Ci, vp(w), Co, None, None, 1, 0, 0, vp(o)))
         outs.append(o.float())
     lin = 2.0 * outs[0] - 0.5 * outs[1]
@@ -48,7 +48,7 @@ def test_conv_linearity_full_size():
     print(f"[property] conv linearity rel-L2 = {err:.2e}")
     assert err < 8e-3
     # determinism: same launch twice is bit-identical
-    o2 = torch.empty_like(outs[0], dtype=torch.bfloat16)
+    o2 = torch.empty_like(outs[0], dtype=HDT)
     _lib.check(L.gyre_op_conv3x3(st(), vp(x), B, H, W, Ci, vp(w), Co, None, None, 1, 0, 0, vp(o2)))
     assert torch.equal(o2.float(), outs[0])
 
@@ -60,13 +60,13 @@ def test_attention_row_sum_and_permutation_full_size():
     B, h, N, D = 4, 8, 4096, 40
     Cc = h * D
     g = torch.Generator(device=DEV).manual_seed(1)
-    q = torch.randn(B, N, Cc, device=DEV, generator=g).to(torch.bfloat16)
-    k = torch.randn(B, N, Cc, device=DEV, generator=g).to(torch.bfloat16)
-    ones_t = torch.ones(B, Cc, N, dtype=torch.bfloat16, device=DEV)
-    o = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=DEV)
+    q = torch.randn(B, N, Cc, device=DEV, generator=g).to(HDT)
+    k = torch.randn(B, N, Cc, device=DEV, generator=g).to(HDT)
+    ones_t = torch.ones(B, Cc, N, dtype=HDT, device=DEV)
+    o = torch.empty(B, N, Cc, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(ones_t), N, B, h, N, N, D, vp(o), Cc))
     assert float((o.float() - 1).abs().max()) < 1e-2
-    v = torch.randn(B, N, Cc, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, N, Cc, device=DEV, generator=g).to(HDT)
     perm = torch.randperm(N, device=DEV, generator=g)
     o1, o2 = torch.empty_like(o), torch.empty_like(o)
     _lib.check(L.gyre_op_attention(st(), vp(q), Cc, vp(k), Cc, vp(v.permute(0, 2, 1).contiguous()), N, B, h, N, N, D, vp(o1), Cc))
@@ -81,7 +81,7 @@ def test_groupnorm_moments_full_size():
     """GroupNorm output (gamma=1, beta=0, no SiLU) has per-(sample, group) mean 0 and variance 1; VAE-scale tensor."""
     L = _lib.lib()
     for B, HW, Cc in ((8, 512 * 512, 128), (16, 4096, 320), (16, 64, 1280)):
-        x = (torch.randn(B, HW, Cc, device=DEV) * 3 + 1.5).to(torch.bfloat16)
+        x = (torch.randn(B, HW, Cc, device=DEV) * 3 + 1.5).to(HDT)
         y = torch.empty_like(x)
         gam, bet = torch.ones(Cc, device=DEV), torch.zeros(Cc, device=DEV)
         wsb = L.gyre_op_groupnorm_workspace(B, HW, Cc, 32)
@@ -97,7 +97,7 @@ def test_sd15_batch_equivariance_full_size():
     samples permutes the output bit-exactly (what weak-scaling data parallelism relies on: every rank runs the same
     per-GPU batch).  A *different* batch size may change the planner's tile / split-K choice and therefore the fp32
     summation order, so unequal splits agree only to bf16 rounding - measured and bounded here."""
-    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
+    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(HDT).to(DEV), 0)
     g = torch.Generator(device=DEV).manual_seed(2)
     x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
     ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
@@ -119,7 +119,7 @@ def test_sd15_batch_equivariance_full_size():
 
 def test_vae_roundtrip_shapes_and_finiteness_768():
     """Config-3 sizes: encode 768x768 -> moments [.,8,96,96]; decode 96x96 latents -> 768x768; finite, deterministic."""
-    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).to(DEV), 1)
+    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(HDT).to(DEV), 1)
     img = torch.rand(2, 3, 768, 768, device=DEV) * 2 - 1
     dist = vae.encode(img).latent_dist
     assert dist.parameters.shape == (2, 8, 96, 96) and bool(torch.isfinite(dist.parameters).all())
@@ -138,8 +138,8 @@ def test_batch_invariant_mode_makes_any_split_bit_exact_full_size():
     (batch 16) and the VAE decode give bit-identical results for ANY split of the batch (SURVEY 8(d) sharding gate,
     reference property tests/batch_independance.py:15-27 made exact)."""
     from gyre_amd.modules import set_batch_invariant
-    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
-    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(torch.bfloat16).to(DEV), 1)
+    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(HDT).to(DEV), 0)
+    vae = fill(GyreHipVAE(gcfg.sd15_vae()).to(HDT).to(DEV), 1)
     g = torch.Generator(device=DEV).manual_seed(2)
     x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
     ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
@@ -168,7 +168,7 @@ def test_folded_layernorm_full_size_matches_the_separate_pass_and_follows_weight
     (planner debug bit 11) up to bf16 rounding; the cached copies are rebuilt when a weight is re-uploaded (per-request
     LoRA merge), LayerNorm affine parameters included."""
     L = _lib.lib()
-    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(torch.bfloat16).to(DEV), 0)
+    net = fill(GyreHipUNet(gcfg.sd15_unet()).to(HDT).to(DEV), 0)
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
     ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
@@ -207,7 +207,7 @@ def test_folded_layernorm_chain_through_a_depth_two_transformer():
     L = _lib.lib()
     cfg = gcfg.UNetConfig(block_out_channels=(320, 640), attn_levels=(True, True), num_heads=(5, 10), transformer_depth=(1, 2),
                           cross_attention_dim=768, use_linear_projection=True)
-    net = fill(GyreHipUNet(cfg).to(torch.bfloat16).to(DEV), 3)
+    net = fill(GyreHipUNet(cfg).to(HDT).to(DEV), 3)
     g = torch.Generator(device=DEV).manual_seed(6)
     x = torch.randn(16, 4, 64, 64, device=DEV, generator=g)
     ctx = torch.randn(16, 77, 768, device=DEV, generator=g)
@@ -245,7 +245,7 @@ def test_groupnorm_folded_into_proj_in_matches_the_apply_pass():
     (per-sample scaled weights, launch_gn_fold): the same function as normalise-then-project up to one bf16 rounding placed
     elsewhere.  Full SD1.5 UNet call with and without the fold (tuning bit 12), and against each other per sample position."""
     cfg = gcfg.sd15_unet()
-    net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
+    net = GyreHipUNet(cfg).to(HDT).to(DEV)
     g = torch.Generator(device=DEV).manual_seed(0)
     with torch.no_grad():
         for k, p in net.named_parameters():
@@ -286,7 +286,7 @@ def test_small_problem_kernel_inside_the_unet_matches_the_4_wave_path(B):
     K slices).  Full SD1.5 UNet call with the kernel on and off (tuning bit 5): the same function - bit for bit where no split-K
     plan changed, else up to the order of a few fp32 sums - and it IS what runs."""
     cfg = gcfg.sd15_unet()
-    net = GyreHipUNet(cfg).to(torch.bfloat16).to(DEV)
+    net = GyreHipUNet(cfg).to(HDT).to(DEV)
     g = torch.Generator(device=DEV).manual_seed(1)
     with torch.no_grad():
         for k, p in net.named_parameters():

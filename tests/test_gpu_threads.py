@@ -15,7 +15,7 @@ import torch
 
 from gyre_amd import config as gcfg, weights
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
-from gpu_util import DEV
+from gpu_util import HDT, DEV
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 def _unet(cfg, seed):
     net = GyreHipUNet(cfg)
     net.load_state_dict(weights.synthetic_state_dict(weights.unet_param_shapes(cfg), seed))
-    return net.to(torch.bfloat16).to(DEV)
+    return net.to(HDT).to(DEV)
 
 
 def _inputs(cfg, B, hw, seed, S=77):
@@ -89,7 +89,7 @@ def test_unet_vae_and_error_paths_concurrently():
     unet = _unet(ucfg, 0)
     vae = GyreHipVAE(vcfg)
     vae.load_state_dict(weights.synthetic_state_dict(weights.vae_param_shapes(vcfg), 0))
-    vae = vae.to(torch.bfloat16).to(DEV)
+    vae = vae.to(HDT).to(DEV)
     bad = _unet(ucfg, 2)
     x, t, ctx = _inputs(ucfg, 2, 16, 3)
     z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4)).to(DEV)

@@ -16,14 +16,14 @@ from gyre_amd import _lib
 from gyre_amd import config as gcfg
 from gyre_amd import weights
 from gyre_amd.modules import GyreHipUNet, GyreHipVAE
-from gpu_util import DEV, bf16_round, randn, release_kept, report, st, vp
+from gpu_util import HDT, DEV, bf16_round, randn, release_kept, report, st, vp
 from oracle import models_ref as M
 
 pytestmark = pytest.mark.gpu
 
 
 def dev_bf16(t):
-    return t.to(torch.bfloat16).contiguous().to(DEV)
+    return t.to(HDT).contiguous().to(DEV)
 
 
 @pytest.mark.parametrize("B,H,W,C,C1,G,silu,add", [(2, 8, 8, 64, 64, 32, 1, 0), (2, 8, 8, 64, 32, 32, 1, 0),
@@ -45,8 +45,8 @@ def test_groupnorm_bwd(B, H, W, C, C1, G, silu, add):
     if add:
         ref = torch.cat([ref[..., :C1] + addend, ref[..., C1:]], -1)
     x1, x2 = dev_bf16(x[..., :C1]), (dev_bf16(x[..., C1:]) if C1 < C else None)
-    dx = torch.empty(B, HW, C1, dtype=torch.bfloat16, device=DEV)
-    dx2 = torch.empty(B, HW, C - C1, dtype=torch.bfloat16, device=DEV) if C1 < C else None
+    dx = torch.empty(B, HW, C1, dtype=HDT, device=DEV)
+    dx2 = torch.empty(B, HW, C - C1, dtype=HDT, device=DEV) if C1 < C else None
     need = L.gyre_op_groupnorm_bwd_workspace(B, HW, C, G)
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     _lib.check(L.gyre_op_groupnorm_bwd(st(), vp(x1), vp(x2), C1, B, HW, C, G, vp(gamma.to(DEV)), vp(beta.to(DEV)), 1e-5, silu,
@@ -67,7 +67,7 @@ def test_layernorm_bwd(M_, C, add):
     (ref,) = torch.autograd.grad(F.layer_norm(xr, (C,), gamma, beta, 1e-5), xr, dy)
     if add:
         ref = ref + addend
-    dx = torch.empty(M_, C, dtype=torch.bfloat16, device=DEV)
+    dx = torch.empty(M_, C, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_layernorm_bwd(st(), vp(dev_bf16(x)), vp(dev_bf16(dy)), M_, C, vp(gamma.to(DEV)), 1e-5,
                                        vp(dev_bf16(addend)) if add else None, vp(dx)))
     release_kept()
@@ -84,7 +84,7 @@ def test_geglu_bwd(M_, F_):
 
     def pack(v, g):   # packed column order of the GEGLU weight rows: 16 values then their 16 gates (kernels_elem.hip repack)
         return torch.stack([v.reshape(M_, F_ // 16, 16), g.reshape(M_, F_ // 16, 16)], 2).reshape(M_, 2 * F_)
-    dpre = torch.empty(M_, 2 * F_, dtype=torch.bfloat16, device=DEV)
+    dpre = torch.empty(M_, 2 * F_, dtype=HDT, device=DEV)
     _lib.check(L.gyre_op_geglu_bwd(st(), vp(dev_bf16(pack(val, gate))), vp(dev_bf16(dy)), M_, F_, vp(dpre)))
     release_kept()
     report(f"geglu_bwd {M_}x{F_}", dpre.float().cpu(), pack(dval, dgate), 2e-2)
@@ -112,9 +112,9 @@ def test_attention_bwd(B, heads, Nq, Nk, D, cross, presc):
     o = (logits.softmax(-1) @ split(vr, Nk)).permute(0, 2, 1, 3).reshape(B, Nq, C_)
     rq, rk, rv = torch.autograd.grad(o, (qr, kr, vr), d_o)
     o_dev = dev_bf16(o.detach())
-    dq = torch.zeros(B, Nq, C_, dtype=torch.bfloat16, device=DEV)
-    dk = torch.zeros(B, Nk, C_, dtype=torch.bfloat16, device=DEV) if not cross else None
-    dv = torch.zeros(B, Nk, C_, dtype=torch.bfloat16, device=DEV) if not cross else None
+    dq = torch.zeros(B, Nq, C_, dtype=HDT, device=DEV)
+    dk = torch.zeros(B, Nk, C_, dtype=HDT, device=DEV) if not cross else None
+    dv = torch.zeros(B, Nk, C_, dtype=HDT, device=DEV) if not cross else None
     need = L.gyre_op_attention_bwd_workspace(B, heads, Nq, Nk, D)
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
     _lib.check(L.gyre_op_attention_bwd(st(), vp(dev_bf16(q)), C_, vp(dev_bf16(k_in)), C_, vp(dev_bf16(v)), C_, vp(o_dev), C_,
