@@ -355,8 +355,9 @@ def test_unet_per_level_parity(full):
     out = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample
     torch.cuda.synchronize()
     for k in names:
-        report(f"{'sd15' if full else 'tiny'} unet level {k} {tuple(taps[k].shape)}", bufs[k].cpu(), taps[k], 2e-2)
-    report("unet eps", out.cpu(), ref, 3e-2)
+        # per-level gate: 2e-2 with bf16 storage; 5e-3 with fp16 storage (the fp16 flavour's run of this file)
+        report(f"{'sd15' if full else 'tiny'} unet level {k} {tuple(taps[k].shape)}", bufs[k].cpu(), taps[k], 5e-3 if HDT == torch.float16 else 2e-2)
+    report("unet eps", out.cpu(), ref, 5e-3 if HDT == torch.float16 else 3e-2)
     # a too-small tap buffer is an error, and taps do not persist into the following forward
     small = torch.empty(4, device=DEV)
     _lib.check(L.gyre_unet_debug_tap(C.c_void_p(net._handle), b"mid", C.c_void_p(small.data_ptr()), 16))
