@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512) void k_gemm8(GemmParams p, int tiles_m, int ti
             //  waiting for first-touch HBM latency: a K step moves 36.9 KB through the CU's vector-memory path, 576 cycles at its
             //  64 B per clock beside 640 cycles of MFMA - the path is as busy as the matrix pipe, and 40 more line requests per wave
             //  and step queue in front of the operand requests.  What bounds this tile is operand bytes per FLOP through that path
-            //  (DESIGN 4c), which neither a prefetch nor a split of K inside the workgroup changes.
+            //  (profiles/HISTORY.md 4c), which neither a prefetch nor a split of K inside the workgroup changes.
             //  Second experiment: the refill's request pieces issued FROM INSIDE the K step, one behind every second MFMA group (the
             //  way the pipelined kernel places its requests), instead of as a block behind the barrier - on the theory that 5 pieces x
             //  60 - 185 cycles of issue cost per wave were serialised in front of the MFMAs.  ISA as intended, bit-identical, and no

@@ -4,7 +4,7 @@
 //   C[M][N] = epilogue( A[M][K] * W[N][K]^T )          same contract as k_gemm8 / k_gemm4s (linear mode, bf16 row-major out)
 //
 // Why another kernel.  With K this short a BM x BN output tile lives for only 5 - 10 K steps, and every tile re-delivers its
-// A rows AND its W rows through the CU's load path (L2 -> LDS, ~37 GB/s per CU whatever issues the requests):
+// A rows AND its W rows through the CU's load path (L2 -> LDS, ~37 GB/s per CU whatever issues the requests - the round 1 - 4 model, withdrawn in round 5: profiles/HISTORY.md 4c):
 // 328 KB per 256x256 tile of the 64x64 FF1, ten tiles per CU, 9.7 us each at the load path's rate against 4.3 us of MFMA
 // time.  Here a workgroup (8 waves) OWNS 256 rows for its whole life: wave w keeps its 32 x K slab of A in REGISTERS as the
 // MFMA's second operand (KT = K / 16 fragments of 4 registers: 80 registers at K = 320, 160 at K = 640), loaded once, and

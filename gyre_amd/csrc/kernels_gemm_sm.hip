@@ -23,7 +23,7 @@
 // is launch and prologue, not the K chain.)
 // (A 128x128 tile for the problems whose 64x64 grid is more than one round - M = 2048, N = K = 1280: 640 tiles - was measured too:
 // 21.2 -> 22.1 us.  That problem moves 210 MB through the CUs' load paths with 64x64 tiles, 820 KB per CU = 22 us at the 37 GB/s a
-// CU's path delivers; 128x128 halves the bytes but leaves 96 CUs idle.  The 128x160 tile of the 8-wave kernel: 20 us.)
+// CU's path delivers (profiles/HISTORY.md 4c); 128x128 halves the bytes but leaves 96 CUs idle.  The 128x160 tile of the 8-wave kernel: 20 us.)
 // Same K order on one accumulator as every other tile config.
 // Replaces the cuBLAS GEMMs behind torch.nn.Linear in the third-party UNet the reference calls at
 // gyre/pipeline/unet/core.py:274 (BasicTransformerBlock to_q / to_k / to_v / to_out, proj_in / proj_out at the deep levels).
