@@ -116,6 +116,7 @@ _SIGS = {
     "gyre_debug_set_ar_workspace": (_i, [_vp, _sz]),
     "gyre_debug_set_wblk_workspace": (_i, [_vp, _sz]),
     "gyre_debug_attn_redo_count": (C.c_long, []),
+    "gyre_debug_xattn_stamps": (_i, [_vp]),
     "gyre_debug_force_attn_variant": (_i, [_i]),
     "gyre_debug_gemm_ablation": (_i, [_i]),
     "gyre_set_batch_invariant": (_i, [_i]),

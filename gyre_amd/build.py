@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgyre_hip.so")
 LIB_F16 = os.path.join(HERE, "libgyre_hip_f16.so")
-SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_sm.hip", "kernels_conv_out.hip", "kernels_attn.hip", "kernels_tome.hip", "kernels_bwd.hip", "model.hip", "model_vjp.hip"]
+SOURCES = ["kernels_elem.hip", "kernels_gemm.hip", "kernels_gemm4s.hip", "kernels_gemm_ar.hip", "kernels_gemm_sm.hip", "kernels_conv_out.hip", "kernels_attn.hip", "kernels_xattn.hip", "kernels_tome.hip", "kernels_bwd.hip", "model.hip", "model_vjp.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_shared.h", "model_impl.h", os.path.join("..", "..", "include", "gyre_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-Wno-unused-result", "-fno-gpu-rdc",

@@ -123,7 +123,7 @@ enum GyreKernelClass {
     KC_G8_CONV_128x160, KC_G8_X1, KC_G8_X2, KC_G8_X3, KC_G8_LIN_128x160,
     KC_G4S_192x320, KC_G4S_192x320_LIN, KC_G4S_256x256, KC_G4S_256x256_LIN, KC_G4S_128x320, KC_G4S_128x320_LIN,
     KC_G4S_128x256, KC_G4S_128x256_LIN, KC_G4S_256x320, KC_G4S_256x320_LIN,
-    KC_ATTN, KC_GN_STATS, KC_GN_APPLY, KC_LAYERNORM, KC_OTHER, KC_ATTN_BWD, KC_NORM_BWD, KC_SPLITK_REDUCE, KC_GEMM_AR, KC_GEMM_SM, KC_COUNT
+    KC_ATTN, KC_GN_STATS, KC_GN_APPLY, KC_LAYERNORM, KC_OTHER, KC_ATTN_BWD, KC_NORM_BWD, KC_SPLITK_REDUCE, KC_GEMM_AR, KC_GEMM_SM, KC_XATTN, KC_COUNT
 };
 struct GyreProfScope {  // RAII: records start/stop events around one launch when enabled
     int slot = -1;

@@ -187,6 +187,22 @@ struct AttnParams {
 };
 int launch_attention(hipStream_t st, const AttnParams& p);
 
+// ---- fused cross-attention block: to_q (+ folded LayerNorm) -> attention over the cached text keys -> to_out + residual (kernels_xattn.hip) ----
+struct XattnParams {
+    const bf16_t* x; int ldx;                 // [M][C] rows BEFORE the LayerNorm (also the residual)
+    const bf16_t* wq;                         // gamma-folded to_q weights [C][C] (launch_ln_fold)
+    const float* q_colsum; const float* q_bias;       // [C] colsum of W', folded bias
+    const float* ln_parts; int ln_nparts; const float* ln_stats; float ln_eps;
+    const bf16_t* k; const bf16_t* vt; int ldvt;     // context cache: K [B][Nk][C] (prescaled), V^T [B][C][ldvt]
+    const bf16_t* wo; const float* bo;       // to_out [C][C], [C]
+    bf16_t* out; int ldo;                     // [M][C]
+    float* rowstat_out;                       // [M][2] (one partial per row) or null
+    int M, rows_per_sample, Nk, heads;
+};
+
+bool xattn_supports(int C, int heads, int Nq, int Nk, int M);
+int launch_xattn(hipStream_t st, const XattnParams& p, int C);
+
 // ---- input-gradient kernels of the CLIP-guided mode (kernels_bwd.hip) ---------------------------------------------
 struct GnBwdParams {
     const bf16_t* x; const bf16_t* x2; int C1;       // forward input (x2 = second source of the skip concat, or null)

@@ -58,7 +58,7 @@ static const char* kclass_name(int k) {
         "k_gemm4s<192, 320, 2, 2, 1", "k_gemm4s<192, 320, 2, 2, 0", "k_gemm4s<256, 256, 2, 2, 1", "k_gemm4s<256, 256, 2, 2, 0",
         "k_gemm4s<128, 320, 2, 2, 1", "k_gemm4s<128, 320, 2, 2, 0", "k_gemm4s<128, 256, 2, 2, 1", "k_gemm4s<128, 256, 2, 2, 0", "k_gemm4s<256, 320, 4, 2, 1", "k_gemm4s<256, 320, 4, 2, 0",
         "k_attn", "k_gn_partial+k_gn_finalize", "k_gn_apply", "k_layernorm", "other", "k_attn_bwd", "k_gn_bwd+k_ln_bwd",
-        "k_splitk_reduce", "k_gemm_ar", "k_gemm_sm"};
+        "k_splitk_reduce", "k_gemm_ar", "k_gemm_sm", "k_xattn"};
     return (k >= 0 && k < KC_COUNT) ? n[k] : "?";
 }
 

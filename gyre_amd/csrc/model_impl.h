@@ -672,6 +672,35 @@ struct Exec {
             qp = q.p; kp = dry() ? nullptr : q.p + C; vtp = vt.p; ldq = ldk = 2 * C;
         } else {
             Nk = kv_rows_per_batch; ldvt = (Nk + 7) / 8 * 8;
+            // Round 6: the whole block - to_q with the folded LayerNorm, attention over the cached text keys, to_out + bias + residual
+            // and the row statistics for the next LayerNorm - as ONE kernel per 128 rows (kernels_xattn.hip) where the shape fits it
+            // (SD1.x's 64x64 level); inference path with a context cache only; tuning bit 13 of gyre_debug_gemm_ablation = off
+            if (ln && !sv && ctx_cache && store && !w.bq && w.k_prescaled && residual.p == xq_in.p && !(gemm_planner_state() & 0x2000L) &&
+                xattn_supports(C, w.heads, Nq, Nk, B * Nq)) {
+                if (ctx_layer >= ctx_cache->size()) GYRE_FAIL(GYRE_ERR_INVALID, "internal: context cache layer overflow");
+                GemmParams pq;                         // describes to_q for the LayerNorm fold (weights W' = W gamma, colsum, bias')
+                pq.A = xq_in.p; pq.lda = C; pq.mode = GEMM_LINEAR; pq.W = w.wq; pq.K = C; pq.N = C; pq.M = B * Nq; pq.bias = nullptr;
+                Tn stats;
+                TRY(ln_fold_into(pq, *ln, stats));
+                TRY(alloc(out, B, xq.H, xq.W, C));
+                if (rs_out) {
+                    rs_out->nparts = 1;
+                    TRY(alloc_raw(rs_out->t, (size_t)B * Nq * 2 * sizeof(float)));
+                }
+                if (!dry()) {
+                    XattnParams xp;
+                    xp.x = xq_in.p; xp.ldx = C; xp.wq = pq.W; xp.q_colsum = pq.ln_colsum; xp.q_bias = pq.bias;
+                    xp.ln_parts = pq.ln_parts; xp.ln_nparts = pq.ln_nparts; xp.ln_stats = pq.ln_stats; xp.ln_eps = 1e-5f;
+                    xp.k = (*ctx_cache)[ctx_layer].k; xp.vt = (*ctx_cache)[ctx_layer].vt; xp.ldvt = ldvt;
+                    xp.wo = w.wo; xp.bo = w.bo; xp.out = out.p; xp.ldo = C;
+                    xp.rowstat_out = rs_out ? (float*)rs_out->t.p : nullptr;
+                    xp.M = B * Nq; xp.rows_per_sample = Nq; xp.Nk = Nk; xp.heads = w.heads;
+                    TRY(launch_xattn(st, xp, C));
+                }
+                ++ctx_layer;
+                free(stats);
+                return 0;
+            }
             TRY(alloc(q, B, xq.H, xq.W, C));
             if (ln) {
                 TRY(ln_linear(xq_in, *ln, w.wq, C, w.bq, 0, q.p, C));

@@ -283,6 +283,9 @@ int gyre_debug_force_attn_variant(int v);
  * this process (always counted since round 6: the increment sits on the redo path only; one blocking 4-byte read-back per call;
  * -1: no device / allocation failure).  bench.py reports the count of its timed region as `attn_redo_count`. */
 long gyre_debug_attn_redo_count(void);
+/* Tuning only: per-workgroup cycle stamps of the fused cross-attention kernel's phase boundaries (8 x uint64 per workgroup of the
+ * last launch) into a caller-allocated device buffer; NULL = off (tools/r06_xattn_phases.py). */
+int gyre_debug_xattn_stamps(void* dev_buf);
 /* Tuning only.  Ablations (results are garbage): bit0 = skip the operand loads inside the K loop, bit1 = skip the MFMAs,
  * bit2 = no epilogue.  Planner switches for same-box A/B runs (results stay valid): bit8 = default tile order, bit9 = conv
  * zero padding from a zero page in the pipelined kernel, bit10 = no pipelined (32x32x16) tile configs, bit11 = LayerNorm as a
@@ -297,8 +300,9 @@ long gyre_debug_attn_redo_count(void);
  * the long-K few-row linear problems from the split-K path.  Round 5: bit24 = the two-stage K loop in the 8-wave kernels' linear mode
  * (instead of the 2 - 4 stage LDS ring with counted waits), bit25 = the deep ring at one workgroup per CU also where two 2-stage
  * workgroups would fit, bit26 = row-major weights everywhere (no blocked weight copies for the LDS-DMA kernels), bit27 = the two-stage K loop for the
- * 128x160 tile's 3x3 convolutions (instead of the same ring).  (Bits 7 and 13 -
- * the small kernel's LayerNorm fold and the W-resident kernel - went with the code they switched on.)
+ * 128x160 tile's 3x3 convolutions (instead of the same ring).  Round 6: bit13 = no fused cross-attention kernel (kernels_xattn.hip:
+ * to_q -> attention -> to_out of SD1.x's 64x64 level in one launch): the three-launch chain as before.  (Bit 7 - the small kernel's
+ * LayerNorm fold - went with the code it switched on.)
  * Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores.
  * These switches are PER CALLING THREAD (thread-local, like gyre_set_batch_invariant): they never change what another thread's
  * handle computes. */
