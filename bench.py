@@ -46,7 +46,7 @@ VAE_DEC_TFLOP = 2.515           # 1257 GMAC @ 512^2
 MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 # kernel classes timed live during the timed region; the one with the largest total is reported as the dominant kernel
-CANDIDATES = ["k_gemm8<", "k_gemm4s<", "k_attn"]
+CANDIDATES = ["k_gemm8<", "k_gemm4s<", "k_attn", "k_xattn"]
 HBM_CLASSES = ["k_gn_", "k_layernorm"]
 
 
@@ -576,7 +576,7 @@ def main():
                             "gbps": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBPS, 4)}
             out["kernel_classes"] = table
             fams = {"k_gemm8 (non-pipelined tile GEMMs / convs)": ("k_gemm8<",), "k_gemm4s (pipelined convs / long-K GEMMs)": ("k_gemm4s<",),
-                    "k_attn": ("k_attn",), "k_gemm_ar": ("k_gemm_ar",), "k_gemm_sm + 4-wave k_gemm": ("k_gemm_sm", "k_gemm<"),
+                    "k_attn": ("k_attn",), "k_xattn (fused cross-attention block)": ("k_xattn",), "k_gemm_ar": ("k_gemm_ar",), "k_gemm_sm + 4-wave k_gemm": ("k_gemm_sm", "k_gemm<"),
                     "GroupNorm (k_gn_*)": ("k_gn_",), "split-K reduction": ("k_splitk",), "LayerNorm": ("k_layernorm",)}
             fam = {}
             for fname, prefixes in fams.items():
