@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_sm(GemmParams p, int tiles_m, i
     // Round 5: the epilogue's bias and residual rows are requested HERE, in front of the ring (by hand: a compiler-visible load
     // would put the compiler's own vmcnt bookkeeping into the counted loop).  They are older than every ring request, so the first
     // counted wait covers them, and the epilogue no longer ends the launch with one more cold round trip.
+    // INVARIANT (the compiler does not know these "=v" registers are pending until the vmcnt(0) behind the K loop): no instruction on
+    // any path between a request and that wait may read or write its destination registers - no copy, no spill, no re-materialisation.
+    // Checked on the ISA of every build: tests/test_host_cpu.py::test_hand_issued_loads_stay_untouched_until_their_wait.
     typedef unsigned sm_u32x4 __attribute__((ext_vector_type(4)));
     sm_u32x4 e_res[2], e_b0[2], e_b1[2];
     const bool e_plain = !(p.vt_out && n0 >= p.vt_col0);

@@ -203,3 +203,62 @@ def test_gemm4s_lds_swizzle_is_conflict_free():
             for g in groups:
                 slots = {(addr[l] % 256) // 16 for l in g}
                 assert len(slots) == 16, (base, ks, g)
+
+
+def test_hand_issued_loads_stay_untouched_until_their_wait():
+    """Advisor (round 5): the small-problem GEMM requests its epilogue's bias / residual rows with hand-written
+    `global_load_dwordx4` into "=v" outputs in FRONT of the LDS-DMA ring, so that the first counted wait covers them - but the
+    compiler does not know those registers are pending: a copy, spill or re-materialisation it placed between the request and the
+    `s_waitcnt vmcnt(0)` behind the K loop would read stale data silently.  The invariant is checked on the ISA of every build:
+    between each such request and that wait no instruction reads or writes the destination registers (both storage flavours)."""
+    import re
+    import shutil
+    import tempfile
+    from gyre_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(B.CSRC, "kernels_gemm_sm.hip")
+    checked = 0
+    for extra in ([], ["-DGYRE_STORE_F16"]):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            r = subprocess.run([hipcc, *B.FLAGS, *extra, "--offload-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            text = open(out).read()
+        # one block of lines per kernel; the scan follows the control flow (a register initialisation on the path that does NOT issue
+        # the requests sits textually between a request and the wait without being reachable from it)
+        for m in re.finditer(r"^(_Z9k_gemm_sm\w+):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+            lines = [ln.split(";")[0].strip() for ln in m.group(2).splitlines()]
+            lines = [ln for ln in lines if ln and not (ln.startswith(".") and not ln.endswith(":"))]
+            label_at = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
+            first_barrier = next(i for i, ln in enumerate(lines) if ln.startswith("s_barrier"))
+            wait = next(i for i, ln in enumerate(lines) if i > first_barrier and re.fullmatch(r"s_waitcnt vmcnt\(0\)", ln))
+            loads = [(i, ln) for i, ln in enumerate(lines[:first_barrier]) if ln.startswith("global_load_dwordx4") and "lds" not in ln]
+            assert loads, "the hand-issued epilogue requests are gone: update this test with the kernel"
+
+            def reachable(start):
+                seen, todo = set(), [start]
+                while todo:
+                    i = todo.pop()
+                    while i < len(lines) and i not in seen and i != wait:
+                        seen.add(i)
+                        ln = lines[i]
+                        br = re.match(r"s_(c?branch\w*)\s+(\S+)", ln)
+                        if br:
+                            todo.append(label_at[br.group(2)])
+                            if br.group(1) == "branch":
+                                break
+                        i += 1
+                return seen
+
+            for i, ln in loads:
+                a, b = map(int, re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\]", ln).groups())
+                dest = set(range(a, b + 1))
+                path = reachable(i + 1)
+                assert path, "no path from the request to the wait?"
+                for j in sorted(path):
+                    used = set(int(x) for x in re.findall(r"\bv(\d+)\b", lines[j]))
+                    for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", lines[j]):
+                        used |= set(range(int(lo), int(hi) + 1))
+                    assert not (used & dest), f"{m.group(1)}: `{lines[j]}` touches v[{a}:{b}] between its request and the wait"
+                checked += 1
+    assert checked >= 8          # two kernels x (2 + 4) requests x two flavours, at least
