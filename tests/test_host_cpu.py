@@ -16,11 +16,12 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "gyre_hip.h")).read()
     declared = set(re.findall(r"\b(gyre_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
-    L = _lib.lib()  # loads and binds every symbol of _SIGS
-    for name in declared:
-        assert hasattr(L, name), f"{name} declared in gyre_hip.h but not exported"
+    for storage in (_lib.BF16, _lib.F16):           # both storage builds export the same ABI
+        L = _lib.lib(storage)  # loads and binds every symbol of _SIGS
+        for name in declared:
+            assert hasattr(L, name), f"{name} declared in gyre_hip.h but not exported"
+        assert L.gyre_abi_version() == 1 and L.gyre_storage_dtype() == storage
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert L.gyre_abi_version() == 1
 
 
 def test_unet_state_dict_is_diffusers_keyed():
