@@ -151,6 +151,7 @@ _SIGS = {
                                    _vp, _i, _vp, _i, _vp, _i]),
     "gyre_op_tome_workspace": (_sz, [_i, _i, _i]),
     "gyre_op_tome_merge": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
+    "gyre_op_cross_attention_block": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "gyre_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gyre_op_copy_probe": (_i, [_vp, _vp, _vp, _sz]),
 }

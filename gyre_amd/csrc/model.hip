@@ -612,6 +612,31 @@ int gyre_op_attention_ex(void* st, const void* q, int ldq, const void* k, int ld
     a.o = (bf16_t*)o; a.ldo = ldo; a.B = B; a.H = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = k_prescaled ? 1 : 0;
     return launch_attention((hipStream_t)st, a);
 }
+// The cross-attention block of a BasicTransformerBlock as the fused kernel runs it (kernels_xattn.hip):
+//   out = softmax(LayerNorm(x) Wq^T . K^T) V Wo^T + bo + x, row_stats[m] = (sum, sum of squares) of the rounded out[m][:]
+// x [M][C] (rows before the LayerNorm, M = B * tokens), wq / wo [C][C] repacked, k [B][Nk][C] PRESCALED by log2(e) / sqrt(C / heads),
+// vt [B][C][ldvt] (V transposed, ldvt >= Nk rounded up to 8).  ws: gyre_op_ln_linear_workspace(C, C, M) bytes.  GYRE_ERR_UNSUPPORTED
+// outside the kernel's domain (xattn_supports: C = 320, 8 heads, Nk <= 80, tokens % 128 == 0, M / 128 >= 256).
+int gyre_op_cross_attention_block(void* st, const void* x, int M, int tokens, int C, int heads, const float* gamma, const float* beta,
+                                  float eps, const void* wq, const void* k, const void* vt, int Nk, int ldvt, const void* wo,
+                                  const float* bo, void* ws, size_t ws_bytes, void* out, float* row_stats) {
+    if (!x || !gamma || !beta || !wq || !k || !vt || !wo || !ws || !out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    if (tokens <= 0 || M % tokens) GYRE_FAIL(GYRE_ERR_INVALID, "cross_attention_block: M must be a multiple of tokens");
+    if (!xattn_supports(C, heads, tokens, Nk, M)) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "cross_attention_block: shape outside the fused kernel's domain");
+    if (ws_bytes < gyre_op_ln_linear_workspace(C, C, M)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "cross_attention_block: workspace too small");
+    bf16_t* wf = (bf16_t*)ws;
+    float* cs = (float*)((char*)ws + align_up((size_t)C * C * 2, 256));
+    float* bb = (float*)((char*)cs + align_up((size_t)C * 4, 256));
+    float* stats = (float*)((char*)bb + align_up((size_t)C * 4, 256));
+    TRY(launch_ln_fold((hipStream_t)st, (const bf16_t*)wq, C, C, gamma, beta, nullptr, wf, cs, bb));
+    TRY(launch_layernorm_stats((hipStream_t)st, (const bf16_t*)x, M, C, eps, stats));
+    XattnParams xp;
+    xp.x = (const bf16_t*)x; xp.ldx = C; xp.wq = wf; xp.q_colsum = cs; xp.q_bias = bb;
+    xp.ln_parts = nullptr; xp.ln_nparts = 0; xp.ln_stats = stats; xp.ln_eps = eps;
+    xp.k = (const bf16_t*)k; xp.vt = (const bf16_t*)vt; xp.ldvt = ldvt; xp.wo = (const bf16_t*)wo; xp.bo = bo;
+    xp.out = (bf16_t*)out; xp.ldo = C; xp.rowstat_out = row_stats; xp.M = M; xp.rows_per_sample = tokens; xp.Nk = Nk; xp.heads = heads;
+    return launch_xattn((hipStream_t)st, xp, C);
+}
 int gyre_op_nchw_to_nhwc(void* st, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y) {
     if (!x || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     return launch_nchw_to_nhwc((hipStream_t)st, x, dtype, B, C, HW, Cpad, (bf16_t*)y);

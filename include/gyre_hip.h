@@ -437,6 +437,15 @@ size_t gyre_op_tome_workspace(int B, int N, int C);
 int gyre_op_tome_merge(void* stream, const void* k, int ldk, const void* v, int ldv, int B, int N, int C, int r,
                        void* workspace, size_t workspace_bytes, void* k_out, void* vt_out, int ldvt,
                        int32_t* order_out, int32_t* node_idx_out);
+/* The cross-attention block of a transformer block as ONE launch (round 6, kernels_xattn.hip; the model runs it for the attn2 module of
+ * diffusers' BasicTransformerBlock at SD1.x's 64x64 level): out = softmax(LayerNorm(x) Wq^T . K^T) V Wo^T + bo + x and, if row_stats
+ * is not NULL, per row the (sum, sum of squares) of the rounded outputs.  x [M][C] = the rows BEFORE the LayerNorm (M = B * tokens),
+ * wq / wo [C][C] repacked, k [B][Nk][C] already multiplied by log2(e) / sqrt(C / heads), vt [B][C][ldvt] = V transposed (ldvt >= Nk
+ * rounded up to 8).  ws: gyre_op_ln_linear_workspace(C, C, M) bytes.  GYRE_ERR_UNSUPPORTED outside the kernel's domain (C = 320,
+ * 8 heads, Nk <= 80, tokens % 128 == 0, M / 128 >= 256). */
+int gyre_op_cross_attention_block(void* stream, const void* x, int M, int tokens, int C, int heads, const float* gamma,
+                                  const float* beta, float eps, const void* wq, const void* k_prescaled, const void* vt, int Nk,
+                                  int ldvt, const void* wo, const float* bo, void* ws, size_t ws_bytes, void* out, float* row_stats);
 int gyre_op_nchw_to_nhwc(void* stream, const void* x, int dtype, int B, int C, int HW, int Cpad, void* y_bf16);
 /* Device-side memcpy-rate probe used by bench.py to calibrate the HBM roofline on the box. */
 int gyre_op_copy_probe(void* stream, const void* src, void* dst, size_t bytes);

@@ -1212,3 +1212,49 @@ def test_colstats_entry_points_reject_bad_integers():
                                        None, 0, C.byref(rows))
         assert rc == -1, (rps, unit, rc)
     assert L.gyre_op_gemm_splitk_bytes(1, 0, 320, 2880, 1) == 0 and L.gyre_op_gemm_splitk_bytes(1, 4096, 320, 2881, 1) == 0
+
+
+# ---- the cross-attention block as one launch (kernels_xattn.hip; gyre_op_cross_attention_block) -----------------------------------
+@pytest.mark.parametrize("B,Nk,bias", [(8, 77, True), (8, 80, False), (16, 33, True), (8, 1, True)])
+def test_fused_cross_attention_block_operator(B, Nk, bias):
+    """out = softmax(LayerNorm(x) Wq^T K^T / sqrt(d)) V Wo^T + bo + x at SD1.x's 64x64 shape (C = 320, 8 heads of 40, 4096 tokens per
+    sample) against fp32 ATen on storage-rounded operands, for a full text chunk, the largest key count the kernel takes, a key count
+    that leaves whole key fragments empty, and a single key; plus the per-row (sum, sum of squares) of the rounded outputs that the
+    next folded LayerNorm consumes, and the refusals outside the kernel's domain."""
+    L = _lib.lib()
+    C_, heads, tokens = 320, 8, 4096
+    D = C_ // heads
+    M = B * tokens
+    x = bf16_round(randn(M, C_, seed=301) * 1.5 + 0.2)
+    g, be = randn(C_, seed=302) * 0.2 + 1, randn(C_, seed=303) * 0.2
+    wq = bf16_round(randn(C_, C_, seed=304) / math.sqrt(C_))
+    wo = bf16_round(randn(C_, C_, seed=305) / math.sqrt(C_))
+    bo = randn(C_, seed=306) * 0.1 if bias else None
+    k = bf16_round(randn(B, Nk, C_, seed=307))
+    v = bf16_round(randn(B, Nk, C_, seed=308))
+    # reference (fp32): the module chain of diffusers' BasicTransformerBlock.attn2 on norm2(x)
+    xn = F.layer_norm(x, (C_,), g, be, 1e-5)
+    q = F.linear(xn, wq).reshape(B, tokens, C_)
+    ref = F.linear(attn_ref(q, k, v, heads).reshape(M, C_), wo, bo) + x
+    # device operands: K prescaled by log2(e) / sqrt(D) (what the weight repack folds into to_k), V transposed and padded to 8 keys
+    ldvt = (Nk + 7) // 8 * 8
+    kpre = (k * (1.4426950408889634 / math.sqrt(D))).to(HDT).contiguous().to(DEV)
+    vt = torch.full((B, C_, ldvt), float("nan"), dtype=HDT, device=DEV)              # padding = NaN on purpose
+    vt[:, :, :Nk] = v.permute(0, 2, 1).to(HDT).to(DEV)
+    out = torch.empty(M, C_, dtype=HDT, device=DEV)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=DEV)
+    ws = torch.empty(L.gyre_op_ln_linear_workspace(C_, C_, M), dtype=torch.uint8, device=DEV)
+    _lib.check(L.gyre_op_cross_attention_block(st(), vp(to_dev_bf16(x)), M, tokens, C_, heads, vp(g.to(DEV)), vp(be.to(DEV)), 1e-5,
+                                               vp(repack_linear(wq)), vp(kpre), vp(vt), Nk, ldvt, vp(repack_linear(wo)),
+                                               vp(bo.to(DEV)) if bias else None, vp(ws), ws.numel(), vp(out), vp(stats)))
+    got = out.float().cpu()
+    assert bool(torch.isfinite(got).all())
+    report(f"fused cross-attention block B{B} Nk{Nk}", got, ref, 8e-3)
+    s_ref = torch.stack([got.sum(1), (got * got).sum(1)], dim=1)                    # statistics of what was stored
+    assert torch.allclose(stats.cpu(), s_ref, rtol=2e-4, atol=2e-2)
+    # outside the domain: too few rows for a full grid, too many keys, rows that straddle samples -> GYRE_ERR_UNSUPPORTED (-6)
+    for (M_, tok_, nk_) in ((4 * tokens, tokens, Nk), (M, tokens, 81), (M, 4000, Nk)):
+        rc = L.gyre_op_cross_attention_block(st(), vp(to_dev_bf16(x)), M_, tok_, C_, heads, vp(g.to(DEV)), vp(be.to(DEV)), 1e-5,
+                                             vp(repack_linear(wq)), vp(kpre), vp(vt), nk_, ldvt, vp(repack_linear(wo)), None,
+                                             vp(ws), ws.numel(), vp(out), None)
+        assert rc in (-6, -1), rc
