@@ -135,6 +135,7 @@ _SIGS = {
     "gyre_op_linear_rowstats_parts": (_i, [_i, _i, _i, _i]),
     "gyre_op_linear_rowstats": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "gyre_op_conv3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "gyre_op_conv3x3_shortcut": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "gyre_op_conv3x3_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i]),
     "gyre_op_repack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gyre_op_repack_linear_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -142,6 +142,13 @@ struct GemmParams {
     // w_sample_stride (elements); row blocks never straddle a sample (gemm_per_sample_w_ok).  The GroupNorm folded into a
     // Transformer2D's proj_in (launch_gn_fold); the per-sample bias travels as `rowbias`
     size_t w_sample_stride = 0;
+    // 1x1 SHORTCUT folded into a 3x3 convolution as extra K steps (round 6; pipelined 256x320 tile only, stride 1, pad 1, no upsample):
+    //   out = conv3x3(A | A2) + (S | S2) Wsc^T + bias        (the resnet's conv2 + conv_shortcut of a channel-changing / concat block)
+    // Behind the nine taps of every 64-channel chunk of the conv input the K loop walks sc_K more channels of a second image pair
+    // (same H x W as the output, split at sc_C1 like A | A2) through the CENTRE tap.  W holds [N][9 Cin + sc_K] rows (the conv's rows
+    // followed by the shortcut's: launch_concat_rows), K = 9 Cin + sc_K, bias = the sum of the two biases.  gemm_conv_shortcut_ok(p)
+    // says whether launch_gemm would run `p` on a kernel that knows the form.
+    const bf16_t* sc_A = nullptr; const bf16_t* sc_A2 = nullptr; int sc_lda = 0, sc_lda2 = 0, sc_C1 = 0, sc_K = 0;
     // conv: circular instead of zero padding along x (bit 0) / y (bit 1) - the reference's request option "tiling"
     // (unified_pipeline.py:1671-1712 patches every Conv2d's own padding to F.pad(mode="circular")); 4-wave tile configs only
     int wrap = 0;
@@ -152,6 +159,10 @@ int gemm_colstat_rows(const GemmParams& p);
 int gemm_rowstat_parts(const GemmParams& p);
 // true when launch_gemm would run `p` on a kernel that reads per-sample weights (w_sample_stride; rows_per_sample set)
 bool gemm_per_sample_w_ok(const GemmParams& p);
+// true when launch_gemm would run `p` (sc_* set) on the kernel that folds the 1x1 shortcut into the 3x3 convolution
+bool gemm_conv_shortcut_ok(const GemmParams& p);
+// out[n][0:K1] = a[n][0:K1], out[n][K1:K1+K2] = b[n][0:K2] (bf16 rows; K1, K2 multiples of 8): the folded conv + shortcut weight
+int launch_concat_rows(hipStream_t st, const bf16_t* a, int K1, const bf16_t* b, int K2, int N, bf16_t* out);
 // true when launch_gemm would run `p` (ln_colsum set or not) on a kernel that supports the folded LayerNorm
 bool gemm_ln_fusable(const GemmParams& p);
 // W'[n][k] = bf16(W[n][k] * gamma[k]); colsum[n] = sum_k W'[n][k]; bias_out[n] = sum_k beta[k] * W[n][k] + (bias ? bias[n] : 0)

@@ -128,6 +128,22 @@ __global__ void k_add_f32(float* __restrict__ y, const float* __restrict__ x, si
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];
 }
+__global__ __launch_bounds__(256) void k_concat_rows(const bf16_t* __restrict__ a, int K1, const bf16_t* __restrict__ b, int K2, int N,
+                                                     bf16_t* __restrict__ out) {
+    const int kv = (K1 + K2) >> 3;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)N * kv) return;
+    const int n = (int)(t / kv), k = (int)(t - (size_t)n * kv) * 8;
+    const uint4 v = k < K1 ? *(const uint4*)(a + (size_t)n * K1 + k) : *(const uint4*)(b + (size_t)n * K2 + (k - K1));
+    *(uint4*)(out + (size_t)n * (K1 + K2) + k) = v;
+}
+int launch_concat_rows(hipStream_t st, const bf16_t* a, int K1, const bf16_t* b, int K2, int N, bf16_t* out) {
+    if (K1 % 8 || K2 % 8 || N < 1) GYRE_FAIL(-1, "concat_rows: row lengths must be multiples of 8");
+    const size_t total = (size_t)N * ((K1 + K2) / 8);
+    hipLaunchKernelGGL(k_concat_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, K1, b, K2, N, out);
+    GYRE_LAUNCH_CHECK();
+    return 0;
+}
 int launch_add_f32(hipStream_t st, float* y, const float* x, size_t n) {
     hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n);
     GYRE_LAUNCH_CHECK();

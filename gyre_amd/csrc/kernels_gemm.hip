@@ -1514,6 +1514,23 @@ bool gemm_per_sample_w_ok(const GemmParams& p0) {
     const int bm = (cfg == 4 || cfg == 6) ? 256 : 128;
     return p.rows_per_sample % bm == 0;
 }
+bool gemm_conv_shortcut_ok(const GemmParams& p0) {
+    GemmParams p = p0;
+    p.debug = g_gemm_debug;
+    if (g_force_cfg || p.force_cfg || (p.debug & 0x80)) return false;        // tuning bit 7: the shortcut stays its own launch
+    // batch-invariant planning: whether the conv gets the pipelined tile depends on M = batch x rows, and the folded form rounds once
+    // where the two launches round twice - so that mode keeps the two launches for every batch size (as it keeps the separate LayerNorm)
+    if (g_invariant_batch > 0) return false;
+    if (p.mode != GEMM_CONV3 || !p.sc_K || p.sc_K % BK || p.Cin % BK || p.K != 9 * p.Cin + p.sc_K || p.stride != 1 || p.pad != 1 || p.ups ||
+        p.Hi != p.Ho || p.Wi != p.Wo || p.wrap || p.batch > 1 || p.out_mode != OUT_BF16)
+        return false;
+    if (!p.A2) { p.C1 = p.Cin; p.A2 = p.A; p.lda2 = p.lda; }
+    if (p.C1 % BK) return false;
+    if (p.rows_per_sample <= 0) p.rows_per_sample = 1;
+    int splits = 1;
+    const int cfg = plan_cfg(p, &splits);
+    return cfg == 24 && gemm4s_supports(p, 24);
+}
 bool gemm_ln_fusable(const GemmParams& p0) {
     GemmParams p = p0;
     p.debug = g_gemm_debug;
@@ -1641,7 +1658,10 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (!p.A2) { p.C1 = p.mode == GEMM_LINEAR ? p.K : p.Cin; p.A2 = p.A; p.lda2 = p.lda; }
     if (p.C1 % 8) GYRE_FAIL(-1, "gemm: source split must be a multiple of 8");
     if (p.mode == GEMM_CONV3) {
-        if (p.Cin % 8 || p.K != 9 * p.Cin) GYRE_FAIL(-1, "conv3x3: Cin must be a multiple of 8 and K == 9*Cin");
+        if (p.Cin % 8 || p.K != 9 * p.Cin + p.sc_K) GYRE_FAIL(-1, "conv3x3: Cin must be a multiple of 8 and K == 9*Cin (+ the folded shortcut's channels)");
+        if (p.sc_K && (p.sc_K % BK || p.Cin % BK || !p.sc_A || p.stride != 1 || p.pad != 1 || p.ups || p.Hi != p.Ho || p.Wi != p.Wo || p.wrap ||
+                       (p.sc_A2 && p.sc_A2 != p.sc_A && (p.sc_C1 <= 0 || p.sc_C1 >= p.sc_K || p.sc_C1 % BK))))
+            GYRE_FAIL(-1, "conv3x3: a folded shortcut needs a stride-1 / pad-1 convolution and whole 64-channel steps on both sides");
     }
     if (p.out_mode == OUT_BF16 && (p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)))
         GYRE_FAIL(-1, "gemm: N / ldc / ldr must be multiples of 4 for bf16 row-major output");
@@ -1660,6 +1680,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
     if (p.ln_colsum && (p.mode != GEMM_LINEAR || p0.A2 || !p.bias || (!p.ln_stats && p.ln_nparts <= 0) || (p.ln_nparts > 0 && !p.ln_parts) ||
                         p.rowbias || p.out_mode != OUT_BF16 || p.batch > 1))
         GYRE_FAIL(-1, "gemm: the folded LayerNorm needs a single-source linear problem with row statistics, bias and bf16 row-major output");
+    if (p.sc_K && (!p.sc_A2 || p.sc_A2 == p.sc_A)) { p.sc_A2 = p.sc_A; p.sc_lda2 = p.sc_lda; p.sc_C1 = p.sc_K; }
     int splits = 1;
     int cfg = plan_cfg(p, &splits);
     {   // tuning aid (tools/gemm_sweep.py): GYRE_GEMM_DUMP=1 prints every problem shape with the planner's choice
@@ -1696,6 +1717,7 @@ int launch_gemm(hipStream_t st, const GemmParams& p0) {
             GYRE_FAIL(-6, "gemm: per-sample weights need an unsplit 8-wave tile config whose row blocks do not straddle samples (gemm_per_sample_w_ok)");
     }
     if (p.mode == GEMM_CONV3 && p.wrap && cfg > 3) GYRE_FAIL(-6, "gemm: circular padding (tiling) exists in the 4-wave tile configs only");
+    if (p.sc_K && cfg != 24) GYRE_FAIL(-6, "gemm: the folded shortcut exists in the pipelined 256x320 tile only (see gemm_conv_shortcut_ok)");
     if (!p.W_blk && g_dbg_blk_ws && gemm_w_block_wanted(p0) && g_dbg_blk_ws_bytes >= (size_t)p.N * p.K * 2) {   // tests / tuning
         int rc = launch_w_block(st, p.W, p.N, p.K, g_dbg_blk_ws);
         if (rc) return rc;

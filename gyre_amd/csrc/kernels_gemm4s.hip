@@ -157,7 +157,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
         srdA = make_srd(cA, (unsigned)(b1 < 0x7ffffff0ull ? b1 : 0x7ffffff0ull));
         srdA2 = make_srd(cA2, (unsigned)(b2 < 0x7ffffff0ull ? b2 : 0x7ffffff0ull));
     }
-
+    // folded 1x1 shortcut (GemmParams::sc_*): a second image pair of the output's size, walked through the centre tap BEHIND the conv's K
+    // steps.  The conv sources are dead from the first shortcut step on, so that step REPLACES them (bases, buffer descriptors, strides,
+    // split) instead of carrying a second set through the loop - the kernel sits at 82 of ~100 scalar registers, and a "s" asm
+    // operand that no longer fits is silently handed over in vector registers.  step_src is called with non-decreasing kc.
+    const int nk_conv = MODE == GEMM_CONV3 ? 9 * (p.Cin / BK) : 0;
+    int src_C1 = p.C1;
+    unsigned src_ld = (unsigned)p.lda * 2u, src_ld2 = (unsigned)p.lda2 * 2u;
+    bool on_shortcut = false;
     // Uniform description of one K step's sources.  A step past the end of this block's K range is requested all the
     // same, from the zero page / out of range (every lane the same 16 bytes): the loop body stays one straight-line block.
     struct StepSrc { const char* ab; const char* wb; srd_t srd; unsigned soff, ld2; int ky, kx; bool live, live_w; };
@@ -171,13 +178,32 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void k_gemm4s(GemmParams
             kw = kc * BK;
             s.ab = live ? a_tile + (size_t)kw * 2 : (const char*)zero;
         } else {
-            const int chunk = kc / 9, tap = kc - chunk * 9;
-            s.ky = tap / 3; s.kx = tap - s.ky * 3;
-            const int c0 = chunk * BK;
-            kw = tap * p.Cin + c0;
-            const bool first = c0 < p.C1;
-            s.soff = (unsigned)(first ? c0 : c0 - p.C1) * 2u;
-            s.ld2 = (unsigned)(first ? p.lda : p.lda2) * 2u;
+            int c0;
+            if (kc >= nk_conv && p.sc_K) {                  // (wave-uniform) a K step of the folded shortcut: centre tap of the second image pair
+                if (!on_shortcut) {                         // once: the shortcut's sources take the conv sources' place
+                    on_shortcut = true;
+                    cA = (const char*)(p.sc_A + spix * p.sc_lda);
+                    cA2 = (const char*)(p.sc_A2 + spix * p.sc_lda2);
+                    src_C1 = p.sc_C1; src_ld = (unsigned)p.sc_lda * 2u; src_ld2 = (unsigned)p.sc_lda2 * 2u;
+                    if (ZFILL == 0) {
+                        const size_t left = (size_t)(p.M / hw_o - ns0) * p.Hi * p.Wi;
+                        const size_t b1 = left * p.sc_lda * 2, b2 = left * p.sc_lda2 * 2;
+                        srdA = make_srd(cA, (unsigned)(b1 < 0x7ffffff0ull ? b1 : 0x7ffffff0ull));
+                        srdA2 = make_srd(cA2, (unsigned)(b2 < 0x7ffffff0ull ? b2 : 0x7ffffff0ull));
+                    }
+                }
+                c0 = (kc - nk_conv) * BK;
+                s.ky = p.pad; s.kx = p.pad;
+                kw = 9 * p.Cin + c0;
+            } else {
+                const int chunk = kc / 9, tap = kc - chunk * 9;
+                s.ky = tap / 3; s.kx = tap - s.ky * 3;
+                c0 = chunk * BK;
+                kw = tap * p.Cin + c0;
+            }
+            const bool first = c0 < src_C1;
+            s.soff = (unsigned)(first ? c0 : c0 - src_C1) * 2u;
+            s.ld2 = first ? src_ld : src_ld2;
             s.srd = first ? srdA : srdA2;
             s.ab = (first ? cA : cA2) + s.soff;
         }
@@ -547,7 +573,7 @@ bool gemm4s_supports(const GemmParams& p, int cfg) {
     if (p.geglu && p.N % 32) return false;
     const int c1 = p.A2 ? p.C1 : (p.mode == GEMM_LINEAR ? p.K : p.Cin);
     if (p.mode == GEMM_LINEAR) { if (p.K % BK || (p.A2 && p.A2 != p.A)) return false; }
-    else if (p.Cin % BK || c1 % BK || p.K != 9 * p.Cin) return false;
+    else if (p.Cin % BK || c1 % BK || p.K != 9 * p.Cin + p.sc_K || (p.sc_K && (p.sc_K % BK || cfg != 24))) return false;
     if (p.mode == GEMM_CONV3) {
         // a tile's rows span at most 256 / (Ho*Wo) + 2 samples; sources are addressed relative to the first of them with
         // 24-bit pixel indices and 31-bit byte offsets

@@ -465,7 +465,10 @@ static int xattn_go(hipStream_t st, const XattnParams& p) {
 }
 
 int launch_xattn(hipStream_t st, const XattnParams& p, int C) {
-    if (!xattn_supports(C, p.heads, p.rows_per_sample, p.Nk, p.M)) GYRE_FAIL(-6, "xattn: shape outside the fused cross-attention kernel's domain");
+    // (the grid-size part of xattn_supports is the CALLER's planning rule - under batch-invariant planning a sub-batch runs here on a
+    //  small grid; the kernel itself needs whole 128-row blocks inside a sample)
+    if (!xattn_supports(C, p.heads, p.rows_per_sample, p.Nk, 256 * 128) || p.M <= 0 || p.M % 128)
+        GYRE_FAIL(-6, "xattn: shape outside the fused cross-attention kernel's domain");
     if ((p.ldx % 8) || (p.ldo % 8) || (p.ldvt % 8) || ((((size_t)p.x | (size_t)p.out | (size_t)p.k | (size_t)p.vt | (size_t)p.wq | (size_t)p.wo) & 15) != 0))
         GYRE_FAIL(-1, "xattn: operands must be 16-byte aligned with strides that are multiples of 8 elements");
     // algorithmic work: two C x C projections + the two attention products; bytes: x in (twice: operand + residual), out, weights, K / V

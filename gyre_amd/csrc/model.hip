@@ -453,6 +453,32 @@ int gyre_op_conv3x3(void* st, const void* x, int B, int Hi, int Wi, int Cin, con
     p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
     return launch_gemm((hipStream_t)st, p);
 }
+// y = conv3x3(x; stride 1, pad 1) + (sx | sx2) w_sc^T + bias + bias_sc: a resnet's conv2 with its 1x1 shortcut folded in as extra K steps
+// (GemmParams::sc_*).  sx [B][H][W][C1], sx2 [B][H][W][C2] or NULL (C2 = 0), w_sc [Cout][C1 + C2].  ws: Cout * (9 Cin + C1 + C2) * 2 + Cout * 4
+// bytes (+ 512 for alignment).  GYRE_ERR_UNSUPPORTED where the planner's kernel for the shape does not know the form.
+int gyre_op_conv3x3_shortcut(void* st, const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const float* bias,
+                             const void* sx, int C1, const void* sx2, int C2, const void* w_sc, const float* bias_sc, void* ws,
+                             size_t ws_bytes, void* y) {
+    if (!x || !w || !y || !sx || !w_sc || !ws || (C2 > 0 && !sx2)) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    GemmParams p;
+    p.A = (const bf16_t*)x; p.lda = Cin; p.mode = GEMM_CONV3; p.Hi = H; p.Wi = W; p.Cin = Cin; p.Ho = H; p.Wo = W;
+    p.stride = 1; p.pad = 1; p.N = Cout; p.M = B * H * W; p.samples = B; p.rows_per_sample = H * W;
+    p.out = y; p.ldc = Cout; p.out_mode = OUT_BF16;
+    p.sc_A = (const bf16_t*)sx; p.sc_lda = C1; p.sc_C1 = C1; p.sc_K = C1 + C2;
+    if (C2 > 0) { p.sc_A2 = (const bf16_t*)sx2; p.sc_lda2 = C2; }
+    p.K = 9 * Cin + p.sc_K;
+    if (!gemm_conv_shortcut_ok(p)) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "conv3x3_shortcut: the planner's kernel for this shape does not fold the shortcut");
+    const size_t wbytes = align_up((size_t)Cout * p.K * 2, 256);
+    if (ws_bytes < wbytes + align_up((size_t)Cout * 4, 256)) GYRE_FAIL(GYRE_ERR_WORKSPACE, "conv3x3_shortcut: workspace too small");
+    bf16_t* wcat = (bf16_t*)ws;
+    float* bcat = (float*)((char*)ws + wbytes);
+    TRY(launch_concat_rows((hipStream_t)st, (const bf16_t*)w, 9 * Cin, (const bf16_t*)w_sc, p.sc_K, Cout, wcat));
+    if (hipMemsetAsync(bcat, 0, (size_t)Cout * 4, (hipStream_t)st) != hipSuccess) GYRE_FAIL(GYRE_ERR_HIP, "memset");
+    if (bias) TRY(launch_add_f32((hipStream_t)st, bcat, bias, (size_t)Cout));
+    if (bias_sc) TRY(launch_add_f32((hipStream_t)st, bcat, bias_sc, (size_t)Cout));
+    p.W = wcat; p.bias = bcat;
+    return launch_gemm((hipStream_t)st, p);
+}
 int gyre_op_conv3x3_nchw(void* st, const void* x, int B, int H, int W, int Cin, const void* w, int Cout, const float* bias, void* y,
                          int y_dtype, int force_tiles) {
     if (!x || !w || !y) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");

@@ -148,6 +148,23 @@ struct Store {
         for (size_t i = 0; i < allocs.size(); ++i)
             if (allocs[i] == ptr) { allocs[i] = allocs.back(); allocs.pop_back(); (void)hipDeviceSynchronize(); (void)hipFree(ptr); return; }
     }
+    // conv2 rows followed by the 1x1 shortcut's rows, and the sum of the two biases, for the folded form (GemmParams::sc_*): keyed by
+    // the conv weight, made on first use, refreshed after any weight change like the other derived copies (+0.4 GB per SD1.5 UNet handle)
+    struct ScEntry { bf16_t* w = nullptr; float* b = nullptr; size_t elems = 0; uint64_t version = 0; };
+    std::unordered_map<const void*, ScEntry> sc_cache;
+    ScEntry* sc_lookup(const void* w, int N, int Kcat, bool* fresh) {
+        ScEntry& en = sc_cache[w];
+        const size_t elems = (size_t)N * Kcat;
+        if (!en.w || en.elems < elems) {
+            const size_t wbytes = (elems * 2 + 255) / 256 * 256;
+            char* base = (char*)dmalloc(wbytes + ((size_t)N * 4 + 255) / 256 * 256, false);
+            if (!base) return nullptr;
+            en.w = (bf16_t*)base; en.b = (float*)(base + wbytes); en.elems = elems; en.version = 0;
+        }
+        *fresh = en.version == weights_version;
+        en.version = weights_version;
+        return &en;
+    }
     ~Store() { for (void* a : allocs) (void)hipFree(a); }
     // returns the cached buffer for `w` (allocating `bytes` on first use) and whether its content is current
     bf16_t* wt_lookup(const void* w, size_t bytes, bool* fresh) {
@@ -431,8 +448,11 @@ struct Exec {
     // ups: nearest-neighbour upsampling fused into the gather.  (Hup, Wup) = size of the upsampled image, by default
     // 2x; diffusers resizes to the skip connection's size when the latent is not a multiple of 2^levels
     // (UNet2DConditionModel forward_upsample_size), which for sizes 2H-1 is the 2x image minus its last row / column.
+    // sc_x (| sc_skip) with sc_w / sc_b: a 1x1 shortcut over that (concatenated) image folded into this convolution as extra K steps
+    // (GemmParams::sc_*); the caller has asked conv3_shortcut_foldable() first
     int conv3(const Tn& x, const ConvW& w, int stride, int pad, int ups, const float* rowbias, int ld_rowbias,
-              const Tn* residual, Tn& y, int Hup = 0, int Wup = 0) {
+              const Tn* residual, Tn& y, int Hup = 0, int Wup = 0, const Tn* sc_x = nullptr, const Tn* sc_skip = nullptr,
+              const bf16_t* sc_w = nullptr, const float* sc_b = nullptr) {
         if (ups && ((Hup && (Hup > 2 * x.H || Hup < 2 * x.H - 1)) || (Wup && (Wup > 2 * x.W || Wup < 2 * x.W - 1))))
             GYRE_FAIL(GYRE_ERR_INVALID, "upsample target must be 2x or 2x-1 of the input");
         int Hin = ups ? (Hup ? Hup : 2 * x.H) : x.H, Win = ups ? (Wup ? Wup : 2 * x.W) : x.W;
@@ -447,8 +467,41 @@ struct Exec {
         if (residual) { p.residual = residual->p; p.ldr = residual->C; }
         p.out = y.p; p.ldc = y.C; p.out_mode = OUT_BF16;
         p.wrap = pad ? tiling : 0;                 // a module's OWN padding turns circular; the VAE's explicit (0,1,0,1) F.pad stays zeros
+        if (sc_x) {
+            fill_shortcut(p, *sc_x, sc_skip);
+            if (!dry()) {
+                bool fresh = false;
+                Store::ScEntry* e = store->sc_lookup(w.w, p.N, p.K, &fresh);
+                if (!e) GYRE_FAIL(GYRE_ERR_HIP, "cannot allocate the folded conv + shortcut weights");
+                if (!fresh) {
+                    TRY(launch_concat_rows(st, w.w, 9 * x.C, sc_w, p.sc_K, p.N, e->w));
+                    GYRE_HIP_CHECK(hipMemcpyAsync(e->b, w.b, (size_t)p.N * sizeof(float), hipMemcpyDeviceToDevice, st));
+                    if (sc_b) TRY(launch_add_f32(st, e->b, sc_b, (size_t)p.N));
+                }
+                p.W = e->w; p.bias = e->b;
+            }
+        }
         TRY(attach_colstats(p, y, Ho * Wo));       // every conv output of the UNet feeds a GroupNorm
         return run_gemm(p);
+    }
+    void fill_shortcut(GemmParams& p, const Tn& sx, const Tn* sskip) const {
+        p.sc_A = sx.p; p.sc_lda = sx.C; p.sc_C1 = sx.C; p.sc_K = sx.C;
+        if (sskip) { p.sc_A2 = sskip->p; p.sc_lda2 = sskip->C; p.sc_K = sx.C + sskip->C; }
+        p.K = 9 * p.Cin + p.sc_K;
+    }
+    // would launch_gemm run conv2 (3x3, stride 1, pad 1 over `b`) with the 1x1 shortcut over sx (| sskip) folded in?  (the pipelined
+    // 256x320 tile knows the form; inference path with a weight store; tuning bit 7 of gyre_debug_gemm_ablation = off)
+    bool conv3_shortcut_foldable(const Tn& b, int cout, const Tn& sx, const Tn* sskip) {
+        if (!store || tiling || b.C % 64 || sx.C % 64 || (sskip && sskip->C % 64) || sx.H != b.H || sx.W != b.W) return false;
+        GemmParams p;
+        p.A = b.p; p.lda = b.C; p.mode = GEMM_CONV3;
+        p.Hi = b.H; p.Wi = b.W; p.Cin = b.C; p.Ho = b.H; p.Wo = b.W; p.stride = 1; p.pad = 1;
+        p.N = pad8(cout); p.M = b.B * b.H * b.W; p.rows_per_sample = b.H * b.W; p.samples = batch;
+        p.out = (void*)(uintptr_t)256; p.ldc = p.N; p.out_mode = OUT_BF16;
+        if (dry()) p.A = (const bf16_t*)(uintptr_t)256;
+        fill_shortcut(p, sx, sskip);
+        if (dry()) { p.sc_A = (const bf16_t*)(uintptr_t)256; if (sskip) p.sc_A2 = (const bf16_t*)(uintptr_t)256; }
+        return gemm_conv_shortcut_ok(p);
     }
     // final 3x3 conv straight to the caller's NCHW buffer
     int conv3_nchw(const Tn& x, const ConvW& w, void* out, int out_dtype) {
@@ -676,7 +729,9 @@ struct Exec {
             // and the row statistics for the next LayerNorm - as ONE kernel per 128 rows (kernels_xattn.hip) where the shape fits it
             // (SD1.x's 64x64 level); inference path with a context cache only; tuning bit 13 of gyre_debug_gemm_ablation = off
             if (ln && !sv && ctx_cache && store && !w.bq && w.k_prescaled && residual.p == xq_in.p && !(gemm_planner_state() & 0x2000L) &&
-                xattn_supports(C, w.heads, Nq, Nk, B * Nq)) {
+                // (batch-invariant planning: the grid-size rule is evaluated for the canonical batch, so that every split of a request
+                //  takes the same path - a sub-batch then runs the fused kernel on a small grid, slower and bit-identical)
+                xattn_supports(C, w.heads, Nq, Nk, gemm_get_batch_invariant() > 0 ? gemm_get_batch_invariant() * Nq : B * Nq)) {
                 if (ctx_layer >= ctx_cache->size()) GYRE_FAIL(GYRE_ERR_INVALID, "internal: context cache layer overflow");
                 GemmParams pq;                         // describes to_q for the LayerNorm fold (weights W' = W gamma, colsum, bias')
                 pq.A = xq_in.p; pq.lda = C; pq.mode = GEMM_LINEAR; pq.W = w.wq; pq.K = C; pq.N = C; pq.M = B * Nq; pq.bias = nullptr;
@@ -744,6 +799,14 @@ struct Exec {
         TRY(groupnorm(h1, nullptr, w.n2g, w.n2b, eps, 1, b));
         if (sv) sv->h1 = h1; else free(h1);
         const Tn* res = &x;
+        if (w.scw && !sv && conv3_shortcut_foldable(b, w.cout, x, skip)) {
+            // Round 6: the 1x1 shortcut rides inside conv2 as extra K steps of the pipelined tile (same accumulators, one rounding):
+            // no shortcut launch, no shortcut tensor, no residual read
+            ConvW c2f{w.c2w, w.c2b, w.cout, w.cout};
+            TRY(conv3(b, c2f, 1, 1, 0, nullptr, 0, nullptr, out, 0, 0, &x, skip, w.scw, w.scb));
+            free(b);
+            return 0;
+        }
         if (w.scw) {
             TRY(alloc(sc, x.B, x.H, x.W, w.cout));
             TRY(linear(x.p, x.C, skip ? skip->p : nullptr, skip ? skip->C : 0, x.C, x.rows(), w.cin, w.scw, w.cout,

@@ -302,7 +302,8 @@ int gyre_debug_xattn_stamps(void* dev_buf);
  * workgroups would fit, bit26 = row-major weights everywhere (no blocked weight copies for the LDS-DMA kernels), bit27 = the two-stage K loop for the
  * 128x160 tile's 3x3 convolutions (instead of the same ring).  Round 6: bit13 = no fused cross-attention kernel (kernels_xattn.hip:
  * to_q -> attention -> to_out of SD1.x's 64x64 level in one launch): the three-launch chain as before.  (Bit 7 - the small kernel's
- * LayerNorm fold - went with the code it switched on.)
+ * LayerNorm fold - went with the code it switched on; the bit is reused:) bit7 = the 1x1 shortcut of a channel-changing / concat resnet
+ * stays its own launch instead of riding inside conv2 as extra K steps of the pipelined tile (round 6).
  * Epilogue ablations (garbage): bit3 = no GELU, bit4 = no stores.
  * These switches are PER CALLING THREAD (thread-local, like gyre_set_batch_invariant): they never change what another thread's
  * handle computes. */
@@ -382,6 +383,14 @@ int gyre_op_linear_t(void* stream, const void* x, int M, int K, const void* w_bf
  * of the input; stride 1|2; pad 1 (pad 0 + bottom/right zero pad when asym!=0, VAE downsample). */
 int gyre_op_conv3x3(void* stream, const void* x, int B, int Hi, int Wi, int Cin, const void* w_krsc, int Cout,
                     const float* bias, const void* residual, int stride, int ups, int asym, void* y);
+/* A resnet's conv2 with its 1x1 shortcut folded in (round 6): y = conv3x3(x; stride 1, pad 1) + (sx | sx2) w_sc^T + bias + bias_sc in ONE
+ * launch - the shortcut's channels are extra K steps of the pipelined 256x320 convolution tile, same accumulators, one rounding.
+ * sx [B][H][W][C1], sx2 [B][H][W][C2] or NULL with C2 = 0 (the skip concatenation of an up block is never materialised), w_sc
+ * [Cout][C1 + C2] repacked.  Cin, C1, C2 multiples of 64.  ws: Cout * (9 Cin + C1 + C2) * 2 + Cout * 4 + 512 bytes.
+ * GYRE_ERR_UNSUPPORTED where the planner's kernel for the shape does not know the form (the model then runs the two launches). */
+int gyre_op_conv3x3_shortcut(void* stream, const void* x, int B, int H, int W, int Cin, const void* w_krsc, int Cout, const float* bias,
+                             const void* sx, int C1, const void* sx2, int C2, const void* w_sc, const float* bias_sc, void* ws,
+                             size_t ws_bytes, void* y);
 /* The output convolution of the UNet / VAE decoder (3x3, stride 1, zero padding 1, Cout <= 16) written as NCHW y
  * [B][Cout][H][W] of dtype y_dtype (0 f32, 1 bf16, 2 f16), as the models' last launch does: the dedicated kernel
  * (kernels_conv_out.hip) where Cin % 64 == 0, the tile kernels otherwise; force_tiles != 0 takes the tile kernels anyway. */

@@ -1258,3 +1258,38 @@ def test_fused_cross_attention_block_operator(B, Nk, bias):
                                              vp(repack_linear(wq)), vp(kpre), vp(vt), nk_, ldvt, vp(repack_linear(wo)), None,
                                              vp(ws), ws.numel(), vp(out), None)
         assert rc in (-6, -1), rc
+
+
+# ---- a resnet's conv2 with its 1x1 shortcut folded in (GemmParams::sc_*; gyre_op_conv3x3_shortcut) -----------------------------------
+@pytest.mark.parametrize("B,H,Cin,Cout,C1,C2", [(16, 64, 320, 320, 320, 320), (16, 64, 320, 320, 640, 320), (16, 32, 640, 640, 320, 0),
+                                                (16, 32, 640, 640, 1280, 640), (16, 16, 1280, 1280, 1280, 1280)])
+def test_conv3x3_with_folded_shortcut(B, H, Cin, Cout, C1, C2):
+    """y = conv3x3(h) + conv1x1(cat[x, skip]) in one launch: the shortcut's channels are extra K steps of the pipelined convolution
+    (one fp32 accumulation, one rounding) - against fp32 ATen on storage-rounded operands, for the shapes of SD1.5's up path (two
+    shortcut sources: the concatenation is never materialised), a down-path resnet (one source) and a deep level that runs in K slices."""
+    L = _lib.lib()
+    h = bf16_round(randn(B, Cin, H, H, seed=401))
+    x1 = bf16_round(randn(B, C1, H, H, seed=402))
+    x2 = bf16_round(randn(B, C2, H, H, seed=403)) if C2 else None
+    w = bf16_round(randn(Cout, Cin, 3, 3, seed=404) / math.sqrt(9 * Cin))
+    wsc = bf16_round(randn(Cout, C1 + C2, seed=405) / math.sqrt(C1 + C2))
+    b, bsc = randn(Cout, seed=406) * 0.1, randn(Cout, seed=407) * 0.1
+    xcat = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    ref = F.conv2d(h, w, b, padding=1) + F.conv2d(xcat, wsc[:, :, None, None], bsc)
+    y = torch.empty(B, H, H, Cout, dtype=HDT, device=DEV)
+    ws = torch.empty(Cout * (9 * Cin + C1 + C2) * 2 + Cout * 4 + 512, dtype=torch.uint8, device=DEV)
+    wsk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)                  # split-K slabs of the deep level
+    L.gyre_debug_set_splitk_workspace(vp(wsk), wsk.numel())
+    try:
+        rc = L.gyre_op_conv3x3_shortcut(st(), vp(to_dev_bf16(nhwc(h))), B, H, H, Cin, vp(repack_conv(w)), Cout, vp(repack_bias(b)),
+                                        vp(to_dev_bf16(nhwc(x1))), C1, vp(to_dev_bf16(nhwc(x2))) if C2 else None, C2,
+                                        vp(repack_linear(wsc)), vp(repack_bias(bsc)), vp(ws), ws.numel(), vp(y))
+        _lib.check(rc)
+        torch.cuda.synchronize()
+    finally:
+        L.gyre_debug_set_splitk_workspace(None, 0)
+    report(f"conv3x3 + folded shortcut B{B} {H}x{H} {Cin}->{Cout} sc {C1}+{C2}", y.float().cpu().permute(0, 3, 1, 2), ref, TOL)
+    # a shape the planner gives to another kernel is refused, not computed wrongly
+    rc = L.gyre_op_conv3x3_shortcut(st(), vp(to_dev_bf16(nhwc(h[:1]))), 1, H, H, Cin, vp(repack_conv(w)), Cout, None,
+                                    vp(to_dev_bf16(nhwc(x1[:1]))), C1, None, 0, vp(repack_linear(wsc[:, :C1])), None, vp(ws), ws.numel(), vp(y))
+    assert rc in (0, -6)

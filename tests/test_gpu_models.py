@@ -586,3 +586,34 @@ def test_fused_cross_attention_block_matches_the_three_launch_chain_and_the_orac
     for xx, tt, cc in ((x[:2], t[:2], ctx[:2]), (x, t, randn(B, 154, 768, seed=43))):
         o2, n2 = run(xx, tt, cc)
         assert n2[0] == n2[0x2000] and torch.equal(o2[0], o2[0x2000])
+
+
+def test_resnet_shortcut_folded_into_conv2_matches_the_two_launches():
+    """Round 6: where a resnet changes its channel count (or reads a skip concatenation) its 1x1 shortcut rides inside conv2 as extra K
+    steps of the pipelined convolution tile (GemmParams::sc_*) instead of being a launch of its own whose result conv2 re-reads as
+    residual.  Same UNet call both ways (tuning bit 7 = two launches): fewer launches, results equal up to one rounding per output
+    (the folded form rounds once, the two launches twice), both at the usual distance from the oracle; batch-invariant planning
+    keeps the two launches (bit-exact batch splits: tests/test_gpu_configs.py)."""
+    L = _lib.lib()
+    cfg = gcfg.sd15_unet()
+    net, sd = make_unet(cfg)
+    B = 8
+    x = randn(B, 4, 64, 64, seed=51)
+    t = torch.tensor([77] * B)
+    ctx = randn(B, 77, 768, seed=52)
+    ref = M.unet_forward(sd, cfg, x[:2], t[:2], ctx[:2])
+    outs, launches = {}, {}
+    for bits in (0x80, 0):
+        old = L.gyre_debug_gemm_ablation(bits)
+        try:
+            net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))          # (first call: per-handle weight copies)
+            outs[bits] = net(x.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV)).sample.float().cpu()
+            launches[bits] = L.gyre_last_launch_count()
+        finally:
+            L.gyre_debug_gemm_ablation(old)
+    print(f"[fold] launches {launches[0x80]} -> {launches[0]}")
+    assert launches[0] < launches[0x80], launches              # at least the 64x64 / 32x32 shortcuts fold at this batch
+    report("SD1.5 UNet batch 8, shortcuts folded (samples 0, 1)", outs[0][:2], ref, 3e-2)
+    report("SD1.5 UNet batch 8, shortcuts as launches (samples 0, 1)", outs[0x80][:2], ref, 3e-2)
+    assert rel_l2(outs[0], outs[0x80]) < 2.5e-2
+    assert rel_l2(outs[0][:2], ref) < 1.2 * rel_l2(outs[0x80][:2], ref) + 1e-3
