@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
                     help="16-bit storage type of activations / weights (fp32 accumulation in both): bf16 = libgyre_hip.so (default), "
                          "fp16 = libgyre_hip_f16.so, the reference's own GPU arithmetic")
+    ap.add_argument("--ablation", type=lambda v: int(v, 0), default=0,
+                    help="gyre_debug_gemm_ablation bits for same-box A/B runs of the whole step (0x80 = shortcuts as their own launches, "
+                         "0x2000 = three-launch cross-attention; include/gyre_hip.h lists the rest); printed in the line when non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class-table", action="store_true", help="skip the extra instrumented step after the timed region")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class INSIDE the timed region (adds event overhead)")
@@ -245,6 +248,8 @@ def main():
     from gyre_amd.pipeline import GyrePipeline
     HDT = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     _lib.set_default_storage(_lib.F16 if args.dtype == "fp16" else _lib.BF16)     # the profiler / redo-counter calls below follow it
+    if args.ablation:
+        _lib.lib().gyre_debug_gemm_ablation(args.ablation)
     from gyre_amd.sharding import gather_batches, shard_bounds
     from gyre_amd.text import ClipTextEncoder, empty_prompt_ids, synthetic_prompt_ids
 
@@ -537,6 +542,8 @@ def main():
             "roofline": roof,
         }
         out.update(latency)
+        if args.ablation:
+            out["ablation_bits"] = hex(args.ablation)
         out["attn_redo_count"] = (redo1 - redo0) if (redo0 >= 0 and redo1 >= 0) else None
         out["attn_redo_note"] = ("attention workgroups of rank 0's device that repeated their tile with the checked pass during the timed "
                                  "region (gyre_debug_attn_redo_count; of ~%d k_attn3 workgroups per step)" % (evals * 5 * 4096 if args.config == "sd15" else 0))
