@@ -191,6 +191,8 @@ def main():
                     help="gyre_debug_gemm_ablation bits for same-box A/B runs of the whole step (0x80 = shortcuts as their own launches, "
                          "0x2000 = three-launch cross-attention; include/gyre_hip.h lists the rest); printed in the line when non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-markers", action="store_true", help="dev: bracket the timed region with a fill<complex128> launch, the marker "
+                    "tools/c5_trace.py / tools/trace_sequence.py cut a rocprofv3 kernel trace at")
     ap.add_argument("--no-class-table", action="store_true", help="skip the extra instrumented step after the timed region")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class INSIDE the timed region (adds event overhead)")
     args = ap.parse_args()
@@ -380,6 +382,8 @@ def main():
     if clocks:
         clocks.start()
     redo0 = _lib.lib().gyre_debug_attn_redo_count()
+    if args.trace_markers:
+        torch.full((1,), 1.0, dtype=torch.complex128, device=dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         s0 = time.perf_counter()
@@ -388,6 +392,9 @@ def main():
         step_times.append(time.perf_counter() - s0)
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.trace_markers:
+        torch.full((1,), 1.0, dtype=torch.complex128, device=dev)
+        torch.cuda.synchronize()
     clock_info = clocks.stop() if clocks else None
     redo1 = _lib.lib().gyre_debug_attn_redo_count()
     prof = _lib.prof_collect()
