@@ -154,15 +154,28 @@ class ClipGuidedMode:
         self.make_cutouts = MakeCutouts(self.clip_size // vae_scale_factor, generators)
         self.make_cutouts_rgb = MakeCutouts(self.clip_size, generators)
         self.approx_decoder = VaeApproximator()
-        self.lossavg: List[float] = []
+        self._lossavg: List[float] = []
+        self._loss_pending: list = []                # (loss tensor on the device, batch) not yet read back, see `lossavg`
         self.flatloss = False
         self._guided_stem_only = False
         self.grad_evals = 0
 
+    @property
+    def lossavg(self) -> List[float]:
+        """Loss history (clipguided.py:418).  The reference reads the loss back inside cond_fn, i.e. BEFORE the backward pass is
+        queued: a host-device synchronisation that leaves the device idle while the host walks the autograd graph of the CLIP
+        model (~400 small launches; ~4 ms of every guided step).  Here the loss stays a device scalar until somebody looks at
+        the history - the flat-loss test at the start of the NEXT step, by which time this step's backward pass, reverse sweep
+        and unconditional evaluation are all queued.  Same values, same order."""
+        if self._loss_pending:
+            pend, self._loss_pending = self._loss_pending, []
+            self._lossavg.extend(float(t) / b for t, b in pend)
+        return self._lossavg
+
     # ---- loss trend (clipguided.py:153-173) ----
     def _has_flatloss(self) -> bool:
         c = self.config
-        if not self.flatloss and len(self.lossavg) > c.gradient_length:
+        if not self.flatloss and len(self._lossavg) + len(self._loss_pending) > c.gradient_length:   # (no read-back before it can matter)
             x = np.linspace(0, 1, c.gradient_length)
             X = np.vstack([x, np.ones(len(x))]).T
             y = np.asarray(self.lossavg[-c.gradient_length:])
@@ -313,6 +326,6 @@ class ClipGuidedMode:
                 dists = spherical_dist_loss(image_embeddings_clip, text_in)
                 dists = dists.view([num_cutouts, latents.shape[0], -1])
                 loss = dists.sum(2).mean(0).sum()
-            self.lossavg.append(float(loss.detach()) / latents.shape[0])
+            self._loss_pending.append((loss.detach(), latents.shape[0]))
             self.grad_evals += 1
             return -torch.autograd.grad(loss * (c.guidance_scale * 500), latents)[0]

@@ -223,7 +223,7 @@ struct GnBwdParams {
     const bf16_t* addend;                            // optional [B][HW][C1], added to dx (identity-shortcut gradient)
     bf16_t* dx; bf16_t* dx2;                         // [B][HW][C1], [B][HW][C - C1]
     // filled in by launch_groupnorm_bwd from its workspace
-    float* partial = nullptr; float* coef = nullptr; float* mean_rstd = nullptr; float* scale_shift = nullptr; int nchunks = 0;
+    float* partial = nullptr; const float* fwd_partial = nullptr; int nchunks = 0;
 };
 size_t gn_bwd_workspace_bytes(int B, int HW, int C, int G);
 int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws);

@@ -3,7 +3,7 @@
 // The reference's ClipGuidedMode (gyre/pipeline/unet/clipguided.py:301-338,420) asks autograd for
 // d loss / d latents through the guided UNet evaluation and the VAE decoder; weights never receive gradients.
 // These are the transposes of the forward kernels for that one direction:
-//   k_gn_bwd_partial / k_gn_bwd_finalize / k_gn_bwd_apply   GroupNorm(+SiLU), concat-aware like the forward
+//   k_gn_bwd_partial / k_gn_bwd_apply                       GroupNorm(+SiLU), concat-aware like the forward
 //   k_ln_bwd                                                 LayerNorm (+ the residual branch's gradient)
 //   k_geglu_bwd                                              GEGLU on the 16-value / 16-gate interleaved columns
 //   k_attn_bwd_delta / k_attn_bwd_dq / k_attn_bwd_dkv        flash-style attention backward on v_mfma_f32_32x32x16_bf16:
@@ -19,7 +19,7 @@
 // GroupNorm (+SiLU) backward.  With u = a*x + b (a = rstd*gamma, b = beta - mean*a, from the forward statistics
 // kernels), g = dy * silu'(u) * gamma and xh = (x - mean) * rstd:
 //     dx = rstd * (g - mean_grp(g) - xh * mean_grp(g * xh))
-// Stage 1 sums g and g*xh per (sample, pixel chunk, group); stage 2 reduces the chunks in a fixed order; stage 3 applies.
+// Stage 1 sums g and g*xh per (sample, pixel chunk, group); stage 2 reduces the chunks in a fixed order (in its prologue) and applies.
 // ------------------------------------------------------------------------------
 #define GNB_MAXV 4
 // d silu / du = s (1 + u (1 - s)), s = sigmoid(u): hardware reciprocal and exp2 (the IEEE division of 1 / (1 + e^-u) was a
@@ -40,14 +40,55 @@ __device__ __forceinline__ void gn_groups8(int c, int cpg, int (&grp)[8]) {
         for (int j = 0; j < 8; ++j) grp[j] = (c + j) / cpg;
     }
 }
+// Forward statistics of sample n, finished in the prologue of BOTH backward kernels from k_gn_partial's partial sums - the
+// arithmetic and the order of k_gn_finalize / k_gn_apply_fin (thread (g, part) adds every parts-th chunk, then the parts in
+// order), so mean / rstd carry the bits the forward pass normalised with.  Round 6: this replaced two launches per GroupNorm
+// (k_gn_finalize, k_gn_bwd_finalize - the latter a 32-thread chain of nchunks dependent loads, 18 us at 64 x 64) of the five.
+// stat: [4][256] floats of LDS (red_s, red_q, mean, rstd); all 256 threads call it.
+__device__ __forceinline__ void gnb_forward_stats(const GnBwdParams& p, int n, float* stat) {
+    float *red_s = stat, *red_q = stat + 256, *mean_s = stat + 512, *rstd_s = stat + 768;
+    const int cpg = p.C / p.G;
+    const float cnt = (float)p.HW * (float)cpg;
+    int parts = 256 / p.G;
+    if (parts < 1) parts = 1;
+    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+    float a = 0.f, b = 0.f;
+    if (part < parts) {
+        const float2* src = (const float2*)p.fwd_partial + (size_t)n * p.nchunks * p.G + g;
+        const int total = (p.nchunks - part + parts - 1) / parts;
+        for (int i0 = 0; i0 < total; i0 += 4) {          // four partials in flight, added in the original order
+            float2 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < total) t[j] = src[(size_t)(part + (i0 + j) * parts) * p.G];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < total) { a += t[j].x; b += t[j].y; }
+        }
+    }
+    red_s[threadIdx.x] = a; red_q[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < p.G) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < parts; ++q) { sa += red_s[q * p.G + g]; sb += red_q[q * p.G + g]; }
+        const float mean = sa / cnt;
+        const float var = fmaxf(sb / cnt - mean * mean, 0.f);
+        mean_s[g] = mean;
+        rstd_s[g] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+}
 template <int NV>      // channel vectors per thread: 1 for C <= 2048
 __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, int PY, int pix_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ float stat[4 * 256];
     float* red = (float*)smem_raw;  // [PY][C][2]
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int CV = p.C / 8, C2 = p.C - p.C1, cpg = p.C / p.G;
     const int p0 = chunk * pix_per_chunk, p1 = min(p.HW, p0 + pix_per_chunk);
+    gnb_forward_stats(p, n, stat);
+    const float *mean_s = stat + 512, *rstd_s = stat + 768;
     float s[NV][8], ss[NV][8];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
@@ -61,13 +102,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, i
             const int cv = tx + v * TX;
             if (cv < CV) {
                 const int c = cv * 8;
-                const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
                 int grp[8];
                 gn_groups8(c, cpg, grp);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float* mr = p.mean_rstd + ((size_t)n * p.G + grp[j]) * 2;
-                    ka[v][j] = sc[j]; kb[v][j] = sc[p.C + j]; kg[v][j] = p.gamma[c + j]; km[v][j] = mr[0]; kr[v][j] = mr[1];
+                    kg[v][j] = p.gamma[c + j]; km[v][j] = mean_s[grp[j]]; kr[v][j] = rstd_s[grp[j]];
+                    ka[v][j] = kr[v][j] * kg[v][j];                       // a = rstd * gamma, b = beta - mean * a (k_gn_finalize)
+                    kb[v][j] = p.beta[c + j] - km[v][j] * ka[v][j];
                 }
             }
         }
@@ -116,48 +157,102 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partial(GnBwdParams p, int TX, i
         dst[0] = a; dst[1] = b;
     }
 }
-__global__ __launch_bounds__(256) void k_gn_bwd_finalize(GnBwdParams p) {
-    const int n = blockIdx.x;
-    const float cnt = (float)p.HW * (float)(p.C / p.G);
-    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
-        float a = 0.f, b = 0.f;
-        for (int ch = 0; ch < p.nchunks; ++ch) {
-            const float* src = p.partial + (((size_t)n * p.nchunks + ch) * p.G + g) * 2;
-            a += src[0]; b += src[1];
-        }
-        p.coef[((size_t)n * p.G + g) * 2 + 0] = a / cnt;
-        p.coef[((size_t)n * p.G + g) * 2 + 1] = b / cnt;
-    }
-}
-__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdParams p, size_t total_vec) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_vec) return;
+// Apply: workgroup = (pixel chunk, sample) like the partial kernel.  Prologue: the forward statistics (above) and the group means of
+// g and g * xh from the partial kernel's sums (thread (g, part) adds every parts-th chunk, then the parts in order); then the lane
+// keeps ONE channel vector's constants in registers and walks its chunk's pixels, four rows requested per trip.
+template <int NV>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdParams p, int TX, int PY, int pix_per_chunk) {
+    __shared__ float stat[4 * 256];
+    __shared__ float cred[2 * 256];
+    __shared__ float coef[2 * 256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int CV = p.C / 8, C2 = p.C - p.C1, cpg = p.C / p.G;
-    const size_t gp = idx / CV;
-    const int c = (int)(idx % CV) * 8;
-    const int n = (int)(gp / p.HW);
-    const bool first = c < p.C1;
-    const bf16_t* src = first ? p.x + gp * p.C1 + c : p.x2 + gp * C2 + (c - p.C1);
-    float f[8], d[8], o[8], ad[8];
-    unpack8(*(const uint4*)src, f);
-    unpack8(*(const uint4*)(p.dy + gp * p.C + c), d);
-    const bool has_add = first && p.addend;
-    if (has_add) unpack8(*(const uint4*)(p.addend + gp * p.C1 + c), ad);
-    const float* sc = p.scale_shift + (size_t)n * 2 * p.C + c;
-    int grp8[8];
-    gn_groups8(c, cpg, grp8);
+    const int p0 = chunk * pix_per_chunk, p1 = min(p.HW, p0 + pix_per_chunk);
+    {
+        int parts = 256 / p.G;
+        if (parts < 1) parts = 1;
+        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+        float a = 0.f, b = 0.f;
+        if (part < parts) {
+            const float2* src = (const float2*)p.partial + (size_t)n * p.nchunks * p.G + g;
+            const int total = (p.nchunks - part + parts - 1) / parts;
+            for (int i0 = 0; i0 < total; i0 += 4) {
+                float2 t[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int grp = grp8[j];
-        const float* mr = p.mean_rstd + ((size_t)n * p.G + grp) * 2;
-        const float* cf = p.coef + ((size_t)n * p.G + grp) * 2;
-        const float u = fmaf(sc[j], f[j], sc[p.C + j]);
-        const float g = d[j] * (p.silu ? silu_grad_f(u) : 1.0f) * p.gamma[c + j];
-        const float xh = (f[j] - mr[0]) * mr[1];
-        o[j] = mr[1] * (g - cf[0] - xh * cf[1]) + (has_add ? ad[j] : 0.f);
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < total) t[j] = src[(size_t)(part + (i0 + j) * parts) * p.G];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j < total) { a += t[j].x; b += t[j].y; }
+            }
+        }
+        cred[threadIdx.x] = a; cred[256 + threadIdx.x] = b;
     }
-    bf16_t* dst = first ? p.dx + gp * p.C1 + c : p.dx2 + gp * C2 + (c - p.C1);
-    *(uint4*)dst = pack8(o);
+    gnb_forward_stats(p, n, stat);                   // (its first barrier also publishes cred)
+    const float *mean_s = stat + 512, *rstd_s = stat + 768;
+    if (threadIdx.x < p.G) {
+        int parts = 256 / p.G;
+        if (parts < 1) parts = 1;
+        const float cnt = (float)p.HW * (float)cpg;
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < parts; ++q) { sa += cred[q * p.G + threadIdx.x]; sb += cred[256 + q * p.G + threadIdx.x]; }
+        coef[threadIdx.x] = sa / cnt; coef[256 + threadIdx.x] = sb / cnt;
+    }
+    __syncthreads();
+    if (ty >= PY) return;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int cv = tx + v * TX;
+        if (cv >= CV) continue;
+        const int c = cv * 8;
+        const bool first = c < p.C1;
+        const bool has_add = first && p.addend;
+        float ka[8], kb[8], kg[8], km[8], kr[8], k0[8], k1[8];
+        int grp[8];
+        gn_groups8(c, cpg, grp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kg[j] = p.gamma[c + j]; km[j] = mean_s[grp[j]]; kr[j] = rstd_s[grp[j]];
+            ka[j] = kr[j] * kg[j];
+            kb[j] = p.beta[c + j] - km[j] * ka[j];
+            k0[j] = coef[grp[j]]; k1[j] = coef[256 + grp[j]];
+        }
+        const bf16_t* xs = first ? p.x + c : p.x2 + (c - p.C1);
+        bf16_t* xd = first ? p.dx + c : p.dx2 + (c - p.C1);
+        const size_t ld = first ? (size_t)p.C1 : (size_t)C2;
+        for (int pix = p0 + ty; pix < p1; pix += 4 * PY) {
+            uint4 rx[4], rd[4], ra[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * PY;
+                if (px < p1) {
+                    const size_t gp = (size_t)n * p.HW + px;
+                    rx[u] = *(const uint4*)(xs + gp * ld);
+                    rd[u] = *(const uint4*)(p.dy + gp * p.C + c);
+                    if (has_add) ra[u] = *(const uint4*)(p.addend + gp * p.C1 + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * PY;
+                if (px >= p1) continue;
+                const size_t gp = (size_t)n * p.HW + px;
+                float f[8], d[8], o[8], ad[8];
+                unpack8(rx[u], f);
+                unpack8(rd[u], d);
+                if (has_add) unpack8(ra[u], ad);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float uu = fmaf(ka[j], f[j], kb[j]);
+                    const float g = d[j] * (p.silu ? silu_grad_f(uu) : 1.0f) * kg[j];
+                    const float xh = (f[j] - km[j]) * kr[j];
+                    o[j] = kr[j] * (g - k0[j] - xh * k1[j]) + (has_add ? ad[j] : 0.f);
+                }
+                *(uint4*)(xd + gp * ld) = pack8(o);
+            }
+        }
+    }
 }
 size_t gn_bwd_workspace_bytes(int B, int HW, int C, int G) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -167,7 +262,8 @@ size_t gn_bwd_workspace_bytes(int B, int HW, int C, int G) {
 int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
     if (p.C % 8 || p.C1 % 8 || p.C % p.G || p.G > 256) GYRE_FAIL(-1, "groupnorm_bwd: C, C1 multiples of 8, C of groups (<= 256)");
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    // forward statistics (same kernels, same summation order as the forward pass)
+    // forward statistics: the forward pass's own partial sums (same kernel, same order); mean / rstd are finished from them in
+    // the prologues of the two kernels below
     GnParams f;
     f.x = p.x; f.x2 = p.x2 ? p.x2 : p.x; f.C1 = p.C1; f.B = p.B; f.HW = p.HW; f.C = p.C; f.G = p.G;
     f.gamma = p.gamma; f.beta = p.beta; f.eps = p.eps; f.silu = p.silu; f.y = nullptr;
@@ -176,10 +272,9 @@ int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
     f.partial = (float*)w;
     f.scale_shift = (float*)(w + al((size_t)p.B * f.nchunks * p.G * 2 * 4));
     w += gn_workspace_bytes(p.B, p.HW, p.C, p.G);
-    p.partial = (float*)w; w += al((size_t)p.B * f.nchunks * p.G * 2 * 4);
-    p.coef = (float*)w; w += al((size_t)p.B * p.G * 2 * 4);
-    f.mean_rstd = (float*)w;
-    p.mean_rstd = f.mean_rstd; p.scale_shift = f.scale_shift; p.nchunks = f.nchunks;
+    p.partial = (float*)w;
+    f.mean_rstd = nullptr;
+    p.fwd_partial = f.partial; p.nchunks = f.nchunks;
     if (!p.x2) p.x2 = p.x;
     int rc = launch_groupnorm_stats(st, f);
     if (rc) return rc;
@@ -190,16 +285,16 @@ int launch_groupnorm_bwd(hipStream_t st, GnBwdParams p, void* ws) {
     int PY = 256 / TX; if (PY < 1) PY = 1;
     const int ppc = (p.HW + p.nchunks - 1) / p.nchunks;
     const size_t lds = (size_t)PY * p.C * 2 * sizeof(float);
-    if (lds > 160 * 1024) GYRE_FAIL(-6, "groupnorm_bwd: LDS budget exceeded");
+    if (lds > 150 * 1024) GYRE_FAIL(-6, "groupnorm_bwd: LDS budget exceeded");
     const int nv = (CV + TX - 1) / TX;
-    if (nv == 1) hipLaunchKernelGGL(k_gn_bwd_partial<1>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
-    else if (nv == 2) hipLaunchKernelGGL(k_gn_bwd_partial<2>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
-    else hipLaunchKernelGGL(k_gn_bwd_partial<GNB_MAXV>, dim3(p.nchunks, p.B), dim3(256), lds, st, p, TX, PY, ppc);
+    const dim3 grid(p.nchunks, p.B);
+    if (nv == 1) hipLaunchKernelGGL(k_gn_bwd_partial<1>, grid, dim3(256), lds, st, p, TX, PY, ppc);
+    else if (nv == 2) hipLaunchKernelGGL(k_gn_bwd_partial<2>, grid, dim3(256), lds, st, p, TX, PY, ppc);
+    else hipLaunchKernelGGL(k_gn_bwd_partial<GNB_MAXV>, grid, dim3(256), lds, st, p, TX, PY, ppc);
     GYRE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(p.B), dim3(256), 0, st, p);
-    GYRE_LAUNCH_CHECK();
-    const size_t total = (size_t)p.B * p.HW * CV;
-    hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, total);
+    if (nv == 1) hipLaunchKernelGGL(k_gn_bwd_apply<1>, grid, dim3(256), 0, st, p, TX, PY, ppc);
+    else if (nv == 2) hipLaunchKernelGGL(k_gn_bwd_apply<2>, grid, dim3(256), 0, st, p, TX, PY, ppc);
+    else hipLaunchKernelGGL(k_gn_bwd_apply<GNB_MAXV>, grid, dim3(256), 0, st, p, TX, PY, ppc);
     GYRE_LAUNCH_CHECK();
     return 0;
 }

@@ -301,7 +301,10 @@ struct ConvW { bf16_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0; }
 // ------------------------------------------------------------------------------------------
 struct CtxKV { bf16_t* k; bf16_t* vt; };
 // Activations a forward pass keeps for the input-gradient pass (model_vjp.hip) instead of returning them to the arena
-struct MhaSave { Tn ao; };                                   // attention output before the out projection
+// ao: attention output before the out projection.  ToMe self-attention also keeps what the merge produced - Q|K rows, merged K / V rows
+// and the matching (order, destination list) - so the reverse sweep neither re-projects nor re-matches (round 6: 0.2 ms per 64 x 64
+// block of the guided step; 288 GB of HBM make the recomputation's memory saving worthless)
+struct MhaSave { Tn ao, qk, km, vm, idx; };
 struct ResSave { Tn h1; };                                   // conv1 output (input of the second GroupNorm)
 struct TBlockSave { Tn h0, n1, h1, n2, h2, n3; MhaSave a1, a2; };   // block input, LN outputs, residual stream after each attention
 struct TransSave { std::vector<TBlockSave> blocks; Tn hlast; };     // hlast: residual stream entering proj_out
@@ -673,14 +676,24 @@ struct Exec {
             TRY(linear(xq.p, C, nullptr, 0, 0, B * Nq, C, w.wv, C, w.bv, nullptr, 0, 0, vrow.p, C));
             TRY(alloc(km, B, Nk, 1, C));
             TRY(alloc(vt, B, C, 1, ldvt));
+            Tn vm, idx;
+            if (sv) {
+                TRY(alloc(vm, B, Nk, 1, C));
+                TRY(alloc_raw(idx, (size_t)3 * B * (Nq / 2) * 4 + 768));
+            }
             TRY(alloc_raw(tws, tome_workspace_bytes(B, Nq, C)));
             if (!dry()) {
                 TomeParams tp;
                 tp.k = q.p + C; tp.ldk = 2 * C; tp.v = vrow.p; tp.ldv = C; tp.B = B; tp.N = Nq; tp.C = C; tp.r = tr;
                 tp.k_out = km.p; tp.vt_out = vt.p; tp.ldvt = ldvt; tp.ws = tws.p; tp.ws_bytes = tws.bytes;
+                if (sv) {
+                    int* order = (int*)idx.p;
+                    tp.vrows_out = vm.p; tp.order_out = order; tp.dstlist_out = order + (((size_t)B * (Nq / 2) + 63) & ~(size_t)63);
+                }
                 TRY(launch_tome_merge(st, tp));
             }
             free(tws); free(vrow);
+            if (sv) { sv->vm = vm; sv->idx = idx; }
             qp = q.p; kp = km.p; vtp = vt.p; ldq = 2 * C; ldk = C;
         } else if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
@@ -783,6 +796,7 @@ struct Exec {
             a.B = B; a.H = w.heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.k_prescaled = w.k_prescaled;
             TRY(launch_attention(st, a));
         }
+        if (sv && tr > 0) { sv->qk = q; sv->km = km; q = Tn(); km = Tn(); }
         free(q); free(k); free(vt); free(km); free(nrm);
         TRY(alloc(out, B, xq.H, xq.W, C));
         TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C, rs_out));

@@ -151,10 +151,14 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
         const int W3 = w.qkv_fused ? 3 * C : 2 * C;     // Q | K (| V) in one row
         const int tr = (e.tome_r > 0 && Nq % 16 == 0) ? tome_effective_r(Nq, e.tome_r) : 0;   // same rule as Exec::mha
         if (tr > 0 && !w.qkv_fused) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "vjp: token merging needs the fused Q|K|V projection");
-        TRY(e.alloc(qkv, B, xq.H, xq.W, W3));
-        TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wqk, W3, w.qkv_fused ? nullptr : w.bqk, nullptr, 0, 0, qkv.p, W3));
-        const bf16_t* vrows; int ldv;
-        if (w.qkv_fused) { vrows = e.dry() ? nullptr : qkv.p + 2 * C; ldv = W3; }
+        const bool kept = tr > 0 && sv.qk.valid() && sv.km.valid() && sv.vm.valid() && sv.idx.valid();   // the forward pass kept Q|K and the merge
+        if (!kept) {
+            TRY(e.alloc(qkv, B, xq.H, xq.W, W3));
+            TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wqk, W3, w.qkv_fused ? nullptr : w.bqk, nullptr, 0, 0, qkv.p, W3));
+        }
+        const bf16_t* vrows = nullptr; int ldv = W3;
+        if (kept) {}
+        else if (w.qkv_fused) { vrows = e.dry() ? nullptr : qkv.p + 2 * C; ldv = W3; }
         else {
             TRY(e.alloc(vc, B, xq.H, xq.W, C));
             TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wv, C, w.bv, nullptr, 0, 0, vc.p, C));
@@ -164,9 +168,26 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
         TRY(e.alloc(dot, B, C, 1, ldqt));
         TRY(e.alloc(dqkv, B, xq.H, xq.W, W3));
         if (!w.qkv_fused) TRY(e.alloc(dv, B, xq.H, xq.W, C));
-        a.q = qkv.p; a.ldq = W3; a.qt = qt.p; a.d_ot = dot.p; a.ldqt = ldqt;
+        a.q = kept ? sv.qk.p : qkv.p; a.ldq = kept ? 2 * C : W3; a.qt = qt.p; a.d_ot = dot.p; a.ldqt = ldqt;
         a.dq = dqkv.p; a.lddq = W3;
-        if (tr > 0) {
+        if (kept) {
+            const int nout = Nq - tr, half = Nq / 2, ldkm = (nout + 31) / 32 * 32;
+            if (need_t) GYRE_FAIL(GYRE_ERR_UNSUPPORTED, "vjp: token merging with a head dim above 160");
+            Tn dkm, dvm;
+            TRY(e.alloc(dkm, B, nout, 1, C));
+            TRY(e.alloc(dvm, B, nout, 1, C));
+            if (!e.dry()) {
+                int* order = (int*)sv.idx.p;
+                int* dstl = order + (((size_t)B * half + 63) & ~(size_t)63);
+                int* inv = dstl + (((size_t)B * half + 63) & ~(size_t)63);
+                a.k = sv.km.p; a.ldk = C; a.v = sv.vm.p; a.ldv = C; a.Nk = nout; a.kt = nullptr; a.ldkt = ldkm;
+                a.dk = dkm.p; a.lddk = C; a.dv = dvm.p; a.lddv = C;
+                TRY(launch_attention_bwd(e.st, a));
+                TRY(launch_tome_unmerge(e.st, dkm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + C, W3));
+                TRY(launch_tome_unmerge(e.st, dvm.p, B, Nq, C, tr, order, dstl, inv, dqkv.p + 2 * C, W3));
+            }
+            e.free(dkm); e.free(dvm);
+        } else if (tr > 0) {
             // ToMe (nonfree/tome_unet.py:138-182): keys / values are merged to N - r rows before the attention.  The matching
             // is re-derived (deterministic), the attention adjoint runs against the merged rows, and the merge's adjoint
             // spreads d K_merged / d V_merged back over the original tokens; indices carry no gradient.
@@ -311,7 +332,8 @@ int transformer_bwd(Exec& e, const Tn& x, const Tn& ctx, int S, int ctx_dim, con
 }
 
 void free_trans_save(Exec& e, TransSave& s) {
-    for (auto& b : s.blocks) { e.free(b.h0); e.free(b.n1); e.free(b.h1); e.free(b.n2); e.free(b.h2); e.free(b.n3); e.free(b.a1.ao); e.free(b.a2.ao); }
+    for (auto& b : s.blocks) { e.free(b.h0); e.free(b.n1); e.free(b.h1); e.free(b.n2); e.free(b.h2); e.free(b.n3); e.free(b.a1.ao); e.free(b.a2.ao);
+                                 e.free(b.a1.qk); e.free(b.a1.km); e.free(b.a1.vm); e.free(b.a1.idx); }
     e.free(s.hlast);
     s.blocks.clear();
 }
