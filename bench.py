@@ -191,6 +191,8 @@ def main():
                     help="gyre_debug_gemm_ablation bits for same-box A/B runs of the whole step (0x80 = shortcuts as their own launches, "
                          "0x2000 = three-launch cross-attention; include/gyre_hip.h lists the rest); printed in the line when non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-debug", action="store_true", help="dev: torch.cuda.set_sync_debug_mode('warn') over the timed region - every "
+                    "host-device synchronisation of a step is reported on stderr with the line that caused it")
     ap.add_argument("--trace-markers", action="store_true", help="dev: bracket the timed region with a fill<complex128> launch, the marker "
                     "tools/c5_trace.py / tools/trace_sequence.py cut a rocprofv3 kernel trace at")
     ap.add_argument("--no-class-table", action="store_true", help="skip the extra instrumented step after the timed region")
@@ -384,12 +386,23 @@ def main():
     redo0 = _lib.lib().gyre_debug_attn_redo_count()
     if args.trace_markers:
         torch.full((1,), 1.0, dtype=torch.complex128, device=dev)
+    if args.sync_debug:
+        import traceback, warnings
+        def _show(message, category, filename, lineno, file=None, line=None):
+            if "synchroniz" in str(message):
+                fr = [f for f in traceback.extract_stack()[:-2] if "/torch/" not in f.filename and "warnings" not in f.filename]
+                sys.stderr.write("[sync] " + " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-4:][::-1]) + "\n")
+        warnings.showwarning = _show
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
     t0 = time.perf_counter()
     for i in range(args.steps):
         s0 = time.perf_counter()
         images, latents = step(i)
         torch.cuda.synchronize()
         step_times.append(time.perf_counter() - s0)
+    if args.sync_debug:
+        torch.cuda.set_sync_debug_mode("default")
     barrier()
     elapsed = time.perf_counter() - t0
     if args.trace_markers:

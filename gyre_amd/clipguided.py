@@ -249,6 +249,8 @@ class ClipGuidedMode:
                 s = sigma
             elif sigma.numel() == res.shape[0] and sigma.numel() > 1:
                 s = sigma.reshape(-1, *[1] * (res.ndim - 1)).to(res.device, res.dtype)
+            elif sigma.device.type == "cpu":
+                s = float(sigma.reshape(-1)[0])        # host scalar: no host-to-device copy (a synchronising one from pageable memory)
             else:
                 s = sigma.reshape(-1)[0].to(res.device, res.dtype)
             return res + grads * (s ** 2)

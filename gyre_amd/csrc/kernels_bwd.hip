@@ -809,6 +809,9 @@ __device__ __forceinline__ bf16x8_t lds_frag_t(const bf16_t* tile_t, int ts, int
     return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 // one tile of two row-major [ROWS][D] operands (rows r0 ..) -> registers; then registers -> LDS (row-major + transposed copies)
+// register sets of the request ring of the LDS-tile kernels below (a set = 8 registers per 5 row vectors of a 32-row tile pair)
+#define ABW_WAVES(DS) ((DS) <= 4 ? 2 : 1)       // resident waves per SIMD the LDS-tile kernels are compiled for
+__host__ __device__ constexpr int abw_pf(int DS) { return DS <= 4 ? 4 : (DS <= 6 ? 2 : 1); }
 template <int MAXIT, int ROWS>
 struct AbwTile {
     uint4 a[MAXIT], b[MAXIT];
@@ -849,7 +852,7 @@ struct AbwTile {
 };
 
 template <int NDB, int DS, int RT>
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES(DS), ABW_WAVES(DS)))) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
     constexpr int ROWS = 32 * RT, TS = ROWS + 4;
     constexpr int MAXIT = (ROWS * (DS * 2) + 255) / 256;         // D <= 16 DS -> D/8 <= 2 DS vectors per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -879,22 +882,22 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
 #pragma unroll
     for (int i = 0; i < NDB; ++i) { dk[i] = f32x16_t{}; dv[i] = f32x16_t{}; }
     const int nqb = (p.Nq + ROWS - 1) / ROWS;
-    AbwTile<MAXIT, ROWS> tile;
-    float st_pref = 0.f;
-    auto fetch = [&](int qb) {
+    // Round 6: a ring of PF register sets.  Tile qb + 1 + PF is requested when tile qb + 1 moves from its registers to LDS, so a
+    // request has PF tile computations to arrive (one tile - 14 MFMAs - did not cover an L2 round trip: the loop ran at the load
+    // latency, 2.1 us per 32 query rows, the matrix cores 19 % busy).  Eight registers per set at D = 40.
+    constexpr int PF = abw_pf(DS);
+    AbwTile<MAXIT, ROWS> tiles[PF];
+    float st_pref[PF];
+    auto fetch = [&](int qb, AbwTile<MAXIT, ROWS>& tile, float& sp) {
         tile.fetch(Q, p.ldq, DO, p.lddo, qb * ROWS, p.Nq, D, tid);
-        if (tid < 2 * ROWS) { const int q = qb * ROWS + (tid % ROWS); st_pref = q < p.Nq ? (tid < ROWS ? LSE[q] : DEL[q]) : 0.f; }
+        sp = 0.f;
+        if (tid < 2 * ROWS) { const int q = qb * ROWS + (tid % ROWS); sp = q < p.Nq ? (tid < ROWS ? LSE[q] : DEL[q]) : 0.f; }
     };
-    auto store = [&](int buf) {
+    auto store = [&](int buf, const AbwTile<MAXIT, ROWS>& tile, float sp) {
         tile.store(part(buf, 0), part(buf, 1), part(buf, 2), part(buf, 3), D, tid);
-        if (tid < 2 * ROWS) stats(buf)[tid] = st_pref;            // [0,ROWS) LSE, [ROWS,2 ROWS) delta
+        if (tid < 2 * ROWS) stats(buf)[tid] = sp;            // [0,ROWS) LSE, [ROWS,2 ROWS) delta
     };
-    fetch(0);
-    store(0);
-    __syncthreads();
-    for (int qb = 0; qb < nqb; ++qb) {
-        const int buf = qb & 1;
-        if (qb + 1 < nqb) fetch(qb + 1);
+    auto compute = [&](int qb, int buf) {
         const bf16_t *Qs = part(buf, 0), *DOs = part(buf, 1), *QTs = part(buf, 2), *DOTs = part(buf, 3);
         const float* sts = stats(buf);
 #pragma unroll
@@ -941,8 +944,25 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv_lds(AttnBwdParams p) {
                 }
             }
         }
-        if (qb + 1 < nqb) store(buf ^ 1);
-        __syncthreads();
+    };
+    fetch(0, tiles[0], st_pref[0]);
+    store(0, tiles[0], st_pref[0]);
+#pragma unroll
+    for (int j = 1; j <= PF; ++j)
+        if (j < nqb) fetch(j, tiles[j % PF], st_pref[j % PF]);
+    __syncthreads();
+    for (int qb0 = 0; qb0 < nqb; qb0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int qb = qb0 + j;
+            if (qb < nqb) {                                       // (workgroup-uniform)
+                compute(qb, qb & 1);
+                const int nx = (j + 1) % PF;        // (compile-time after the unroll)                  // register set of tile qb + 1
+                if (qb + 1 < nqb) store((qb + 1) & 1, tiles[nx], st_pref[nx]);
+                if (qb + 1 + PF < nqb) fetch(qb + 1 + PF, tiles[nx], st_pref[nx]);
+                __syncthreads();
+            }
+        }
     }
     if (k0 >= p.Nk) return;
 #pragma unroll
@@ -987,15 +1007,11 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
         qh[i] = ld_frag(Q, p.ldq, q, p.Nq, i * 16 + 8 * hi, D);
         doh[i] = ld_frag(DO, p.lddo, q, p.Nq, i * 16 + 8 * hi, D);
     }
-    AbwTile<MAXIT, ROWS> tile;
+    constexpr int PF = abw_pf(DS);                // request ring, see k_attn_bwd_dkv_lds
+    AbwTile<MAXIT, ROWS> tiles[PF];
     // ---- pass 1: row log-sum-exp (streams K only) ----
     float mx = NEG, sum = 0.f;
-    tile.fetch(K, p.ldk, nullptr, 0, 0, p.Nk, D, tid);
-    tile.store(part(0, 0), nullptr, nullptr, nullptr, D, tid);
-    __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nkb) tile.fetch(K, p.ldk, nullptr, 0, (kb + 1) * ROWS, p.Nk, D, tid);
+    auto pass1 = [&](int kb, int buf) {
         const bf16_t* Ks = part(buf, 0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1017,8 +1033,25 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
             sum = sum * __builtin_amdgcn_exp2f(mx - nm) + ts;
             mx = nm;
         }
-        if (kb + 1 < nkb) tile.store(part(buf ^ 1, 0), nullptr, nullptr, nullptr, D, tid);
-        __syncthreads();
+    };
+    tiles[0].fetch(K, p.ldk, nullptr, 0, 0, p.Nk, D, tid);
+    tiles[0].store(part(0, 0), nullptr, nullptr, nullptr, D, tid);
+#pragma unroll
+    for (int j = 1; j <= PF; ++j)
+        if (j < nkb) tiles[j % PF].fetch(K, p.ldk, nullptr, 0, j * ROWS, p.Nk, D, tid);
+    __syncthreads();
+    for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int kb = kb0 + j;
+            if (kb < nkb) {
+                pass1(kb, kb & 1);
+                const int nx = (j + 1) % PF;        // (compile-time after the unroll)
+                if (kb + 1 < nkb) tiles[nx].store(part((kb + 1) & 1, 0), nullptr, nullptr, nullptr, D, tid);
+                if (kb + 1 + PF < nkb) tiles[nx].fetch(K, p.ldk, nullptr, 0, (kb + 1 + PF) * ROWS, p.Nk, D, tid);
+                __syncthreads();
+            }
+        }
     }
     float lse2;
     {
@@ -1033,12 +1066,7 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
     f32x16_t acc[NDB];
 #pragma unroll
     for (int i = 0; i < NDB; ++i) acc[i] = f32x16_t{};
-    tile.fetch(K, p.ldk, V, p.ldv, 0, p.Nk, D, tid);
-    tile.store(part(0, 0), part(0, 1), part(0, 2), nullptr, D, tid);
-    __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nkb) tile.fetch(K, p.ldk, V, p.ldv, (kb + 1) * ROWS, p.Nk, D, tid);
+    auto pass2 = [&](int kb, int buf) {
         const bf16_t *Ks = part(buf, 0), *Vs = part(buf, 1), *KTs = part(buf, 2);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1068,8 +1096,25 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
                                                                      acc[i], 0, 0, 0);
             }
         }
-        if (kb + 1 < nkb) tile.store(part(buf ^ 1, 0), part(buf ^ 1, 1), part(buf ^ 1, 2), nullptr, D, tid);
-        __syncthreads();
+    };
+    tiles[0].fetch(K, p.ldk, V, p.ldv, 0, p.Nk, D, tid);
+    tiles[0].store(part(0, 0), part(0, 1), part(0, 2), nullptr, D, tid);
+#pragma unroll
+    for (int j = 1; j <= PF; ++j)
+        if (j < nkb) tiles[j % PF].fetch(K, p.ldk, V, p.ldv, j * ROWS, p.Nk, D, tid);
+    __syncthreads();
+    for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int kb = kb0 + j;
+            if (kb < nkb) {
+                pass2(kb, kb & 1);
+                const int nx = (j + 1) % PF;        // (compile-time after the unroll)
+                if (kb + 1 < nkb) tiles[nx].store(part((kb + 1) & 1, 0), part((kb + 1) & 1, 1), part((kb + 1) & 1, 2), nullptr, D, tid);
+                if (kb + 1 + PF < nkb) tiles[nx].fetch(K, p.ldk, V, p.ldv, (kb + 1 + PF) * ROWS, p.Nk, D, tid);
+                __syncthreads();
+            }
+        }
     }
     if (q >= p.Nq) return;
     bf16_t* out = p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D;
@@ -1085,12 +1130,7 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
 }
 
 template <int NDB, int DS, int RT>
-__global__ __launch_bounds__(256) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
-// D <= 48: the body fits 128 registers without spilling, so FOUR workgroups share a CU instead of three - the loop has no software
-// pipelining of its own (LDS fragment reads sit right in front of the MFMAs that use them), more resident waves are what hides them
-template <int NDB, int DS, int RT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_attn_bwd_dq_lds_o4(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
-
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES(DS), ABW_WAVES(DS)))) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
 bool attn_bwd_needs_transposes(int D) { return D > 160; }
 size_t attn_bwd_stats_bytes(int B, int H, int Nq) {
     const size_t npad = (size_t)(Nq + 31) / 32 * 32;
@@ -1119,7 +1159,6 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     GYRE_LAUNCH_CHECK();
     if (lds_path) {
         const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : 3));
-        static const bool occ3 = getenv("GYRE_ABW_OCC3") != nullptr;        // tuning: the three-workgroups-per-CU build of the dQ kernel
         // 32-row LDS tiles: 64-row tiles (RT = 2) were measured slower (2.71 vs 2.14 ms at N = 4096, D = 40: fewer resident
         // workgroups outweigh the halved barrier count)
         const size_t lds = 2 * attn_bwd_stage_bytes(p.D, 1);
@@ -1134,7 +1173,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
             GYRE_LAUNCH_CHECK();                                                                                      \
         } while (0)
         switch (sel) {
-            case 0: if (occ3) GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); else GYRE_ABW_GO((k_attn_bwd_dq_lds_o4<2, 3, 1>), gq); break;
+            case 0: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); break;
             case 1: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 4, 1>), gq); break;
             case 2: GYRE_ABW_GO((k_attn_bwd_dq_lds<3, 6, 1>), gq); break;
             default: GYRE_ABW_GO((k_attn_bwd_dq_lds<5, 10, 1>), gq); break;
