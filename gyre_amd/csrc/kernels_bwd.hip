@@ -13,6 +13,7 @@
 //   k_conv_weight_t / k_transpose                            W^T operands of the data-gradient GEMMs / convs
 // Gradients are NHWC bf16 like the activations; every reduction accumulates in fp32 in a fixed order.
 #include "kernels.h"
+#include <type_traits>
 #include "gemm_shared.h"
 
 // ------------------------------------------------------------------------------
@@ -1131,9 +1132,337 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
 
 template <int NDB, int DS, int RT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES(DS), ABW_WAVES(DS)))) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
+
+// ==========================================================================================================================
+// Round 6: the same two kernels on an LDS-DMA ring with transposing LDS reads - head dims whose rows are an ODD number of 16-byte
+// vectors up to 48 (D = 40: the 64 x 64 self-attentions of SD1.x, 85 % of config 5's attention-backward time).
+//   * the streamed side arrives by global_load_lds (no registers, no staging stores): a stage = one 64-row tile pair, row-major
+//     and contiguous ([64][D], 80-byte rows at D = 40: conflict-free 16-byte column reads) + the row statistics; NS = 4 stages,
+//     three tiles in flight behind counted vmcnt waits, one barrier per 64 rows (28 / 20 MFMAs per wave) instead of one per 32;
+//   * the second products' operands (dO^T, Q^T, K^T fragments in the permuted row order of the 32x32x16 result layout) come
+//     straight out of the row-major tile through ds_read_b64_tr_b16 (each 16-lane group transposes a [4 rows][16 columns] block:
+//     lane c hands in the address of row c / 4, columns 4 (c % 4) .. + 3 and receives column c of the four rows), so the
+//     transposed LDS copies - sixteen 2-byte stores per lane and tile - are gone;
+//   * rows past the end: the request is clamped to the last row (finite data) and the statistics make it vanish - the dQ kernel
+//     leaves log-sum-exp = 1e30 on the pad rows of the 64-row statistics arrays, so P = 2^(s - 1e30) = 0 there; ragged KEY tiles keep
+//     the masked form of the dQ kernel, and need nothing in the dK / dV kernel (a key past the end only feeds its own, unwritten, row);
+//   * LDS is zeroed once: the 16-byte column reads of the last k-step run past column D (zero B operand, but 0 x NaN = NaN).
+// ==========================================================================================================================
+typedef short abw_v4s __attribute__((ext_vector_type(4)));
+template <int D> struct Abw2 {
+    static_assert(D % 8 == 0 && D <= 48 && ((D / 8) & 1), "odd number of 16-byte vectors per row");
+    static constexpr int NV = D / 8, RS = D;                  // slots / elements per LDS row
+    static constexpr int DS = (D + 15) / 16, NDB = (D + 31) / 32;
+    static constexpr int TILE = 64 * NV * 16;                 // bytes of a 64-row tile = NV wave-wide 16-byte DMA instructions
+    static constexpr int OFF_A = 512, OFF_B = 512 + TILE, OFF_PAD = 512 + 2 * TILE, OFF_DUMP = OFF_PAD + 256;
+    static constexpr int STAGE = OFF_DUMP + 256;              // [lse 64 | delta 64][tile A][tile B][zero pad][dump of the filler requests]
+    static constexpr int NS = 4;
+};
+__device__ __forceinline__ void abw_dma16(const void* src, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+}
+__device__ __forceinline__ void abw_dma4(const void* src, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory");
+}
+// fragment of the transposed operand for MFMA step (rows t .. t + 3 and t + 8 .. t + 11 of this lane's 16-lane group's block)
+__device__ __forceinline__ bf16x8_t abw_tr_frag(const char* lane_base, int byte_off, int rs_bytes) {
+    typedef __attribute__((address_space(3))) abw_v4s* lp;
+    const abw_v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lane_base + byte_off));
+    const abw_v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lane_base + byte_off + 8 * rs_bytes));
+    struct { abw_v4s x, y; } both = {a, b};
+    return __builtin_bit_cast(bf16x8_t, both);
+}
+
+__device__ __forceinline__ float abw_keep(bf16x8_t v) { const uint4 u = __builtin_bit_cast(uint4, v); return __builtin_bit_cast(float, u.x ^ u.y ^ u.z ^ u.w); }
+// ABL (timing experiments, wrong results): 1 no softmax arithmetic, 2 no second products, 4 no requests inside the loop, 8 no barrier / wait
+template <int D, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_attn_bwd_dkv_dma(AttnBwdParams p) {
+    using T = Abw2<D>;
+    constexpr int DS = T::DS, NDB = T::NDB, RS = T::RS, NV = T::NV, NS = T::NS, STAGE = T::STAGE;
+    constexpr int PPW = (2 * NV + 2 + 3) / 4;                 // requests per wave and tile (fillers make it the same for every wave)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    const float* LSE = p.lse + ((size_t)b * p.H + h) * p.NqPad;
+    const float* DEL = p.delta + ((size_t)b * p.H + h) * p.NqPad;
+    for (int i = tid; i < NS * STAGE / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    const int key = k0 + col;
+    bf16x8_t kh[DS], vh[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+        kh[i] = ld_frag(K, p.ldk, key, p.Nk, i * 16 + 8 * hi, D);
+        vh[i] = ld_frag(V, p.ldv, key, p.Nk, i * 16 + 8 * hi, D);
+    }
+    // this lane's part of request i of a tile: wave-instruction id = wave + 4 i; ids [0, NV) tile A (Q), [NV, 2 NV) tile B (dO):
+    // slot n = 64 id' + lane of the tile -> row n / NV, vector n % NV
+    int prow[PPW]; const char* pbase[PPW]; unsigned pld[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int id = wave + 4 * i;
+        const bool second = id >= NV;
+        const int n = (second ? id - NV : id) * 64 + lane;
+        prow[i] = n / NV;
+        pbase[i] = (const char*)((second ? DO : Q) + (n % NV) * 8);
+        pld[i] = (unsigned)(second ? p.lddo : p.ldq) * 2u;
+    }
+    const int ntiles = (p.Nq + 63) / 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int t, int slot) {
+        const unsigned sb = lds0 + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int id = wave + 4 * i;                           // (wave-uniform: scalar branches)
+            if (t < ntiles && id < 2 * NV) {
+                const int r = min(t * 64 + prow[i], p.Nq - 1);
+                abw_dma16(pbase[i] + (size_t)((unsigned)r * pld[i]), sb + (id < NV ? T::OFF_A + id * 1024 : T::OFF_B + (id - NV) * 1024));
+            } else if (t < ntiles && id < 2 * NV + 2) {
+                abw_dma4((id == 2 * NV ? LSE : DEL) + t * 64 + lane, sb + (id - 2 * NV) * 256);
+            } else {
+                abw_dma4(LSE + lane, sb + T::OFF_DUMP);            // filler: keeps the vmcnt arithmetic the same in every wave and at the tail
+            }
+        }
+    };
+    f32x16_t dk[NDB], dv[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) { dk[i] = f32x16_t{}; dv[i] = f32x16_t{}; }
+    // lane part of the transposing reads: row (c >> 2) + 4 hi, columns 16 ((lane >> 4) & 1) + 4 (c & 3), c = lane & 15
+    const int tr_lane = (((lane & 15) >> 2) + 4 * hi) * RS * 2 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    // a USE of the loop-invariant fragments in front of the loop: hipcc's wait-count pass puts the wait for their loads at the first
+    // use, and inside the loop that is an s_waitcnt vmcnt(0) on every trip - it drains the request ring (seen in the ISA)
+#pragma unroll
+    for (int i = 0; i < DS; ++i) asm volatile("" : "+v"(kh[i]), "+v"(vh[i]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t, t);
+    for (int t = 0; t < ntiles; ++t) {
+        if (!(ABL & 8)) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (!(ABL & 4)) issue(t + NS - 1, (t + NS - 1) % NS);
+        const char* stg = smem + (t % NS) * STAGE;
+        const float* sts = (const float*)stg;
+        const bf16_t *Qs = (const bf16_t*)(stg + T::OFF_A), *DOs = (const bf16_t*)(stg + T::OFF_B);
+        const char *qtr = stg + T::OFF_A + tr_lane, *dotr = stg + T::OFF_B + tr_lane;
+        // (A hand-pipelined order - both halves' S / dP products first, every transposing read a phase ahead of its MFMA, the softmax
+        // of one half between MFMA groups of the other - needs 221 registers, i.e. two waves per SIMD instead of three, and measured
+        // 614 - 638 us against 585: the loop is bound by LDS reads - 44 KB per wave and tile for 28 MFMAs, one operand fragment per
+        // MFMA is what a 32-key wave tile costs - and more resident waves overlap the three pipes better than a longer schedule.
+        // Ablations, `tools/abw_abl.sh`: no softmax arithmetic -81 us, no second products -106, no transposing reads -56, no
+        // statistics reads -43, no requests -76; the first-product skeleton alone 293 us.)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16_t s = {}, dp = {};
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                const bf16x8_t qa = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Qs + (rt * 32 + col) * RS + i * 16 + 8 * hi));
+                const bf16x8_t da = __builtin_bit_cast(bf16x8_t, *(const uint4*)(DOs + (rt * 32 + col) * RS + i * 16 + 8 * hi));
+                s = GYRE_MFMA_32x32x16(qa, kh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(da, vh[i], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = rt * 32 + 8 * g + 4 * hi;
+                float4 l4, d4;
+                if (ABL & 32) { l4 = make_float4(p.alpha, p.beta, p.alpha, p.beta); d4 = l4; }
+                else { l4 = *(const float4*)(sts + ql); d4 = *(const float4*)(sts + 64 + ql); }
+                const float l[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ABL & 1) { s[4 * g + r] += l[r]; dp[4 * g + r] += dl[r]; continue; }
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[4 * g + r], p.alpha, -l[r]));
+                    s[4 * g + r] = pr;
+                    dp[4 * g + r] = pr * (dp[4 * g + r] - dl[r]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8_t pf = pack_frag(s, m), dsf = pack_frag(dp, m);
+#pragma unroll
+                for (int i = 0; i < NDB; ++i) {
+                    const int off = (rt * 32 + 16 * m) * RS * 2 + i * 64;
+                    const bf16x8_t dof = (ABL & 16) ? pf : abw_tr_frag(dotr, off, RS * 2);
+                    const bf16x8_t qf = (ABL & 16) ? dsf : abw_tr_frag(qtr, off, RS * 2);
+                    if (ABL & 2) { dv[i][m] += abw_keep(pf) + abw_keep(dof); dk[i][m] += abw_keep(dsf) + abw_keep(qf); continue; }
+                    dv[i] = GYRE_MFMA_32x32x16(pf, dof, dv[i], 0, 0, 0);
+                    dk[i] = GYRE_MFMA_32x32x16(dsf, qf, dk[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the filler requests still in flight target this workgroup's LDS
+    if (k0 >= p.Nk) return;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) {
+        const int d = i * 32 + col;
+        if (d >= D) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (kk < p.Nk) {
+                p.dk[((size_t)b * p.Nk + kk) * p.lddk + h * D + d] = f32_to_bf16(dk[i][r] * p.beta);
+                p.dv[((size_t)b * p.Nk + kk) * p.lddv + h * D + d] = f32_to_bf16(dv[i][r]);
+            }
+        }
+    }
+}
+
+// dQ in ONE pass over the keys (the register-staged kernel streams K twice: a log-sum-exp pass, then the products): the row
+// normalisation is linear in the accumulator - dQ = (1 / l) sum_k 2^(s_k - m) (dP_k - delta) K_k with l = sum_k 2^(s_k - m) for ANY
+// reference m - so the kernel keeps a reference per query, accumulates against it and divides at the end, like the forward kernel's
+// output; the reference is re-centred (accumulators and l rescaled, wave-uniform branch) on the first tile and whenever a score
+// exceeds it by more than 2^RECENTRE (p <= 2^20: harmless in fp32 sums and in the bf16 dS operand) - in practice once per row.
+// Lanes l and l + 32 hold the same query (different keys of the tile) and meet in the MFMA contraction, so they share the reference.
+// The row log-sum-exp m + log2(l) goes to p.lse for the dK / dV kernel.  26 -> 20 MFMAs and half the exponentials per 64 keys.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_attn_bwd_dq_dma(AttnBwdParams p) {
+    using T = Abw2<D>;
+    constexpr int DS = T::DS, NDB = T::NDB, RS = T::RS, NV = T::NV, NS = T::NS, STAGE = T::STAGE;
+    constexpr int PPW = (2 * NV + 3) / 4;
+    constexpr float RECENTRE = 20.f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bf16_t* Q = p.q + (size_t)b * p.Nq * p.ldq + h * D;
+    const bf16_t* K = p.k + (size_t)b * p.Nk * p.ldk + h * D;
+    const bf16_t* V = p.v + (size_t)b * p.Nk * p.ldv + h * D;
+    const bf16_t* DO = p.d_o + (size_t)b * p.Nq * p.lddo + h * D;
+    for (int i = tid; i < NS * STAGE / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+    const int q = q0 + col;
+    const size_t stat = ((size_t)b * p.H + h) * p.NqPad + q;
+    const int ntiles = (p.Nk + 63) / 64;
+    bf16x8_t qh[DS], doh[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+        qh[i] = ld_frag(Q, p.ldq, q, p.Nq, i * 16 + 8 * hi, D);
+        doh[i] = ld_frag(DO, p.lddo, q, p.Nq, i * 16 + 8 * hi, D);
+    }
+    float delta = q < p.Nq ? p.delta[stat] : 0.f;
+    int prow[PPW]; const char* pbase[PPW]; unsigned pld[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int id = wave + 4 * i;
+        const bool second = id >= NV;
+        const int n = (second ? id - NV : id) * 64 + lane;
+        prow[i] = n / NV;
+        pbase[i] = (const char*)((second ? V : K) + (n % NV) * 8);
+        pld[i] = (unsigned)(second ? p.ldv : p.ldk) * 2u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const char* filler = (const char*)(p.delta + ((size_t)b * p.H + h) * p.NqPad);
+    auto issue = [&](int t, int slot) {
+        const unsigned sb = lds0 + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int id = wave + 4 * i;                           // (wave-uniform: scalar branches)
+            if (t < ntiles && id < 2 * NV) {
+                const int r = min(t * 64 + prow[i], p.Nk - 1);
+                abw_dma16(pbase[i] + (size_t)((unsigned)r * pld[i]), sb + (id < NV ? T::OFF_A + id * 1024 : T::OFF_B + (id - NV) * 1024));
+            } else {
+                abw_dma4(filler + lane * 4, sb + T::OFF_DUMP);     // filler: the same vmcnt arithmetic in every wave and at the tail
+            }
+        }
+    };
+    f32x16_t acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) acc[i] = f32x16_t{};
+    float mref = -1e30f, lsum = 0.f;
+    const int tr_lane = (((lane & 15) >> 2) + 4 * hi) * RS * 2 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) asm volatile("" : "+v"(qh[i]), "+v"(doh[i]));      // (see k_attn_bwd_dkv_dma)
+    asm volatile("" : "+v"(delta));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t, t);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(t + NS - 1, (t + NS - 1) % NS);
+        const char* stg = smem + (t % NS) * STAGE;
+        const bf16_t *Ks = (const bf16_t*)(stg + T::OFF_A), *Vs = (const bf16_t*)(stg + T::OFF_B);
+        const char* ktr = stg + T::OFF_A + tr_lane;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            f32x16_t s = {}, dp = {};
+#pragma unroll
+            for (int i = 0; i < DS; ++i) {
+                const bf16x8_t ka = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Ks + (rt * 32 + col) * RS + i * 16 + 8 * hi));
+                const bf16x8_t va = __builtin_bit_cast(bf16x8_t, *(const uint4*)(Vs + (rt * 32 + col) * RS + i * 16 + 8 * hi));
+                s = GYRE_MFMA_32x32x16(ka, qh[i], s, 0, 0, 0);
+                dp = GYRE_MFMA_32x32x16(va, doh[i], dp, 0, 0, 0);
+            }
+            const bool whole = t * 64 + rt * 32 + 32 <= p.Nk;       // (wave-uniform)
+            float tmx = -1e30f;
+            if (whole) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] *= p.alpha; tmx = fmaxf(tmx, s[r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    s[r] = key < p.Nk ? s[r] * p.alpha : -1e30f;
+                    tmx = fmaxf(tmx, s[r]);
+                }
+            }
+            tmx = fmaxf(tmx, __shfl_xor(tmx, 32));
+            if (__any(tmx > mref + RECENTRE)) {
+                const float nm = fmaxf(mref, tmx);                  // (a lane whose row is fine moves too: any reference is exact)
+                const float sc = __builtin_amdgcn_exp2f(mref - nm);
+                mref = nm; lsum *= sc;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(s[r] - mref);          // masked keys: 2^(-1e30 - m) = 0
+                lsum += pr;
+                s[r] = pr * (dp[r] - delta);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8_t dsf = pack_frag(s, m);
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+                    acc[i] = GYRE_MFMA_32x32x16(abw_tr_frag(ktr, (rt * 32 + 16 * m) * RS * 2 + i * 64, RS * 2), dsf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the filler requests still in flight target this workgroup's LDS
+    lsum += __shfl_xor(lsum, 32);
+    if (hi == 0 && q < p.NqPad) p.lse[stat] = q < p.Nq ? mref + __builtin_amdgcn_logf(lsum) : 1e30f;      // pad rows: P = 0 in the dK / dV kernel
+    if (q >= p.Nq) return;
+    const float fin = p.beta / lsum;
+    bf16_t* out = p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = i * 32 + 8 * g + 4 * hi;
+            if (d < D)
+                *(uint2*)(out + d) = make_uint2(pack_bf16x2(acc[i][4 * g] * fin, acc[i][4 * g + 1] * fin),
+                                                pack_bf16x2(acc[i][4 * g + 2] * fin, acc[i][4 * g + 3] * fin));
+        }
+}
+
 bool attn_bwd_needs_transposes(int D) { return D > 160; }
 size_t attn_bwd_stats_bytes(int B, int H, int Nq) {
-    const size_t npad = (size_t)(Nq + 31) / 32 * 32;
+    const size_t npad = (size_t)(Nq + 63) / 64 * 64;     // 64-row tiles of the LDS-DMA kernels
     return 2 * (((size_t)B * H * npad * 4 + 255) & ~(size_t)255);
 }
 int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
@@ -1143,7 +1472,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     const bool lds_path = !attn_bwd_needs_transposes(p.D);
     if (!lds_path && (!p.kt || p.ldkt < (p.Nk + 31) / 32 * 32 || (p.dk && (!p.qt || !p.d_ot || p.ldqt < (p.Nq + 31) / 32 * 32))))
         GYRE_FAIL(-1, "attention_bwd: transposed operands need token strides padded to a multiple of 32");
-    p.NqPad = (p.Nq + 31) / 32 * 32;
+    p.NqPad = (p.Nq + 63) / 64 * 64;
     const size_t half = ((size_t)p.B * p.H * p.NqPad * 4 + 255) & ~(size_t)255;
     p.lse = (float*)p.stats; p.delta = (float*)((char*)p.stats + half);
     const float sc = 1.0f / sqrtf((float)p.D);
@@ -1157,6 +1486,30 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
     const size_t nd = (size_t)p.B * p.Nq * p.H;
     hipLaunchKernelGGL(k_attn_bwd_delta, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, p);
     GYRE_LAUNCH_CHECK();
+    static const bool no_dma = getenv("GYRE_ABW_NO_DMA") != nullptr;      // tuning / A-B: the register-staged kernels for D = 40 too
+    if (p.D == 40 && !no_dma) {
+        const size_t lds = (size_t)Abw2<40>::NS * Abw2<40>::STAGE;
+        const dim3 gq((unsigned)((p.Nq + 127) / 128), p.H, p.B), gk((unsigned)((p.Nk + 127) / 128), p.H, p.B);
+        hipLaunchKernelGGL((k_attn_bwd_dq_dma<40>), gq, dim3(256), lds, st, p);
+        GYRE_LAUNCH_CHECK();
+        if (!p.dk) return 0;
+        static const int abl = getenv("GYRE_ABW_ABL") ? atoi(getenv("GYRE_ABW_ABL")) : 0;     // timing experiments only
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 1>), gk, dim3(256), lds, st, p); break;
+            case 2: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 2>), gk, dim3(256), lds, st, p); break;
+            case 3: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 3>), gk, dim3(256), lds, st, p); break;
+            case 4: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 4>), gk, dim3(256), lds, st, p); break;
+            case 12: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 12>), gk, dim3(256), lds, st, p); break;
+            case 16: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 16>), gk, dim3(256), lds, st, p); break;
+            case 32: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 32>), gk, dim3(256), lds, st, p); break;
+            case 48: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 48>), gk, dim3(256), lds, st, p); break;
+            case 63: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 63>), gk, dim3(256), lds, st, p); break;
+            case 15: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 15>), gk, dim3(256), lds, st, p); break;
+            default: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40>), gk, dim3(256), lds, st, p); break;
+        }
+        GYRE_LAUNCH_CHECK();
+        return 0;
+    }
     if (lds_path) {
         const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : 3));
         // 32-row LDS tiles: 64-row tiles (RT = 2) were measured slower (2.71 vs 2.14 ms at N = 4096, D = 40: fewer resident

@@ -93,15 +93,30 @@ def test_geglu_bwd(M_, F_):
 @pytest.mark.parametrize("B,heads,Nq,Nk,D,cross,presc", [
     (2, 2, 64, 64, 40, 0, 1), (1, 8, 100, 100, 40, 0, 1), (2, 4, 96, 77, 80, 1, 1), (1, 2, 256, 256, 160, 0, 1),
     (2, 3, 130, 130, 64, 0, 0), (1, 1, 144, 144, 512, 0, 0), (1, 5, 1024, 1024, 64, 0, 1), (2, 8, 1024, 77, 40, 1, 1),
-    (1, 1, 33, 33, 8, 0, 0)])
+    (1, 1, 33, 33, 8, 0, 0),
+    # the LDS-DMA kernels of D = 40 (round 6): ragged query and key tiles, keys != queries (ToMe), not prescaled, many key tiles
+    (1, 2, 1000, 840, 40, 0, 0), (1, 1, 200, 4100, 40, 0, 1), (2, 2, 65, 127, 40, 0, 1), (1, 3, 128, 64, 40, 0, 1)])
 def test_attention_bwd(B, heads, Nq, Nk, D, cross, presc):
     """dq / dk / dv of softmax(q k^T / sqrt(D)) v.  With k_prescaled the kernel is handed k' = k * log2(e)/sqrt(D) (what
     the UNet's to_k weights produce) and returns the gradient with respect to k'."""
+    _attention_bwd_case(B, heads, Nq, Nk, D, cross, presc)
+
+
+def test_attention_bwd_large_logits_recentre_the_single_pass_dq_kernel():
+    """Scores tens of log2 units apart and growing along the key axis: the one-pass dQ kernel of D = 40 re-centres its reference
+    several times per row (kernels_bwd.hip k_attn_bwd_dq_dma, RECENTRE = 20) - same gradients as autograd."""
+    _attention_bwd_case(1, 2, 192, 640, 40, 0, 1, qscale=6.0, ramp=True)
+
+
+def _attention_bwd_case(B, heads, Nq, Nk, D, cross, presc, qscale=1.0, ramp=False):
     L = _lib.lib()
     C_ = heads * D
     c = math.log2(math.e) / math.sqrt(D)
-    q = bf16_round(randn(B, Nq, C_, seed=1))
-    k_in = bf16_round(randn(B, Nk, C_, seed=2) * (c if presc else 1.0))     # what the kernel sees
+    q = bf16_round(randn(B, Nq, C_, seed=1) * qscale)
+    kk = randn(B, Nk, C_, seed=2)
+    if ramp:                                                              # later keys score higher: the running reference keeps moving
+        kk = kk * torch.linspace(0.2, 2.0, Nk).view(1, Nk, 1)
+    k_in = bf16_round(kk * (c if presc else 1.0))     # what the kernel sees
     v = bf16_round(randn(B, Nk, C_, seed=3))
     d_o = bf16_round(randn(B, Nq, C_, seed=4))
     qr, kr, vr = q.clone().requires_grad_(), k_in.clone().requires_grad_(), v.clone().requires_grad_()
@@ -121,7 +136,7 @@ def test_attention_bwd(B, heads, Nq, Nk, D, cross, presc):
                                        vp(dev_bf16(d_o)), C_, B, heads, Nq, Nk, D, presc, vp(ws), need, vp(dq), C_,
                                        vp(dk), C_, vp(dv), C_))
     release_kept()
-    tag = f"attn_bwd B{B} h{heads} {Nq}x{Nk} D{D} presc{presc}"
+    tag = f"attn_bwd B{B} h{heads} {Nq}x{Nk} D{D} presc{presc}" + (" large logits" if ramp else "")
     report(tag + " dq", dq.float().cpu(), rq, 2e-2)
     if not cross:
         report(tag + " dk", dk.float().cpu(), rk, 2e-2)
