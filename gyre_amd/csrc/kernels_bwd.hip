@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 // normalisation is linear in the accumulator - dQ = (1 / l) sum_k 2^(s_k - m) (dP_k - delta) K_k with l = sum_k 2^(s_k - m) for ANY
 // reference m - so the kernel keeps a reference per query, accumulates against it and divides at the end, like the forward kernel's
 // output; the reference is re-centred (accumulators and l rescaled, wave-uniform branch) on the first tile and whenever a score
-// exceeds it by more than 2^RECENTRE (p <= 2^20: harmless in fp32 sums and in the bf16 dS operand) - in practice once per row.
+// exceeds it by more than 2^RECENTRE (p <= 2^20: harmless in fp32 sums and in the bf16 dS operand; 2^8 in the fp16 build) - in practice once per row.
 // Lanes l and l + 32 hold the same query (different keys of the tile) and meet in the MFMA contraction, so they share the reference.
 // The row log-sum-exp m + log2(l) goes to p.lse for the dK / dV kernel.  26 -> 20 MFMAs and half the exponentials per 64 keys.
 template <int D>
@@ -1328,7 +1328,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     using T = Abw2<D>;
     constexpr int DS = T::DS, NDB = T::NDB, RS = T::RS, NV = T::NV, NS = T::NS, STAGE = T::STAGE;
     constexpr int PPW = (2 * NV + 3) / 4;
+#ifdef GYRE_STORE_F16
+    constexpr float RECENTRE = 8.f;      // dS = p (dP - delta) is an fp16 MFMA operand: p <= 2^8 leaves |dP - delta| < 255 before 65504
+#else
     constexpr float RECENTRE = 20.f;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
