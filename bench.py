@@ -550,8 +550,9 @@ def main():
                 "inpaint768": f"SD1.5 grafted inpaint {size}x{size} (9-ch inpaint UNet + base UNet, hires fix, VAE encode), {n_steps} steps "
                               f"DPM++2M ({evals} UNet evals), batch={B}, {args.dtype} (BASELINE.json configs[2])",
                 "tomeclip": f"SD1.5 txt2img {size}x{size}, ToMe r={args.tome_r} + CLIP guidance (scale {args.clip_scale}, guided base, 2 + 2 "
-                            f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch, bf16), {n_steps} steps DPM++2M ({evals} UNet "
-                            f"evals incl. the differentiated stems), batch={B}, {args.dtype} (BASELINE.json configs[4])"}[args.config],
+                            f"cut-outs, every step guided; random-init ViT-B/32 in host PyTorch, bf16), {n_steps} steps DPM++2M ({evals} sampler-level "
+                            f"UNet evals incl. the differentiated stems: per guided step ONE activation-keeping native pass over cat[uncond, cond] + the "
+                            f"reverse sweep of its conditional half), batch={B}, {args.dtype} (BASELINE.json configs[4])"}[args.config],
                        "images_per_step": sum(sizes), "images_per_rank": sizes, "parallelism": f"dp{world}",
                        "dist_backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen,
                        "rank_devices": rank_devices,

@@ -95,6 +95,7 @@ _SIGS = {
     "gyre_unet_vjp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp, _i, _vp, _i, _vp]),
     "gyre_unet_vjp_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i, _vp]),
     "gyre_unet_vjp_finish": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
+    "gyre_unet_vjp_finish_range": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i]),
     "gyre_unet_vjp_pending": (_i, [_vp]),
     "gyre_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(_vp)]),
     "gyre_vae_destroy": (None, [_vp]),

@@ -188,20 +188,35 @@ class ClipGuidedMode:
         return self.flatloss
 
     # ---- noise-prediction level (wrap_guidance_unet, :180-265) ----
-    def wrap_guidance_unet(self, unet_g, unet_u, child, guidance_scale: float):
+    def wrap_guidance_unet(self, unet_g, unet_u, child, guidance_scale: float, unet_both=None):
         """unet_g / unet_u: conditional / unconditional noise predictors (x, t) -> eps; child: their plain CFG combination
-        (what the wrapped mode would have built).  unet_u None = no classifier-free guidance."""
+        (what the wrapped mode would have built).  unet_u None = no classifier-free guidance.
+        unet_both: optional predictor over cat[uncond, cond] embeddings (the parallel CFG binding).  The reference evaluates the
+        conditional stem under autograd and, once the gradient is there, the unconditional one on the SAME latents and timestep
+        (:218-241): with unet_both the two are one call on cat[x, x] - the unconditional half is used detached and only the
+        conditional half is differentiated (modules.grad_samples), same values as the two calls."""
         diffusers_style = isinstance(self.scheduler, S.DiffusersScheduler)
-        g_cache: List[Tensor] = []
+        g_cache: list = []
 
         def fork(latents, t):                            # k-diffusion samplers (:218-241)
             if self._guided_stem_only:
+                if unet_both is not None:
+                    from .modules import grad_samples
+                    n = latents.shape[0]
+                    t2 = torch.cat([t, t]) if isinstance(t, torch.Tensor) and t.shape else t
+                    with grad_samples(n, n):
+                        both = unet_both(torch.cat([latents, latents]), t2)
+                    noise_pred_u, noise_pred_g = both.chunk(2)
+                    g_cache.append((noise_pred_g, noise_pred_u.detach()))
+                    return noise_pred_g
                 noise_pred_g = unet_g(latents, t)
-                g_cache.append(noise_pred_g)
+                g_cache.append((noise_pred_g, None))
                 return noise_pred_g
             if g_cache:
-                noise_pred_g = g_cache.pop().detach()
-                noise_pred_u = unet_u(latents, t)
+                noise_pred_g, noise_pred_u = g_cache.pop()
+                noise_pred_g = noise_pred_g.detach()
+                if noise_pred_u is None:
+                    noise_pred_u = unet_u(latents, t)
                 return noise_pred_u + guidance_scale * (noise_pred_g - noise_pred_u)
             return child(latents, t)
 

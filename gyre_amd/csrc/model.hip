@@ -297,7 +297,14 @@ int gyre_unet_vjp_finish(gyre_unet* h, void* st, const void* d_eps, int ddt, voi
     if (!h || !d_eps || !dx_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
     for (int d : {ddt, dxdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
     g_launches = 0;
-    return gyre_unet_vjp_reverse(*h, (hipStream_t)st, d_eps, ddt, dx_out, dxdt);
+    return gyre_unet_vjp_reverse(*h, (hipStream_t)st, d_eps, ddt, dx_out, dxdt, 0, h->vjp.B);
+}
+int gyre_unet_vjp_finish_range(gyre_unet* h, void* st, const void* d_eps, int ddt, void* dx_out, int dxdt, int b0, int nb) {
+    if (!h || !d_eps || !dx_out) GYRE_FAIL(GYRE_ERR_INVALID, "null argument");
+    for (int d : {ddt, dxdt}) if (d < 0 || d > 2) GYRE_FAIL(GYRE_ERR_INVALID, "bad dtype");
+    if (h->vjp.valid && (b0 < 0 || nb < 1 || b0 + nb > h->vjp.B)) GYRE_FAIL(GYRE_ERR_INVALID, "vjp_finish_range: samples outside the pending batch");
+    g_launches = 0;
+    return gyre_unet_vjp_reverse(*h, (hipStream_t)st, d_eps, ddt, dx_out, dxdt, b0, nb);
 }
 
 int gyre_vae_create(const gyre_vae_cfg* cfg, int device, gyre_vae** out) {

@@ -304,7 +304,7 @@ struct CtxKV { bf16_t* k; bf16_t* vt; };
 // ao: attention output before the out projection.  ToMe self-attention also keeps what the merge produced - Q|K rows, merged K / V rows
 // and the matching (order, destination list) - so the reverse sweep neither re-projects nor re-matches (round 6: 0.2 ms per 64 x 64
 // block of the guided step; 288 GB of HBM make the recomputation's memory saving worthless)
-struct MhaSave { Tn ao, qk, km, vm, idx; };
+struct MhaSave { Tn ao, qk, km, vm, idx; int idx_B = 0, idx_b0 = 0; };      // idx_B: batch the index arrays were laid out for; idx_b0: first sample of a narrowed sweep
 struct ResSave { Tn h1; };                                   // conv1 output (input of the second GroupNorm)
 struct TBlockSave { Tn h0, n1, h1, n2, h2, n3; MhaSave a1, a2; };   // block input, LN outputs, residual stream after each attention
 struct TransSave { std::vector<TBlockSave> blocks; Tn hlast; };     // hlast: residual stream entering proj_out
@@ -693,7 +693,7 @@ struct Exec {
                 TRY(launch_tome_merge(st, tp));
             }
             free(tws); free(vrow);
-            if (sv) { sv->vm = vm; sv->idx = idx; }
+            if (sv) { sv->vm = vm; sv->idx = idx; sv->idx_B = B; sv->idx_b0 = 0; }
             qp = q.p; kp = km.p; vtp = vt.p; ldq = 2 * C; ldk = C;
         } else if (!cross) {  // self attention: fused Q|K projection, V projected straight into V^T
             Nk = Nq; ldvt = (Nk + 7) / 8 * 8;
@@ -1554,6 +1554,6 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
                       void* dx_out, int dxdt, const float* temb_add);
 int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x, int xdt, const int64_t* t, const void* ctx, int cdt,
                           int B, int H, int W, int S, void* ws, size_t ws_bytes, void* eps_out, int odt, const float* temb_add);
-int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt);
+int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt, int b0, int nb);
 int gyre_vae_run_decode_vjp(gyre_vae& v, bool dry, hipStream_t st, const void* z, int zdt, int B, int h_, int w_, const void* d_img,
                             int ddt, void* ws, size_t wsb, void* img_out, int odt, void* dz_out, int dzdt);

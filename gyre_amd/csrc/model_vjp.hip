@@ -177,9 +177,11 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
             TRY(e.alloc(dkm, B, nout, 1, C));
             TRY(e.alloc(dvm, B, nout, 1, C));
             if (!e.dry()) {
-                int* order = (int*)sv.idx.p;
-                int* dstl = order + (((size_t)B * half + 63) & ~(size_t)63);
-                int* inv = dstl + (((size_t)B * half + 63) & ~(size_t)63);
+                // (index arrays laid out for the forward pass's batch; a narrowed sweep starts at its first sample)
+                const size_t seg = ((size_t)(sv.idx_B ? sv.idx_B : B) * half + 63) & ~(size_t)63;
+                int* order = (int*)sv.idx.p + (size_t)sv.idx_b0 * half;
+                int* dstl = order + seg;
+                int* inv = dstl + seg;
                 a.k = sv.km.p; a.ldk = C; a.v = sv.vm.p; a.ldv = C; a.Nk = nout; a.kt = nullptr; a.ldkt = ldkm;
                 a.dk = dkm.p; a.lddk = C; a.dv = dvm.p; a.lddv = C;
                 TRY(launch_attention_bwd(e.st, a));
@@ -462,13 +464,42 @@ int gyre_unet_vjp_forward(gyre_unet& u, bool dry, hipStream_t st, const void* x,
 }
 
 // Reverse half: d_x = (d eps / d x)^T d_eps from the state gyre_unet_vjp_forward left behind
-int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt) {
+// Samples [b0, b0 + nb) of every kept activation (batch-major NHWC: a pointer offset; offsets / sizes of the arena bookkeeping stay)
+static void narrow_tn(Tn& t, int fullB, int b0, int nb) {
+    if (!t.valid() || t.B != fullB) return;
+    if (t.p) t.p += (size_t)b0 * t.H * t.W * t.C;
+    t.B = nb;
+    t.cs = nullptr; t.cs_chunks = 0;                   // (producer statistics are not used by the sweep)
+}
+static void narrow_state(UNetVjpState& V, int b0, int nb) {
+    const int fb = V.B;
+    auto node = [&](UNetVjpNode& nd) {
+        for (Tn* t : {&nd.x, &nd.skip, &nd.r, &nd.out, &nd.rs.h1, &nd.ts.hlast}) narrow_tn(*t, fb, b0, nb);
+        for (auto& b : nd.ts.blocks) {
+            for (Tn* t : {&b.h0, &b.n1, &b.h1, &b.n2, &b.h2, &b.n3, &b.a1.ao, &b.a2.ao, &b.a1.qk, &b.a1.km, &b.a1.vm}) narrow_tn(*t, fb, b0, nb);
+            b.a1.idx_b0 = b0;
+        }
+    };
+    for (auto& nd : V.downs) node(nd);
+    for (auto& nd : V.ups) node(nd);
+    node(V.midn); node(V.mid1n);
+    for (auto& t : V.skips) narrow_tn(t, fb, b0, nb);
+    narrow_tn(V.h, fb, b0, nb);
+    narrow_tn(V.cx, fb, b0, nb);
+    V.B = nb;
+}
+int gyre_unet_vjp_reverse(gyre_unet& u, hipStream_t st, const void* d_eps, int ddt, void* dx_out, int dxdt, int b0, int nb) {
     UNetVjpState& V = u.vjp;
     if (!V.valid) GYRE_FAIL(GYRE_ERR_INVALID, "unet vjp: no forward state pending (another call on this handle ran in between)");
     V.valid = false;                                   // one reverse sweep per forward: gradients are freed as they are consumed
     const gyre_unet_cfg& c = u.cfg;
     Exec& e = u.ex;
     const bool dry = V.dry;
+    if (nb != V.B) {
+        if (V.B < 2 || b0 < 0 || nb < 1 || b0 + nb > V.B) GYRE_FAIL(GYRE_ERR_INVALID, "unet vjp: sample range outside the pending batch");
+        narrow_state(V, b0, nb);
+        e.batch = nb;
+    }
     const int B = V.B, H = V.H, W = V.W, S = V.S, D = c.cross_attention_dim;
     e.st = st;
     std::vector<UNetVjpNode>&downs = V.downs, &ups = V.ups;
@@ -536,7 +567,7 @@ int gyre_unet_run_vjp(gyre_unet& u, bool dry, hipStream_t st, const void* x, int
                       int B, int H, int W, int S, const void* d_eps, int ddt, void* ws, size_t ws_bytes, void* eps_out, int odt,
                       void* dx_out, int dxdt, const float* temb_add) {
     TRY(gyre_unet_vjp_forward(u, dry, st, x, xdt, t, ctx, cdt, B, H, W, S, ws, ws_bytes, eps_out, odt, temb_add));
-    return gyre_unet_vjp_reverse(u, st, d_eps, ddt, dx_out, dxdt);
+    return gyre_unet_vjp_reverse(u, st, d_eps, ddt, dx_out, dxdt, 0, B);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -399,7 +399,8 @@ class GyreHipUNet(_NativeModule):
         if torch.is_grad_enabled() and sample.requires_grad:
             if residuals is not None:
                 raise NotImplementedError("input gradients through ControlNet residuals (CLIP guidance + ControlNet)")
-            out = _UNetInputGrad.apply(sample, self, h, t, encoder_hidden_states, added_cond_kwargs)
+            out = _UNetInputGrad.apply(sample, self, h, t, encoder_hidden_states, added_cond_kwargs,
+                                       getattr(_HINTS, "grad_samples", None))
         else:
             with torch.no_grad():
                 out = self._forward_native(h, sample, t, encoder_hidden_states, added_cond_kwargs, residuals)
@@ -508,12 +509,26 @@ class GyreHipUNet(_NativeModule):
         self._vjp_pending = token = (object(), eps)
         return token
 
-    def _vjp_finish(self, h, sample, d_out):
+    def _vjp_finish(self, h, sample, d_out, grad_samples=None):
+        """Reverse sweep on the pending forward state; grad_samples = (b0, nb): only those samples' cotangent is non-zero by the
+        caller's statement (modules.grad_samples) - the sweep runs on them alone, the other samples' gradient is zero."""
         dev = sample.device
+        self._vjp_pending = None
+        if grad_samples is not None and tuple(grad_samples) != (0, sample.shape[0]):
+            b0, nb = grad_samples
+            g = d_out[b0:b0 + nb].contiguous()
+            _lib.require_gpu_tensor(g, "d_eps")
+            dx = torch.zeros_like(sample)
+            part = torch.empty_like(sample[b0:b0 + nb])
+            with torch.cuda.device(dev):
+                _lib.check(self._L().gyre_unet_vjp_finish_range(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(g.data_ptr()),
+                                                                 _lib.dtype_code(g), C.c_void_p(part.data_ptr()), _lib.dtype_code(part),
+                                                                 int(b0), int(nb)))
+            dx[b0:b0 + nb] = part
+            return dx
         g = d_out.contiguous()
         _lib.require_gpu_tensor(g, "d_eps")
         dx = torch.empty_like(sample)
-        self._vjp_pending = None
         with torch.cuda.device(dev):
             _lib.check(self._L().gyre_unet_vjp_finish(C.c_void_p(h), C.c_void_p(_lib.stream_ptr(dev)), C.c_void_p(g.data_ptr()),
                                                        _lib.dtype_code(g), C.c_void_p(dx.data_ptr()), _lib.dtype_code(dx)))
@@ -553,8 +568,8 @@ class _UNetInputGrad(torch.autograd.Function):
     handle in between, backward recomputes through the one-shot gyre_unet_vjp instead."""
 
     @staticmethod
-    def forward(fctx, sample, module, h, t, enc, added):
-        fctx.module, fctx.h, fctx.added = module, h, added
+    def forward(fctx, sample, module, h, t, enc, added, grad_samples=None):
+        fctx.module, fctx.h, fctx.added, fctx.grad_samples = module, h, added, grad_samples
         fctx.save_for_backward(sample.detach(), t, enc.detach())
         fctx.token = module._vjp_begin(h, sample.detach(), t, enc.detach(), added)
         return fctx.token[1]
@@ -564,13 +579,33 @@ class _UNetInputGrad(torch.autograd.Function):
         sample, t, enc = fctx.saved_tensors
         m = fctx.module
         if getattr(m, "_vjp_pending", None) is fctx.token and m._L().gyre_unet_vjp_pending(C.c_void_p(fctx.h)):
-            return m._vjp_finish(fctx.h, sample, d_out), None, None, None, None, None
-        # state dropped by another call on the handle (gyre_unet_vjp_pending == 0): recompute in one shot
+            return m._vjp_finish(fctx.h, sample, d_out, fctx.grad_samples), None, None, None, None, None, None
+        # state dropped by another call on the handle (gyre_unet_vjp_pending == 0): recompute in one shot (whole batch: the
+        # cotangent of the other samples is zero)
         _, dx = m._vjp_native(fctx.h, sample, t, enc, fctx.added, d_out)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 _HINTS = threading.local()
+
+
+class grad_samples:
+    """``with grad_samples(b0, nb): eps = unet(x.requires_grad_(), ...)`` - the caller states that only samples [b0, b0 + nb) of the
+    result will receive a cotangent (the others are used detached): the native reverse sweep then runs on those samples alone
+    (include/gyre_hip.h gyre_unet_vjp_finish_range).  The CLIP-guided mode evaluates cat[uncond, cond] in one activation-keeping
+    pass and differentiates the conditional half (gyre_amd/clipguided.py).  Ignored by modules without a native sweep."""
+
+    def __init__(self, b0: int, nb: int):
+        self.rng = (int(b0), int(nb))
+
+    def __enter__(self):
+        self.prev = getattr(_HINTS, "grad_samples", None)
+        _HINTS.grad_samples = self.rng
+        return self
+
+    def __exit__(self, *exc):
+        _HINTS.grad_samples = self.prev
+        return False
 
 
 class cfg_pairs:

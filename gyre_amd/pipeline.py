@@ -286,9 +286,15 @@ class GyrePipeline:
         leaf.clip_mode = clip_mode
         if clip_mode is not None:       # ClipGuidedMode.wrap_guidance_unet over the conditional / unconditional stems
             cfg = guidance_scale > 1.0
+            both_unet = None
+            if cfg and cfg_execution != "sequential":      # one activation-keeping pass over cat[uncond, cond] per guided step
+                both_added = None
+                if added_cond is not None:
+                    both_added = {k: torch.cat([uncond_added_cond[k], added_cond[k]]) for k in added_cond}
+                both_unet = bind(cfg_embeddings["both"], both_added)
             leaf.eps_unet = clip_mode.wrap_guidance_unet(bind(text_embeddings, added_cond),
                                                          bind(uncond_embeddings, uncond_added_cond) if cfg else None,
-                                                         leaf.eps_unet, guidance_scale)
+                                                         leaf.eps_unet, guidance_scale, unet_both=both_unet)
 
     def _generate_leaf_latents(self, leaf, sched, generators, fill_strength):
         """Mode.generateLatents: txt2img noise, or (init sample, optional shaped-noise fill, noise) for an init image."""

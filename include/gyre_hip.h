@@ -214,6 +214,12 @@ int gyre_unet_vjp_begin(gyre_unet* h, void* stream, const void* x_nchw, int x_dt
                         const void* ctx, int ctx_dtype, int B, int H, int W, int S, void* workspace, size_t workspace_bytes,
                         void* eps_out_nchw, int out_dtype, const float* temb_add);
 int gyre_unet_vjp_finish(gyre_unet* h, void* stream, const void* d_eps_nchw, int d_eps_dtype, void* dx_out_nchw, int dx_dtype);
+/* _finish for samples [b0, b0 + nb) of the pending forward pass only: d_eps / dx_out hold nb samples.  The reference's guided mode
+ * differentiates the conditional evaluation and needs the unconditional one of the same latents right after
+ * (unet/clipguided.py:218-241): one activation-keeping pass over cat[uncond, cond] (batch 2B) + the reverse sweep of the
+ * conditional half replaces a batch-B keeping pass and a batch-B plain pass (SD1.5 + ToMe, B = 8: 19.8 against 12.6 + 11.7 ms). */
+int gyre_unet_vjp_finish_range(gyre_unet* h, void* stream, const void* d_eps_nchw, int d_eps_dtype, void* dx_out_nchw, int dx_dtype,
+                               int b0, int nb);
 
 /* Parity tests only: the next forward copies the named intermediate activation (f32, NCHW) into out.  Names follow
  * the oracle's taps: "down<i>" (end of down level i, after its downsampler), "mid", "up<i>" (end of up level i, after

@@ -212,6 +212,37 @@ def test_tiny_unet_vjp_with_tome(r):
     assert float((plain - got).abs().max()) > 1e-4          # merging really changed the gradient
 
 
+@pytest.mark.parametrize("r", [0, 40])
+def test_reverse_sweep_of_a_sample_range_of_the_kept_batch(r):
+    """gyre_unet_vjp_finish_range (modules.grad_samples): ONE activation-keeping pass over cat[uncond, cond] and the reverse sweep of
+    the conditional half = the keeping pass + sweep of the conditional half alone (what the guided mode ran before) and the plain
+    pass of the unconditional half; the other samples get a zero gradient.  With and without token merging (whose index arrays are
+    laid out for the full batch)."""
+    from gyre_amd.modules import grad_samples
+    cfg = gcfg.tiny_unet()
+    net, sd = _unet(cfg)
+    net.set_tome(r)
+    x1 = randn(2, 4, 16, 16, seed=1)
+    x = torch.cat([x1, x1]).to(DEV)                       # the CFG layout: both halves carry the same latents
+    t = torch.tensor([981, 17, 981, 17]).to(DEV)
+    ctx = randn(4, 77, cfg.cross_attention_dim, seed=2).to(DEV)
+    cot = randn(2, 4, 16, 16, seed=3).to(DEV)
+    xa = x[2:].clone().requires_grad_()
+    eps_a = net(xa, t[2:], encoder_hidden_states=ctx[2:].contiguous()).sample
+    (dx_a,) = torch.autograd.grad(eps_a, xa, cot)
+    with torch.no_grad():
+        eps_u = net(x[:2], t[:2], encoder_hidden_states=ctx[:2].contiguous()).sample
+    xb = x.clone().requires_grad_()
+    with grad_samples(2, 2):
+        eps_b = net(xb, t, encoder_hidden_states=ctx).sample
+    (dx_b,) = torch.autograd.grad(eps_b[2:], xb, cot)
+    report(f"range sweep tome {r}: eps of the differentiated half", eps_b[2:].detach().float().cpu(), eps_a.detach().float().cpu(), 2e-2)
+    report(f"range sweep tome {r}: eps of the detached half", eps_b[:2].detach().float().cpu(), eps_u.float().cpu(), 2e-2)
+    report(f"range sweep tome {r}: d_x", dx_b[2:].float().cpu(), dx_a.float().cpu(), 3e-2)
+    assert float(dx_b[:2].abs().max()) == 0.0
+    net.set_tome(0)
+
+
 def test_tiny_vae_decode_vjp():
     cfg = gcfg.tiny_vae()
     sd = weights.synthetic_state_dict(weights.vae_param_shapes(cfg), 0)
