@@ -60,6 +60,21 @@ def test_guidance_runs_and_changes_the_image(tiny, sampler, extra):
     assert torch.equal(guided, again)                                    # per-image generators: reproducible
 
 
+def test_one_call_over_both_cfg_halves_equals_the_two_calls_of_the_reference(tiny):
+    """Guided base, k-diffusion sampler: the reference evaluates the conditional stem under autograd and then the unconditional stem on
+    the same latents (clipguided.py:218-241).  With the parallel CFG binding the host mode makes ONE call on cat[x, x] /
+    cat[uncond, cond] and differentiates the conditional half (wrap_guidance_unet(unet_both=...)); with the sequential binding it
+    makes the reference's two calls.  Same images (fp32 oracle UNet: batch 2B vs B only reorders nothing inside a sample)."""
+    pipe, kw, ids = make(tiny)
+    one = pipe(sampler="dpmpp_2m", clip_guidance_scale=0.5, clip_input_ids=ids, **kw)
+    loss_one = list(pipe.last_clip_modes[0].lossavg)
+    two = pipe(sampler="dpmpp_2m", clip_guidance_scale=0.5, clip_input_ids=ids, cfg_execution="sequential", **kw)
+    loss_two = list(pipe.last_clip_modes[0].lossavg)
+    assert len(loss_one) == len(loss_two) >= 4
+    assert max(abs(a - b) for a, b in zip(loss_one, loss_two)) < 1e-4
+    assert float((one - two).abs().max()) < 2e-3, float((one - two).abs().max())
+
+
 def test_guidance_follows_the_dtype_the_clip_model_was_loaded_in(tiny):
     """The reference feeds its CLIP model tensors of the pipeline's own (fp16) dtype (clipguided.py:400-404); here the decoded image is
     fp32 and is cast to the model's dtype, the loss stays fp32: a bf16 CLIP model guides like the fp32 one, up to bf16 noise."""
