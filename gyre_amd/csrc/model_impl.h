@@ -797,6 +797,7 @@ struct Exec {
             TRY(launch_attention(st, a));
         }
         if (sv && tr > 0) { sv->qk = q; sv->km = km; q = Tn(); km = Tn(); }
+        else if (sv && cross) { sv->qk = q; q = Tn(); }       // the reverse sweep's S = Q K^T recomputation starts from the kept Q
         free(q); free(k); free(vt); free(km); free(nrm);
         TRY(alloc(out, B, xq.H, xq.W, C));
         TRY(linear(ao.p, C, nullptr, 0, 0, B * Nq, C, w.wo, C, w.bo, residual.p, C, 0, out.p, C, rs_out));

@@ -133,14 +133,17 @@ int mha_bwd(Exec& e, const Tn& xq, bool cross, const bf16_t* kvsrc, int S, int k
     a.kt = kt.p; a.ldkt = ldkt;
     TRY(e.alloc(d_xq, B, xq.H, xq.W, C));
     if (cross) {
-        TRY(e.alloc(qkv, B, xq.H, xq.W, C));
-        TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wq, C, w.bq, nullptr, 0, 0, qkv.p, C));
+        const bool kept_q = sv.qk.valid() && sv.qk.C == C;            // the forward pass kept to_q's output
+        if (!kept_q) {
+            TRY(e.alloc(qkv, B, xq.H, xq.W, C));
+            TRY(e.linear(xq.p, C, nullptr, 0, 0, M, C, w.wq, C, w.bq, nullptr, 0, 0, qkv.p, C));
+        }
         TRY(e.alloc(kc, B, Nk, 1, C));
         TRY(e.linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wk, C, w.bk, nullptr, 0, 0, kc.p, C));
         TRY(e.alloc(vc, B, Nk, 1, C));
         TRY(e.linear(kvsrc, kv_dim, nullptr, 0, 0, B * Nk, kv_dim, w.wv, C, w.bv, nullptr, 0, 0, vc.p, C));
         TRY(e.alloc(dqkv, B, xq.H, xq.W, C));
-        a.q = qkv.p; a.ldq = C; a.k = kc.p; a.ldk = C; a.v = vc.p; a.ldv = C;
+        a.q = kept_q ? sv.qk.p : qkv.p; a.ldq = C; a.k = kc.p; a.ldk = C; a.v = vc.p; a.ldv = C;
         a.dq = dqkv.p; a.lddq = C; a.dk = nullptr; a.dv = nullptr; a.qt = nullptr; a.d_ot = nullptr; a.ldqt = ldqt;
         if (!e.dry()) {
             if (need_t) TRY(launch_transpose(e.st, kc.p, C, Nk, C, kt.p, ldkt, B, (size_t)Nk * C, (size_t)C * ldkt));
@@ -335,7 +338,7 @@ int transformer_bwd(Exec& e, const Tn& x, const Tn& ctx, int S, int ctx_dim, con
 
 void free_trans_save(Exec& e, TransSave& s) {
     for (auto& b : s.blocks) { e.free(b.h0); e.free(b.n1); e.free(b.h1); e.free(b.n2); e.free(b.h2); e.free(b.n3); e.free(b.a1.ao); e.free(b.a2.ao);
-                                 e.free(b.a1.qk); e.free(b.a1.km); e.free(b.a1.vm); e.free(b.a1.idx); }
+                                 e.free(b.a1.qk); e.free(b.a1.km); e.free(b.a1.vm); e.free(b.a1.idx); e.free(b.a2.qk); }
     e.free(s.hlast);
     s.blocks.clear();
 }
@@ -476,7 +479,7 @@ static void narrow_state(UNetVjpState& V, int b0, int nb) {
     auto node = [&](UNetVjpNode& nd) {
         for (Tn* t : {&nd.x, &nd.skip, &nd.r, &nd.out, &nd.rs.h1, &nd.ts.hlast}) narrow_tn(*t, fb, b0, nb);
         for (auto& b : nd.ts.blocks) {
-            for (Tn* t : {&b.h0, &b.n1, &b.h1, &b.n2, &b.h2, &b.n3, &b.a1.ao, &b.a2.ao, &b.a1.qk, &b.a1.km, &b.a1.vm}) narrow_tn(*t, fb, b0, nb);
+            for (Tn* t : {&b.h0, &b.n1, &b.h1, &b.n2, &b.h2, &b.n3, &b.a1.ao, &b.a2.ao, &b.a1.qk, &b.a1.km, &b.a1.vm, &b.a2.qk}) narrow_tn(*t, fb, b0, nb);
             b.a1.idx_b0 = b0;
         }
     };
