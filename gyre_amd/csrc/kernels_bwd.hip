@@ -811,7 +811,8 @@ __device__ __forceinline__ bf16x8_t lds_frag_t(const bf16_t* tile_t, int ts, int
 }
 // one tile of two row-major [ROWS][D] operands (rows r0 ..) -> registers; then registers -> LDS (row-major + transposed copies)
 // register sets of the request ring of the LDS-tile kernels below (a set = 8 registers per 5 row vectors of a 32-row tile pair)
-#define ABW_WAVES(DS) ((DS) <= 4 ? 2 : 1)       // resident waves per SIMD the LDS-tile kernels are compiled for
+#define ABW_WAVES(DS) ((DS) <= 4 ? 2 : 1)       // resident waves per SIMD the LDS-tile dK / dV kernels are compiled for
+#define ABW_WAVES_DQ(DS) ((DS) <= 6 ? 2 : 1)    // ... the dQ kernels (no dK / dV accumulators: D = 80 fits two)
 __host__ __device__ constexpr int abw_pf(int DS) { return DS <= 4 ? 4 : (DS <= 6 ? 2 : 1); }
 template <int MAXIT, int ROWS>
 struct AbwTile {
@@ -1131,7 +1132,7 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
 }
 
 template <int NDB, int DS, int RT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES(DS), ABW_WAVES(DS)))) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES_DQ(DS), ABW_WAVES_DQ(DS)))) void k_attn_bwd_dq_lds(AttnBwdParams p) { abw_dq_lds_body<NDB, DS, RT>(p); }
 
 // ==========================================================================================================================
 // Round 6: the same two kernels on an LDS-DMA ring with transposing LDS reads - head dims whose rows are an ODD number of 16-byte
