@@ -1011,60 +1011,15 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
     }
     constexpr int PF = abw_pf(DS);                // request ring, see k_attn_bwd_dkv_lds
     AbwTile<MAXIT, ROWS> tiles[PF];
-    // ---- pass 1: row log-sum-exp (streams K only) ----
-    float mx = NEG, sum = 0.f;
-    auto pass1 = [&](int kb, int buf) {
-        const bf16_t* Ks = part(buf, 0);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            f32x16_t s = {};
-#pragma unroll
-            for (int i = 0; i < DS; ++i)
-                s = GYRE_MFMA_32x32x16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
-            float tmx = NEG;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                s[r] = key < p.Nk ? s[r] * p.alpha : NEG;
-                tmx = fmaxf(tmx, s[r]);
-            }
-            const float nm = fmaxf(mx, tmx);
-            float ts = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ts += __builtin_amdgcn_exp2f(s[r] - nm);
-            sum = sum * __builtin_amdgcn_exp2f(mx - nm) + ts;
-            mx = nm;
-        }
-    };
-    tiles[0].fetch(K, p.ldk, nullptr, 0, 0, p.Nk, D, tid);
-    tiles[0].store(part(0, 0), nullptr, nullptr, nullptr, D, tid);
-#pragma unroll
-    for (int j = 1; j <= PF; ++j)
-        if (j < nkb) tiles[j % PF].fetch(K, p.ldk, nullptr, 0, j * ROWS, p.Nk, D, tid);
-    __syncthreads();
-    for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int kb = kb0 + j;
-            if (kb < nkb) {
-                pass1(kb, kb & 1);
-                const int nx = (j + 1) % PF;        // (compile-time after the unroll)
-                if (kb + 1 < nkb) tiles[nx].store(part((kb + 1) & 1, 0), nullptr, nullptr, nullptr, D, tid);
-                if (kb + 1 + PF < nkb) tiles[nx].fetch(K, p.ldk, nullptr, 0, (kb + 1 + PF) * ROWS, p.Nk, D, tid);
-                __syncthreads();
-            }
-        }
-    }
-    float lse2;
-    {
-        const float omx = __shfl_xor(mx, 32), osum = __shfl_xor(sum, 32);
-        const float nm = fmaxf(mx, omx);
-        sum = sum * __builtin_amdgcn_exp2f(mx - nm) + osum * __builtin_amdgcn_exp2f(omx - nm);
-        lse2 = nm + __builtin_amdgcn_logf(sum);
-        if (hi == 0 && q < p.Nq) p.lse[stat] = lse2;
-    }
     const float delta = q < p.Nq ? p.delta[stat] : 0.f;
-    // ---- pass 2: dQ^T[d][q] += K^T[d][keys] dS^T[keys][q] ----
+    // ---- ONE pass (round 6, as k_attn_bwd_dq_dma): dQ^T[d][q] += K^T[d][keys] dS^T[keys][q] against a running reference, divided
+    // by the row sum at the end; the separate log-sum-exp pass over K is gone ----
+#ifdef GYRE_STORE_F16
+    constexpr float RECENTRE = 8.f;
+#else
+    constexpr float RECENTRE = 20.f;
+#endif
+    float mref = NEG, lsum = 0.f;
     f32x16_t acc[NDB];
 #pragma unroll
     for (int i = 0; i < NDB; ++i) acc[i] = f32x16_t{};
@@ -1078,16 +1033,33 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
                 s = GYRE_MFMA_32x32x16(lds_frag(Ks, rs, rt * 32 + col, i * 16 + 8 * hi, D), qh[i], s, 0, 0, 0);
                 dp = GYRE_MFMA_32x32x16(lds_frag(Vs, rs, rt * 32 + col, i * 16 + 8 * hi, D), doh[i], dp, 0, 0, 0);
             }
+            float tmx = NEG;
             if (kb * ROWS + rt * 32 + 32 <= p.Nk) {          // whole key tile: no per-element range test
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.alpha, -lse2)) * (dp[r] - delta);
+                for (int r = 0; r < 16; ++r) { s[r] *= p.alpha; tmx = fmaxf(tmx, s[r]); }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb * ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(fmaf(s[r], p.alpha, -lse2)) : 0.f;
-                    s[r] = pr * (dp[r] - delta);
+                    s[r] = key < p.Nk ? s[r] * p.alpha : NEG;
+                    tmx = fmaxf(tmx, s[r]);
                 }
+            }
+            tmx = fmaxf(tmx, __shfl_xor(tmx, 32));          // lanes l and l + 32 hold the same query: one reference
+            if (__any(tmx > mref + RECENTRE)) {
+                const float nm = fmaxf(mref, tmx);
+                const float sc = __builtin_amdgcn_exp2f(mref - nm);
+                mref = nm; lsum *= sc;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= sc;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(s[r] - mref);          // masked keys: 2^(-1e30 - m) = 0
+                lsum += pr;
+                s[r] = pr * (dp[r] - delta);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -1118,7 +1090,10 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
             }
         }
     }
+    lsum += __shfl_xor(lsum, 32);
+    if (hi == 0 && q < p.NqPad) p.lse[stat] = q < p.Nq ? mref + __builtin_amdgcn_logf(lsum) : 1e30f;
     if (q >= p.Nq) return;
+    const float fin = p.beta / lsum;
     bf16_t* out = p.dq + ((size_t)b * p.Nq + q) * p.lddq + h * D;
 #pragma unroll
     for (int i = 0; i < NDB; ++i)
@@ -1126,8 +1101,8 @@ __device__ __forceinline__ void abw_dq_lds_body(const AttnBwdParams& p) {
         for (int g = 0; g < 4; ++g) {
             const int d = i * 32 + 8 * g + 4 * hi;
             if (d < D)
-                *(uint2*)(out + d) = make_uint2(pack_bf16x2(acc[i][4 * g] * p.beta, acc[i][4 * g + 1] * p.beta),
-                                                pack_bf16x2(acc[i][4 * g + 2] * p.beta, acc[i][4 * g + 3] * p.beta));
+                *(uint2*)(out + d) = make_uint2(pack_bf16x2(acc[i][4 * g] * fin, acc[i][4 * g + 1] * fin),
+                                                pack_bf16x2(acc[i][4 * g + 2] * fin, acc[i][4 * g + 3] * fin));
         }
 }
 
