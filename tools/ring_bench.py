@@ -52,10 +52,11 @@ for (M, K, N, res) in SHAPES:
 
 # 3x3 convs of the UNet (batch 16) and of the VAE decoder
 from gpu_util import repack_conv
+CB = int(os.environ.get("CONV_BATCH", "16"))          # batch of the UNet convs below (8: the reverse sweep of config 5)
 CONVS = [(16, 64, 320, 320), (16, 64, 640, 320), (16, 32, 640, 640), (16, 32, 1280, 640), (16, 16, 1280, 1280), (16, 16, 2560, 1280), (16, 8, 1280, 1280),
          (16, 32, 320, 640), (16, 16, 640, 1280), (16, 32, 1920, 640), (16, 64, 960, 320), (4, 128, 512, 512), (2, 256, 256, 256)]
 if os.environ.get("CONVS", "1") == "1":
-    for (B, H, Ci, Co) in CONVS:
+    for (B, H, Ci, Co) in [((CB if B_ == 16 else B_), H_, Ci_, Co_) for (B_, H_, Ci_, Co_) in CONVS]:
         x = randn(B, H, H, Ci, seed=5).to(torch.bfloat16).to(DEV)
         w = repack_conv(randn(Co, Ci, 3, 3, seed=6) / math.sqrt(9 * Ci)); b = repack_bias(randn(Co, seed=7))
         y = torch.empty(B, H, H, Co, dtype=torch.bfloat16, device=DEV)
