@@ -1473,7 +1473,8 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
         hipLaunchKernelGGL((k_attn_bwd_dq_dma<40>), gq, dim3(256), lds, st, p);
         GYRE_LAUNCH_CHECK();
         if (!p.dk) return 0;
-        static const int abl = getenv("GYRE_ABW_ABL") ? atoi(getenv("GYRE_ABW_ABL")) : 0;     // timing experiments only
+#ifdef GYRE_ABW_ABLATIONS       // timing experiments (tools/abw_abl.sh; build the library with -DGYRE_ABW_ABLATIONS): wrong results by design
+        static const int abl = getenv("GYRE_ABW_ABL") ? atoi(getenv("GYRE_ABW_ABL")) : 0;
         switch (abl) {
             case 1: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 1>), gk, dim3(256), lds, st, p); break;
             case 2: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 2>), gk, dim3(256), lds, st, p); break;
@@ -1487,6 +1488,9 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
             case 15: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40, 15>), gk, dim3(256), lds, st, p); break;
             default: hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40>), gk, dim3(256), lds, st, p); break;
         }
+#else
+        hipLaunchKernelGGL((k_attn_bwd_dkv_dma<40>), gk, dim3(256), lds, st, p);
+#endif
         GYRE_LAUNCH_CHECK();
         return 0;
     }
