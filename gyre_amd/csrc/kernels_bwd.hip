@@ -811,7 +811,7 @@ __device__ __forceinline__ bf16x8_t lds_frag_t(const bf16_t* tile_t, int ts, int
 }
 // one tile of two row-major [ROWS][D] operands (rows r0 ..) -> registers; then registers -> LDS (row-major + transposed copies)
 // register sets of the request ring of the LDS-tile kernels below (a set = 8 registers per 5 row vectors of a 32-row tile pair)
-#define ABW_WAVES(DS) ((DS) <= 4 ? 2 : 1)       // resident waves per SIMD the LDS-tile dK / dV kernels are compiled for
+#define ABW_WAVES(DS) ((DS) <= 5 ? 2 : 1)       // resident waves per SIMD the LDS-tile dK / dV kernels are compiled for
 #define ABW_WAVES_DQ(DS) ((DS) <= 6 ? 2 : 1)    // ... the dQ kernels (no dK / dV accumulators: D = 80 fits two)
 __host__ __device__ constexpr int abw_pf(int DS) { return DS <= 4 ? 4 : (DS <= 6 ? 2 : 1); }
 template <int MAXIT, int ROWS>
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ABW_WAVES(D
     // Round 6: a ring of PF register sets.  Tile qb + 1 + PF is requested when tile qb + 1 moves from its registers to LDS, so a
     // request has PF tile computations to arrive (one tile - 14 MFMAs - did not cover an L2 round trip: the loop ran at the load
     // latency, 2.1 us per 32 query rows, the matrix cores 19 % busy).  Eight registers per set at D = 40.
-    constexpr int PF = abw_pf(DS);
+    constexpr int PF = DS == 5 ? 1 : abw_pf(DS);        // (D = 80: one set keeps the kernel at two waves per SIMD without spilling)
     AbwTile<MAXIT, ROWS> tiles[PF];
     float st_pref[PF];
     auto fetch = [&](int qb, AbwTile<MAXIT, ROWS>& tile, float& sp) {
@@ -1495,7 +1495,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
         return 0;
     }
     if (lds_path) {
-        const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 96 ? 2 : 3));
+        const int sel = p.D <= 48 ? 0 : (p.D <= 64 ? 1 : (p.D <= 80 ? 4 : (p.D <= 96 ? 2 : 3)));      // 4: D = 80 with five k-steps (the 32 x 32 level)
         // 32-row LDS tiles: 64-row tiles (RT = 2) were measured slower (2.71 vs 2.14 ms at N = 4096, D = 40: fewer resident
         // workgroups outweigh the halved barrier count)
         const size_t lds = 2 * attn_bwd_stage_bytes(p.D, 1);
@@ -1513,6 +1513,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
             case 0: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 3, 1>), gq); break;
             case 1: GYRE_ABW_GO((k_attn_bwd_dq_lds<2, 4, 1>), gq); break;
             case 2: GYRE_ABW_GO((k_attn_bwd_dq_lds<3, 6, 1>), gq); break;
+            case 4: GYRE_ABW_GO((k_attn_bwd_dq_lds<3, 5, 1>), gq); break;
             default: GYRE_ABW_GO((k_attn_bwd_dq_lds<5, 10, 1>), gq); break;
         }
         if (!p.dk) return 0;
@@ -1520,6 +1521,7 @@ int launch_attention_bwd(hipStream_t st, AttnBwdParams p) {
             case 0: GYRE_ABW_GO((k_attn_bwd_dkv_lds<2, 3, 1>), gk); break;
             case 1: GYRE_ABW_GO((k_attn_bwd_dkv_lds<2, 4, 1>), gk); break;
             case 2: GYRE_ABW_GO((k_attn_bwd_dkv_lds<3, 6, 1>), gk); break;
+            case 4: GYRE_ABW_GO((k_attn_bwd_dkv_lds<3, 5, 1>), gk); break;
             default: GYRE_ABW_GO((k_attn_bwd_dkv_lds<5, 10, 1>), gk); break;
         }
 #undef GYRE_ABW_GO

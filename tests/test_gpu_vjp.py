@@ -95,7 +95,8 @@ def test_geglu_bwd(M_, F_):
     (2, 3, 130, 130, 64, 0, 0), (1, 1, 144, 144, 512, 0, 0), (1, 5, 1024, 1024, 64, 0, 1), (2, 8, 1024, 77, 40, 1, 1),
     (1, 1, 33, 33, 8, 0, 0),
     # the LDS-DMA kernels of D = 40 (round 6): ragged query and key tiles, keys != queries (ToMe), not prescaled, many key tiles
-    (1, 2, 1000, 840, 40, 0, 0), (1, 1, 200, 4100, 40, 0, 1), (2, 2, 65, 127, 40, 0, 1), (1, 3, 128, 64, 40, 0, 1)])
+    (1, 2, 1000, 840, 40, 0, 0), (1, 1, 200, 4100, 40, 0, 1), (2, 2, 65, 127, 40, 0, 1), (1, 3, 128, 64, 40, 0, 1),
+    (2, 2, 200, 160, 80, 0, 1), (1, 2, 96, 96, 96, 0, 0)])      # D = 80 (five k-steps) and D = 96 (six) self-attention
 def test_attention_bwd(B, heads, Nq, Nk, D, cross, presc):
     """dq / dk / dv of softmax(q k^T / sqrt(D)) v.  With k_prescaled the kernel is handed k' = k * log2(e)/sqrt(D) (what
     the UNet's to_k weights produce) and returns the gradient with respect to k'."""
