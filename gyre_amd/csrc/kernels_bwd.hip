@@ -1234,7 +1234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         // 614 - 638 us against 585: the loop is bound by LDS reads - 44 KB per wave and tile for 28 MFMAs, one operand fragment per
         // MFMA is what a 32-key wave tile costs - and more resident waves overlap the three pipes better than a longer schedule.
         // Ablations, `tools/abw_abl.sh`: no softmax arithmetic -81 us, no second products -106, no transposing reads -56, no
-        // statistics reads -43, no requests -76; the first-product skeleton alone 293 us.)
+        // statistics reads -43, no requests -76; the first-product skeleton alone 293 us.  A 64-keys-per-wave form - every fragment
+        // feeding two MFMAs, 198 VGPRs + 192 AGPRs, ONE wave per SIMD - halves the LDS reads and measured 720 us against 603.)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             f32x16_t s = {}, dp = {};
